@@ -1,0 +1,153 @@
+/*
+ * rgbm.h -- C-ABI of librepairgbm.so: the MI355X-native (HIP, gfx950) repair-model engine.
+ *
+ * The reference (maropu/spark-data-repair-plugin) has no FFI of its own: its seam for this hot
+ * path is the scikit-learn estimator protocol that python/repair/train.py and
+ * python/repair/model.py drive against LightGBM 3.3.1.  Each entry point below names the
+ * reference interface it replaces (paths relative to /root/reference).  The Python side binds
+ * these with ctypes (spark-data-repair-plugin_amd/repair/gbm.py); INTEGRATION.md shows the stub
+ * a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every array is caller-owned, plain pointers + sizes, never retained after return;
+ *   - feature matrices are int32 label codes, COLUMN-MAJOR ([column][row]); code -1 (or any code
+ *     outside [0, n_codes)) means NULL / unknown category == LightGBM's NaN;
+ *   - return 0 on success, negative on error; rgbm_last_error() gives the (thread-local) message;
+ *   - device_id >= 0 selects the HIP device; there is NO CPU fallback: without a usable GPU every
+ *     compute entry point fails with RGBM_ERR_NO_DEVICE.
+ */
+#ifndef RGBM_H_
+#define RGBM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBM_OK 0
+#define RGBM_ERR_ARG (-1)
+#define RGBM_ERR_PARAM (-2)
+#define RGBM_ERR_LABEL (-3)
+#define RGBM_ERR_NO_DEVICE (-10)
+#define RGBM_ERR_HIP (-11)
+#define RGBM_ERR_NOMEM (-12)
+#define RGBM_ERR_FORMAT (-20)
+
+#define RGBM_OBJ_BINARY 0
+#define RGBM_OBJ_MULTICLASS 1
+#define RGBM_OBJ_REGRESSION 2
+
+typedef struct rgbm_model rgbm_model; /* opaque; host-resident trees, lazily mirrored on a device */
+typedef struct rgbm_table rgbm_table; /* opaque; an int32 code table resident in HBM */
+
+/* LightGBM parameters as set by python/repair/train.py:102-115 (fixed) and :148-156 (searched),
+ * under their LightGBM core names (sklearn aliases in comments). */
+typedef struct {
+    int32_t objective;    /* train.py:97-100  binary | multiclass | regression */
+    int32_t num_class;    /* train.py:118-119 (multiclass only; binary uses 2) */
+    int32_t n_estimators; /* model.lgb.n_estimators, train.py:53-55 */
+    int32_t num_leaves;   /* searched, train.py:149 */
+    int32_t max_depth;    /* model.lgb.max_depth, train.py:43-44 */
+    int32_t max_bin;      /* model.lgb.max_bin, train.py:45-46 (2..255) */
+    int32_t min_data_in_leaf; /* min_child_samples, train.py:153 */
+    int32_t min_data_in_bin;  /* LightGBM default 3 */
+    int32_t bagging_freq;     /* subsample_freq, train.py:151 */
+    int32_t seed;             /* random_state=42, train.py:113 */
+    int32_t device_id;        /* HIP device ordinal */
+    int32_t reserved;
+    double learning_rate;           /* model.lgb.learning_rate, train.py:41-42 */
+    double lambda_l1;               /* reg_alpha, train.py:47-49 */
+    double lambda_l2;               /* reg_lambda, train.py:155 */
+    double min_gain_to_split;       /* min_split_gain, train.py:50-52 */
+    double min_sum_hessian_in_leaf; /* min_child_weight, train.py:154 */
+    double bagging_fraction;        /* subsample, train.py:150 */
+    double feature_fraction;        /* colsample_bytree, train.py:152 */
+} rgbm_params;
+
+/* Per-call measurements filled by the training entry points (bench.py roofline inputs). */
+typedef struct {
+    double hist_ms;          /* sum of hist_build kernel time (HIP events on the launch stream) */
+    double total_ms;         /* whole training call, device side */
+    int64_t hist_launches;   /* number of hist_build launches */
+    int64_t hist_rows;       /* rows scanned by hist_build over all launches and class trees */
+    int64_t hist_bytes;      /* algorithmic bytes: rows * (F + 8) (+4 per row via an index list) */
+    int64_t root_rows;       /* of which full-table (root) scans */
+    double root_ms;          /* hist_build time spent in root scans */
+    int64_t trees;           /* trees grown */
+} rgbm_train_stats;
+
+/* Number of usable HIP devices (0 if none). */
+int rgbm_device_count(void);
+/* Message of the last failing call on this thread. */
+const char* rgbm_last_error(void);
+/* Library / numerics-spec version (bumped whenever results could change). */
+int rgbm_version(void);
+
+/* ---- fit --------------------------------------------------------------------------------
+ * Replaces `lgb.LGBMClassifier(**p).fit(X, y)` / `lgb.LGBMRegressor(**p).fit(X, y)`:
+ * python/repair/train.py:121-131 (construction), :171-172 (inside cross_val_score), :215-216
+ * (final fit).
+ *   X_colmajor [f][n]   feature codes;  n_codes[f] dictionary sizes
+ *   y_code [n]          class index (0..n_y_codes-1) or, for regression, index into y_value
+ *   y_value [n_y_codes] regression only: the distinct target values, ascending
+ *   class_weight [n_y_codes] or NULL: per-label weight (sklearn class_weight='balanced' is
+ *                       n / (n_labels * count_label), train.py:39-40,105); sample_weight [n] or NULL
+ */
+int rgbm_train(const int32_t* X_colmajor, int64_t n, int32_t f, const int32_t* n_codes,
+               const int32_t* y_code, int32_t n_y_codes, const double* y_value,
+               const double* class_weight, const double* sample_weight,
+               const rgbm_params* p, rgbm_model** out, rgbm_train_stats* stats /* may be NULL */);
+
+/* ---- predict_proba / predict ------------------------------------------------------------
+ * Replaces `model.predict_proba(X)` / `model.predict(X)`: python/repair/model.py:1120,1130.
+ * out: binary [n][2] = {1-p, p}; multiclass [n][num_class]; regression [n]. */
+int rgbm_predict(const rgbm_model* m, const int32_t* X_colmajor, int64_t n, int32_t f,
+                 int32_t device_id, double* out);
+
+/* ---- chained repair ---------------------------------------------------------------------
+ * Replaces the body of the grouped-map UDF `repair(pdf)`: python/repair/model.py:1107-1133.
+ * For each model in order: score every row from the listed feature columns, arg-max (first
+ * maximum, like numpy), then overwrite ONLY the NULL cells of the target column with
+ * class_code[label] so that later models see the repair.
+ *   table [c][n] codes, modified in place; feat_cols/feat_off[T+1]; class_code/class_off[T+1]
+ *   (an empty class list == regression target: column left untouched);
+ *   out_label [T][n] class index (-1 for regression), out_prob [T][n] its probability / raw value. */
+int rgbm_repair_chain(const rgbm_model* const* models, int32_t T, const int32_t* target_col,
+                      const int32_t* feat_cols, const int32_t* feat_off,
+                      const int32_t* class_code, const int32_t* class_off,
+                      int32_t* table_colmajor, int64_t n, int32_t c, int32_t device_id,
+                      int32_t* out_label, double* out_prob);
+
+/* ---- HBM-resident table (the batch path: python/repair/model.py:768-815 without toPandas) ---
+ * Upload the label-encoded table once; train one model per target attribute on the rows whose
+ * target cell is non-NULL (model.py:776), all other listed columns being the features. */
+int rgbm_table_create(const int32_t* codes_colmajor, int64_t n, int32_t c, const int32_t* n_codes,
+                      int32_t device_id, rgbm_table** out);
+void rgbm_table_free(rgbm_table* t);
+int rgbm_table_train(const rgbm_table* t, int32_t target_col, const int32_t* feat_cols, int32_t f,
+                     const double* y_value /* regression dictionary or NULL */,
+                     const double* class_weight /* [n_codes[target]] or NULL */,
+                     const rgbm_params* p, rgbm_model** out, rgbm_train_stats* stats);
+/* Chained repair of rows [row_begin, row_begin+n_rows) of the resident table, in place in HBM.
+ * out_label/out_prob [T][n_rows] are copied back to the host (either may be NULL). */
+int rgbm_table_repair_chain(rgbm_table* t, const rgbm_model* const* models, int32_t T,
+                            const int32_t* target_col, const int32_t* feat_cols, const int32_t* feat_off,
+                            int64_t row_begin, int64_t n_rows, int32_t* out_label, double* out_prob);
+/* Copy one column of the resident table back to the host. */
+int rgbm_table_read_column(const rgbm_table* t, int32_t col, int32_t* out /* [n] */);
+
+/* ---- model handle: pickling (python/repair/model.py:910,921,1069) -------------------------- */
+int rgbm_model_save(const rgbm_model* m, void* buf, size_t* len); /* buf==NULL: length query */
+int rgbm_model_load(const void* buf, size_t len, rgbm_model** out);
+void rgbm_model_free(rgbm_model* m);
+/* info[5] = {objective, num_class, trees_per_iteration, n_iterations, n_features} */
+int rgbm_model_info(const rgbm_model* m, int32_t* info);
+/* LightGBM feature_importances_ (train.py:219): type 0 = split counts, 1 = total gain. */
+int rgbm_model_importance(const rgbm_model* m, int32_t type, double* out /* [n_features] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBM_H_ */

@@ -552,32 +552,42 @@ ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_c
     if (w) { for (int64_t i = 0; i < N; ++i) if (w[i] > w_max) w_max = w[i]; } else w_max = 1.0;
     if (!(w_max > 0.0)) w_max = 1.0;
 
-    /* BoostFromScore */
+    /* BoostFromScore.  Label totals are defined order-free: without per-row sample weights the
+     * weight of label c is cnt[c] * class_weight[c]; sums run over labels in ascending order.
+     * (With sample weights they are row-order sums -- host-array path only.) */
     double* init = (double*)calloc(K, sizeof(double));
     double ymin = 0.0, ymax = 0.0;
-    if (obj == 2) {
-        double suml = 0.0, sumw = 0.0;
-        ymin = ymax = y_value[y_code[0]];
-        for (int64_t i = 0; i < N; ++i) {
-            double yv = y_value[y_code[i]], wi = w ? w[i] : 1.0;
-            suml += yv * wi; sumw += wi;
-            if (yv < ymin) ymin = yv;
-            if (yv > ymax) ymax = yv;
-        }
-        init[0] = suml / sumw;
-    } else {
-        int nk = (obj == 0) ? 2 : K;
-        double* cw = (double*)calloc(nk, sizeof(double)); double sumw = 0.0;
-        for (int64_t i = 0; i < N; ++i) { double wi = w ? w[i] : 1.0; cw[y_code[i]] += wi; sumw += wi; }
-        if (obj == 0) {
-            double pavg = cw[1] / sumw;
+    {
+        int nl = n_y_codes > 0 ? n_y_codes : 1;
+        if (obj == 0 && nl < 2) nl = 2;
+        if (obj == 1 && nl < K) nl = K;
+        int64_t* cnt = (int64_t*)calloc(nl, sizeof(int64_t));
+        double* tot = (double*)calloc(nl, sizeof(double));
+        for (int64_t i = 0; i < N; ++i) ++cnt[y_code[i]];
+        if (sample_weight) { for (int64_t i = 0; i < N; ++i) tot[y_code[i]] += w[i]; }
+        else { for (int c = 0; c < nl; ++c) tot[c] = (double)cnt[c] * (class_weight ? class_weight[c] : 1.0); }
+        double sumw = 0.0;
+        for (int c = 0; c < nl; ++c) sumw += tot[c];
+        if (obj == 2) {
+            double suml = 0.0; int first = 1;
+            for (int c = 0; c < nl; ++c) {
+                if (cnt[c] == 0) continue;
+                if (first) { ymin = ymax = y_value[c]; first = 0; }
+                if (y_value[c] < ymin) ymin = y_value[c];
+                if (y_value[c] > ymax) ymax = y_value[c];
+            }
+            if (sample_weight) { for (int64_t i = 0; i < N; ++i) suml += y_value[y_code[i]] * w[i]; }
+            else { for (int c = 0; c < nl; ++c) suml += tot[c] * y_value[c]; }
+            init[0] = suml / sumw;
+        } else if (obj == 0) {
+            double pavg = tot[1] / sumw;
             if (pavg > 1.0 - kEps) pavg = 1.0 - kEps;
             if (pavg < kEps) pavg = kEps;
             init[0] = log(pavg / (1.0 - pavg));
         } else {
-            for (int k = 0; k < K; ++k) { double pr = cw[k] / sumw; init[k] = log(pr > kEps ? pr : kEps); }
+            for (int k = 0; k < K; ++k) { double pr = tot[k] / sumw; init[k] = log(pr > kEps ? pr : kEps); }
         }
-        free(cw);
+        free(cnt); free(tot);
     }
 
     /* quantisation scales (D1) */

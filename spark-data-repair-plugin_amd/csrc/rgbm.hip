@@ -1,0 +1,822 @@
+// rgbm.hip -- librepairgbm.so: host orchestration + C-ABI (include/rgbm.h) over the gfx950 kernels.
+//
+// One training call = one HIP stream; the whole leaf-wise growth of the K class trees of a
+// boosting iteration runs on the device in lock step (grid.y = class tree) without any host
+// round trip: the per-tree control blocks (rg::TreeState) live in HBM and every kernel of the
+// fixed launch sequence
+//     hist -> split_find -> tree_step -> partition -> finish_split     (num_leaves-1 times)
+// reads its work description from there.  The host only enqueues.
+//
+// There is NO CPU fallback in this library: without a HIP device every compute entry point
+// returns RGBM_ERR_NO_DEVICE (the CPU oracle under oracle/ is test infrastructure and is never
+// linked or loaded from here).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rgbm.h"
+#include "rgbm_kernels.h"
+
+#define RGBM_VERSION 100   // numerics spec v1.00
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            char b_[512];                                                                              \
+            snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            throw std::runtime_error(b_);                                                              \
+        }                                                                                              \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    void alloc(size_t count) {
+        release(); n = count;
+        if (count) {
+            hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+            if (e != hipSuccess) { p = nullptr; char b[256]; snprintf(b, sizeof(b), "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); throw std::runtime_error(b); }
+        }
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    ~DevBuf() { release(); }
+    void upload(const T* h, size_t count, hipStream_t s) { if (count) HIPCHK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }
+    void download(T* h, size_t count, hipStream_t s) const { if (count) HIPCHK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
+    void zero(hipStream_t s) { if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+struct Feat { int32_t n_codes = 0, V = 0, has_nan = 0; std::vector<int32_t> ub; };
+struct Tree {
+    int32_t L = 1;
+    std::vector<int32_t> feat, theta, dleft, left, right;
+    std::vector<double> gain, leaf_value;
+    std::vector<int32_t> leaf_count;
+};
+
+struct DeviceModel {   // predictor mirror of a model on one device
+    DevBuf<rg::PNode> nodes; DevBuf<double> leaf_value;
+    DevBuf<uint8_t> lut; DevBuf<long long> lut_off; DevBuf<int32_t> n_codes; DevBuf<uint8_t> miss; DevBuf<int32_t> ident;
+    int node_stride = 1, leaf_stride = 1;
+};
+
+}  // namespace
+
+struct rgbm_model {
+    int32_t objective = 0, num_class = 0, K = 1, n_iter = 0, F = 0;
+    std::vector<Feat> feats;
+    std::vector<Tree> trees;
+    std::mutex mu;
+    std::map<int, DeviceModel*> dev;
+    ~rgbm_model() { for (auto& kv : dev) { (void)hipSetDevice(kv.first); delete kv.second; } }
+};
+
+struct rgbm_table {
+    int device = 0; int64_t n = 0; int32_t c = 0;
+    std::vector<int32_t> n_codes;
+    DevBuf<int32_t> codes;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Host logic: bin finding (LightGBM bin.cpp GreedyFindBin / FindBinWithZeroAsOneBin restated in
+// code space; see DESIGN.md "Binning").  Input: counts per code over the training rows.
+// ---------------------------------------------------------------------------------------------
+int greedy_find_bin(const std::vector<int32_t>& dv, const std::vector<int64_t>& cnt, int max_bin, int64_t total_cnt,
+                    int min_data_in_bin, std::vector<int32_t>& ub) {
+    const int nd = (int)dv.size();
+    ub.clear();
+    if (nd <= 0) return 0;
+    if (nd <= max_bin) {
+        int64_t cur = 0;
+        for (int i = 0; i + 1 < nd; ++i) {
+            cur += cnt[i];
+            if (cur >= min_data_in_bin) { ub.push_back((int32_t)(((int64_t)dv[i] + (int64_t)dv[i + 1]) / 2)); cur = 0; }
+        }
+        ub.push_back(INT32_MAX);
+        return (int)ub.size();
+    }
+    if (min_data_in_bin > 0) {
+        max_bin = (int)std::min<int64_t>(max_bin, total_cnt / min_data_in_bin);
+        max_bin = std::max(max_bin, 1);
+    }
+    double mean_bin_size = (double)total_cnt / max_bin;
+    int rest_bin_cnt = max_bin;
+    int64_t rest_sample_cnt = total_cnt;
+    std::vector<char> big(nd, 0);
+    for (int i = 0; i < nd; ++i)
+        if ((double)cnt[i] >= mean_bin_size) { big[i] = 1; --rest_bin_cnt; rest_sample_cnt -= cnt[i]; }
+    mean_bin_size = (double)rest_sample_cnt / rest_bin_cnt;
+    std::vector<int32_t> upper(max_bin, INT32_MAX), lower(max_bin, INT32_MAX);
+    int bin_cnt = 0;
+    lower[0] = dv[0];
+    int64_t cur = 0;
+    for (int i = 0; i + 1 < nd; ++i) {
+        if (!big[i]) rest_sample_cnt -= cnt[i];
+        cur += cnt[i];
+        double half = mean_bin_size * 0.5f;
+        if (half < 1.0) half = 1.0;
+        if (big[i] || (double)cur >= mean_bin_size || (big[i + 1] && (double)cur >= half)) {
+            upper[bin_cnt] = dv[i];
+            ++bin_cnt;
+            lower[bin_cnt] = dv[i + 1];
+            if (bin_cnt >= max_bin - 1) break;
+            cur = 0;
+            if (!big[i]) { --rest_bin_cnt; mean_bin_size = (double)rest_sample_cnt / (double)rest_bin_cnt; }
+        }
+    }
+    ++bin_cnt;
+    for (int i = 0; i + 1 < bin_cnt; ++i) {
+        int32_t v = (int32_t)(((int64_t)upper[i] + (int64_t)lower[i + 1]) / 2);
+        if (ub.empty() || ub.back() != v) ub.push_back(v);
+    }
+    ub.push_back(INT32_MAX);
+    return (int)ub.size();
+}
+
+void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const rgbm_params& p, Feat& f) {
+    std::vector<int32_t> dv; std::vector<int64_t> dc;
+    int64_t seen = 0;
+    for (int32_t c = 0; c < n_codes; ++c) if (cnt[c]) { dv.push_back(c); dc.push_back(cnt[c]); seen += cnt[c]; }
+    const int64_t na = n_train - seen;
+    int mb = p.max_bin - (na > 0 ? 1 : 0) - 1;   // NaN bin, zero bin (FindBinWithZeroAsOneBin)
+    if (mb < 1) mb = 1;
+    f.n_codes = n_codes; f.has_nan = na > 0 ? 1 : 0;
+    f.V = greedy_find_bin(dv, dc, mb, seen, p.min_data_in_bin, f.ub);
+}
+
+inline int code_to_bin(const Feat& f, int32_t c) {
+    int lo = 0, hi = f.V - 1;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (c <= f.ub[mid]) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+
+// LightGBM utils/random.h (as remembered)
+struct LgbRand {
+    uint32_t x;
+    explicit LgbRand(uint32_t seed) : x(seed) {}
+    int rnd16() { x = 214013u * x + 2531011u; return (int)((x >> 16) & 0x7FFF); }
+    int rnd32() { x = 214013u * x + 2531011u; return (int)(x & 0x7FFFFFFF); }
+    float next_float() { return (float)rnd16() / 32768.0f; }
+    int next_int(int lo, int hi) { return rnd32() % (hi - lo) + lo; }
+    std::vector<int> sample(int N, int K) {
+        std::vector<int> ret;
+        if (K > N || K <= 0) return ret;
+        if (K == N) { for (int i = 0; i < N; ++i) ret.push_back(i); return ret; }
+        if (K > 1 && (double)K > ((double)N / std::log2((double)K))) {
+            for (int i = 0; i < N; ++i) {
+                double prob = (double)(K - (int)ret.size()) / (double)(N - i);
+                if (next_float() < prob) ret.push_back(i);
+            }
+            return ret;
+        }
+        std::vector<char> in(N, 0);
+        for (int r = N - K; r < N; ++r) { int v = next_int(0, r); if (in[v]) in[r] = 1; else in[v] = 1; }
+        for (int i = 0; i < N; ++i) if (in[i]) ret.push_back(i);
+        return ret;
+    }
+};
+
+int ceil_log2(double v) { int ex; double m = std::frexp(v, &ex); return (m == 0.5) ? ex - 1 : ex; }
+
+void check_params(const rgbm_params& p) {
+    if (p.objective < 0 || p.objective > 2) throw std::invalid_argument("objective must be 0 (binary), 1 (multiclass) or 2 (regression)");
+    if (p.max_bin < 2 || p.max_bin > 255) throw std::invalid_argument("max_bin must be in [2, 255]");
+    if (p.num_leaves < 2 || p.num_leaves > 32767) throw std::invalid_argument("num_leaves must be in [2, 32767]");
+    if (p.n_estimators < 1) throw std::invalid_argument("n_estimators must be positive");
+    if (!(p.learning_rate > 0.0)) throw std::invalid_argument("learning_rate must be positive");
+    if (p.objective == 1 && p.num_class < 2) throw std::invalid_argument("multiclass needs num_class >= 2");
+    if (p.min_data_in_leaf < 0 || p.lambda_l1 < 0 || p.lambda_l2 < 0) throw std::invalid_argument("negative regularisation / min_data_in_leaf");
+    if (p.bagging_freq > 0 && p.bagging_fraction < 1.0) throw std::invalid_argument("bagging (subsample < 1) is not implemented in the HIP trainer yet");
+}
+
+void use_device(int device_id) {
+    int nd = 0;
+    hipError_t e = hipGetDeviceCount(&nd);
+    if (e != hipSuccess || nd <= 0) throw std::domain_error("no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= nd) throw std::domain_error("device_id out of range: there are " + std::to_string(nd) + " HIP device(s)");
+    HIPCHK(hipSetDevice(device_id));
+}
+
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    StreamGuard() { HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+};
+
+struct HostLabelStats {   // row-order weight sums, only used with per-row sample weights
+    bool valid = false;
+    std::vector<double> tot; double suml = 0.0, w_max = 0.0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// The trainer (GBDT::Train) on a resident table.
+// ---------------------------------------------------------------------------------------------
+rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t* feat_cols, int32_t F,
+                       const double* y_value, const double* class_weight, const double* sample_weight_host,
+                       const HostLabelStats* hls, const rgbm_params& p, rgbm_train_stats* stats) {
+    using namespace rg;
+    check_params(p);
+    if (F <= 0) throw std::invalid_argument("no feature columns");
+    if (target_col < 0 || target_col >= tab.c) throw std::invalid_argument("target column out of range");
+    for (int f = 0; f < F; ++f) if (feat_cols[f] < 0 || feat_cols[f] >= tab.c) throw std::invalid_argument("feature column out of range");
+    if (F > 65535) throw std::invalid_argument("more than 65535 feature columns");
+    const int64_t N = tab.n;
+    const int obj = p.objective;
+    const int n_y = tab.n_codes[target_col];
+    const int K = obj == 1 ? p.num_class : 1;
+    if (obj == 1 && n_y > p.num_class) throw std::out_of_range("target has more label codes than num_class");
+    if (obj == 0 && n_y > 2) throw std::out_of_range("binary objective with more than 2 label codes");
+    if (obj == 2 && !y_value) throw std::out_of_range("regression needs the y_value dictionary");
+    StreamGuard sg_; hipStream_t s = sg_.s;
+    hipEvent_t ev_begin, ev_end; HIPCHK(hipEventCreate(&ev_begin)); HIPCHK(hipEventCreate(&ev_end));
+    HIPCHK(hipEventRecord(ev_begin, s));
+
+    // ---- 1. code frequencies of the training rows (features + the target itself)
+    std::vector<int32_t> cols(feat_cols, feat_cols + F); cols.push_back(target_col);
+    std::vector<int32_t> ncod(F + 1); std::vector<long long> cnt_off(F + 2, 0);
+    for (int f = 0; f <= F; ++f) { ncod[f] = tab.n_codes[cols[f]]; cnt_off[f + 1] = cnt_off[f] + std::max(ncod[f], 1); }
+    DevBuf<int32_t> d_cols(F + 1), d_ncod(F + 1); DevBuf<long long> d_cnt_off(F + 2); DevBuf<unsigned int> d_cnt(cnt_off[F + 1]);
+    d_cols.upload(cols.data(), F + 1, s); d_ncod.upload(ncod.data(), F + 1, s); d_cnt_off.upload(cnt_off.data(), F + 2, s); d_cnt.zero(s);
+    const int32_t* d_ycol = tab.codes.p + (long long)target_col * N;
+    {
+        int gx = (int)std::min<int64_t>((N + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_count_codes, dim3(gx, F + 1), dim3(256), 0, s, tab.codes.p, (long long)N, d_ycol, d_cols.p, d_ncod.p, d_cnt_off.p, d_cnt.p);
+    }
+    std::vector<unsigned int> cnt(cnt_off[F + 1]);
+    d_cnt.download(cnt.data(), cnt.size(), s);
+    HIPCHK(hipStreamSynchronize(s));
+    const unsigned int* ycnt = cnt.data() + cnt_off[F];
+    int64_t n_train = 0;
+    for (int c = 0; c < n_y; ++c) n_train += ycnt[c];
+    if (n_train <= 0) throw std::out_of_range("no training rows (every target cell is NULL)");
+    if (N >= (1ll << 31) - 4096) throw std::invalid_argument("more than 2^31 rows per table are not supported");
+
+    // ---- 2. bins
+    auto model = new rgbm_model();
+    std::unique_ptr<rgbm_model> guard(model);
+    model->objective = obj; model->num_class = obj == 1 ? K : (obj == 0 ? 2 : 1); model->K = K; model->F = F;
+    model->feats.resize(F);
+    std::vector<FeatMeta> fmeta(F);
+    std::vector<long long> lut_off(F + 1, 0);
+    std::vector<uint8_t> miss(F), trivial(F);
+    int totbins = 0;
+    for (int f = 0; f < F; ++f) {
+        Feat& ft = model->feats[f];
+        find_bin(cnt.data() + cnt_off[f], ncod[f], n_train, p, ft);
+        fmeta[f].V = ft.V; fmeta[f].has_nan = ft.has_nan; fmeta[f].nbins = std::max(ft.V + ft.has_nan, 1); fmeta[f].hoff = totbins;
+        totbins += fmeta[f].nbins;
+        trivial[f] = (ft.V + ft.has_nan <= 1) || ft.V == 0;
+        miss[f] = (uint8_t)(ft.has_nan ? ft.V : 0);
+        lut_off[f + 1] = lut_off[f] + std::max(ncod[f], 1);
+    }
+    std::vector<uint8_t> lut(lut_off[F]);
+    for (int f = 0; f < F; ++f) {
+        const Feat& ft = model->feats[f];
+        int b = 0;
+        for (int c = 0; c < ncod[f]; ++c) { while (b < ft.V - 1 && c > ft.ub[b]) ++b; lut[lut_off[f] + c] = (uint8_t)(ft.V > 0 ? b : 0); }
+    }
+    const int nchunk = (F + 15) / 16;
+    std::vector<ChunkMeta> cmeta(nchunk);
+    size_t lds_hist = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        ChunkMeta& cm = cmeta[ch]; cm.first_feat = ch * 16; cm.nfeat = std::min(16, F - ch * 16); cm.fast_slots = 0; cm.wide_bins = 0;
+        for (int j = 0; j < cm.nfeat; ++j) {
+            FeatMeta& m = fmeta[ch * 16 + j];
+            int sh = 0; while (sh < 5 && (m.nbins << (sh + 1)) <= 256) ++sh;
+            m.rep_shift = sh; m.fast_base = cm.fast_slots; m.wide_off = cm.wide_bins;
+            cm.fast_slots += m.nbins << sh; cm.wide_bins += m.nbins;
+        }
+        lds_hist = std::max(lds_hist, (size_t)cm.fast_slots * 8 + (size_t)cm.wide_bins * 16);
+    }
+
+    // ---- 3. label statistics, init scores (BoostFromScore), quantisation scales
+    const int nl = std::max({n_y, obj == 0 ? 2 : 1, obj == 1 ? K : 1});
+    std::vector<double> tot(nl, 0.0);
+    double w_max = 0.0;
+    if (hls && hls->valid) { tot = hls->tot; tot.resize(nl, 0.0); w_max = hls->w_max; }
+    else {
+        for (int c = 0; c < n_y; ++c) {
+            tot[c] = (double)ycnt[c] * (class_weight ? class_weight[c] : 1.0);
+            if (ycnt[c]) w_max = std::max(w_max, class_weight ? class_weight[c] : 1.0);
+        }
+    }
+    if (!(w_max > 0.0)) w_max = 1.0;
+    double sumw = 0.0;
+    for (int c = 0; c < nl; ++c) sumw += tot[c];
+    std::vector<double> init(K, 0.0);
+    double ymin = 0.0, ymax = 0.0;
+    const double keps = k_eps();
+    if (obj == 2) {
+        bool first = true; double suml = 0.0;
+        for (int c = 0; c < n_y; ++c) {
+            if (!ycnt[c]) continue;
+            if (first) { ymin = ymax = y_value[c]; first = false; }
+            ymin = std::min(ymin, y_value[c]); ymax = std::max(ymax, y_value[c]);
+        }
+        if (hls && hls->valid) suml = hls->suml; else for (int c = 0; c < nl; ++c) suml += tot[c] * (c < n_y ? y_value[c] : 0.0);
+        init[0] = suml / sumw;
+    } else if (obj == 0) {
+        double pavg = tot[1] / sumw;
+        if (pavg > 1.0 - keps) pavg = 1.0 - keps;
+        if (pavg < keps) pavg = keps;
+        init[0] = std::log(pavg / (1.0 - pavg));
+    } else {
+        for (int k = 0; k < K; ++k) { double pr = tot[k] / sumw; init[k] = std::log(pr > keps ? pr : keps); }
+    }
+    const double factor = obj == 1 ? (double)K / (double)(K - 1) : 1.0;
+    double bound_g, bound_h;
+    if (obj == 2) { bound_g = (ymax - ymin) * w_max; if (!(bound_g > 0.0)) bound_g = 1.0; bound_h = w_max; }
+    else if (obj == 0) { bound_g = w_max; bound_h = 0.25 * w_max; }
+    else { bound_g = w_max; bound_h = factor * 0.25 * w_max; }
+    const int e_g = 20 - ceil_log2(bound_g), e_h = 21 - ceil_log2(bound_h);
+
+    TrainConst tc; memset(&tc, 0, sizeof(tc));
+    tc.sg = std::ldexp(1.0, e_g); tc.sh = std::ldexp(1.0, e_h); tc.inv_sg = std::ldexp(1.0, -e_g); tc.inv_sh = std::ldexp(1.0, -e_h);
+    tc.l1 = p.lambda_l1; tc.l2 = p.lambda_l2; tc.min_gain_to_split = p.min_gain_to_split; tc.min_sum_hessian = p.min_sum_hessian_in_leaf;
+    tc.learning_rate = p.learning_rate; tc.factor = factor; tc.min_data_in_leaf = p.min_data_in_leaf; tc.max_depth = p.max_depth;
+    tc.num_leaves = p.num_leaves; tc.F = F; tc.K = K; tc.totbins = std::max(totbins, 1); tc.nchunk = nchunk; tc.objective = obj;
+    tc.N = N; tc.n_train = n_train;
+    const int NL = p.num_leaves, NE = p.n_estimators;
+
+    // ---- 4. device state
+    DevBuf<FeatMeta> d_fmeta(F); DevBuf<ChunkMeta> d_cmeta(nchunk); DevBuf<long long> d_lut_off(F + 1); DevBuf<uint8_t> d_lut(lut.size()), d_miss(F);
+    d_fmeta.upload(fmeta.data(), F, s); d_cmeta.upload(cmeta.data(), nchunk, s); d_lut_off.upload(lut_off.data(), F + 1, s);
+    d_lut.upload(lut.data(), lut.size(), s); d_miss.upload(miss.data(), F, s);
+    DevBuf<uint4> d_rec((size_t)nchunk * N);
+    hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tab.codes.p, (long long)N, 0ll, (long long)N,
+                       d_cols.p, d_ncod.p, d_lut_off.p, d_lut.p, d_miss.p, F, nchunk, d_rec.p);
+    DevBuf<int32_t> d_base(n_train); DevBuf<unsigned int> d_counter(1); d_counter.zero(s);
+    hipLaunchKernelGGL(k_iota_train, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, (long long)N, d_base.p, d_counter.p);
+    DevBuf<int2> d_gh((size_t)K * N); d_gh.zero(s);
+    DevBuf<double> d_score((size_t)K * N), d_init(K);
+    d_init.upload(init.data(), K, s);
+    hipLaunchKernelGGL(k_init_score, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_score.p, (long long)N, K, d_init.p);
+    DevBuf<int32_t> d_idx0((size_t)K * n_train), d_idx1((size_t)K * n_train);
+    DevBuf<HistBin> d_pool((size_t)K * NL * tc.totbins);
+    DevBuf<TreeState> d_state(K); DevBuf<Leaf> d_leaves((size_t)K * NL); DevBuf<Cand> d_cand((size_t)K * 2 * F);
+    DevBuf<double> d_upd((size_t)K * NL); DevBuf<int32_t> d_sorted((size_t)K * NL * 3), d_any(NE); d_any.zero(s);
+    const size_t NT = (size_t)NE * K;
+    DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
+    DevBuf<double> t_gain(NT * (NL - 1)), t_val(NT * NL);
+    t_cnt.zero(s); t_val.zero(s);
+    TreeOut to{t_L.p, t_feat.p, t_theta.p, t_dleft.p, t_left.p, t_right.p, t_gain.p, t_val.p, t_cnt.p};
+    DevBuf<double> d_cw, d_yv, d_sw;
+    if (class_weight) { d_cw.alloc(n_y); d_cw.upload(class_weight, n_y, s); }
+    if (y_value) { d_yv.alloc(n_y); d_yv.upload(y_value, n_y, s); }
+    if (sample_weight_host) { d_sw.alloc(N); d_sw.upload(sample_weight_host, N, s); }
+
+    // per-tree feature masks (ColSampler::ResetByTree), generated in LightGBM's draw order
+    std::vector<uint8_t> used((size_t)NT * F, 0);
+    {
+        LgbRand sr((uint32_t)p.seed);
+        sr.rnd16(); sr.rnd16(); sr.rnd16();
+        LgbRand ff((uint32_t)sr.rnd16());
+        std::vector<int> valid; for (int f = 0; f < F; ++f) if (!trivial[f]) valid.push_back(f);
+        for (size_t t = 0; t < NT; ++t) {
+            uint8_t* u = used.data() + t * F;
+            if (p.feature_fraction < 1.0) {
+                int cntf = (int)std::floor((double)valid.size() * p.feature_fraction + 0.5);
+                if (cntf < 1) cntf = 1;
+                for (int i : ff.sample((int)valid.size(), cntf)) u[valid[i]] = 1;
+            } else for (int f : valid) u[f] = 1;
+        }
+    }
+    DevBuf<uint8_t> d_used(used.size()); d_used.upload(used.data(), used.size(), s);
+
+    if (lds_hist > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
+    if (lds_hist > 160 * 1024) throw std::invalid_argument("histogram working set exceeds LDS");
+
+    const long long root_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+    const int hist_gx = (int)std::max<long long>(1, std::min<long long>(root_tiles, (1536 + (long long)K * nchunk - 1) / ((long long)K * nchunk)));
+    const int part_gx = (int)std::max<long long>(1, std::min<long long>((n_train + 1023) / 1024, (1024 + K - 1) / K));
+    const int upd_gx = (int)std::max<long long>(1, std::min<long long>((n_train + 255) / 256, (2048 + K - 1) / K));
+    const int grad_gx = (int)std::min<long long>((N + 255) / 256, 4096);
+    const size_t upd_lds = (size_t)(3 * NL + (NL & 1)) * 4 + (size_t)NL * 8;
+
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> hist_ev;   // only when stats are requested
+    std::vector<char> hist_ev_root;
+    auto launch_hist = [&](bool root) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (stats) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
+        hipLaunchKernelGGL(k_hist, dim3(hist_gx, K, nchunk), dim3(256), lds_hist, s, d_rec.p, d_gh.p, d_idx0.p, d_idx1.p, d_base.p,
+                           d_state.p, d_pool.p, d_fmeta.p, d_cmeta.p, tc);
+        if (stats) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
+    };
+
+    // ---- 5. boosting iterations: everything below is enqueue-only
+    for (int it = 0; it < NE; ++it) {
+        const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw = sample_weight_host ? d_sw.p : nullptr;
+        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, d_gh.p, tc);
+        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, d_gh.p, tc);
+        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, d_gh.p, tc);
+        hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, it, tc);
+        const uint8_t* usedp = d_used.p + (size_t)it * K * F;
+        for (int step = 0; step < NL - 1; ++step) {
+            launch_hist(step == 0);
+            hipLaunchKernelGGL(k_split_find, dim3((F + 3) / 4, K), dim3(256), 0, s, d_pool.p, d_state.p, d_leaves.p, d_fmeta.p, usedp, d_cand.p, tc);
+            hipLaunchKernelGGL(k_tree_step, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_cand.p, d_pool.p, d_fmeta.p, to, it, tc);
+            hipLaunchKernelGGL(k_partition, dim3(part_gx, K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(d_rec.p), d_idx0.p, d_idx1.p, d_base.p, d_state.p, tc);
+            hipLaunchKernelGGL(k_finish_split, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, to, it, tc);
+        }
+        hipLaunchKernelGGL(k_finalize_tree, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, to, d_init.p, d_upd.p, d_sorted.p, d_any.p, it, tc);
+        hipLaunchKernelGGL(k_score_update, dim3(upd_gx, K), dim3(256), upd_lds, s, d_state.p, d_leaves.p, d_sorted.p, d_upd.p, d_idx0.p, d_idx1.p, d_base.p, d_score.p, tc);
+    }
+    HIPCHK(hipGetLastError());
+
+    // ---- 6. trees back to the host
+    std::vector<int32_t> hL(NT), hfeat(NT * (NL - 1)), htheta(NT * (NL - 1)), hdleft(NT * (NL - 1)), hleft(NT * (NL - 1)), hright(NT * (NL - 1)), hcnt(NT * NL), hany(NE);
+    std::vector<double> hgain(NT * (NL - 1)), hval(NT * NL);
+    t_L.download(hL.data(), hL.size(), s); t_feat.download(hfeat.data(), hfeat.size(), s); t_theta.download(htheta.data(), htheta.size(), s);
+    t_dleft.download(hdleft.data(), hdleft.size(), s); t_left.download(hleft.data(), hleft.size(), s); t_right.download(hright.data(), hright.size(), s);
+    t_cnt.download(hcnt.data(), hcnt.size(), s); t_gain.download(hgain.data(), hgain.size(), s); t_val.download(hval.data(), hval.size(), s);
+    d_any.download(hany.data(), NE, s);
+    HIPCHK(hipEventRecord(ev_end, s));
+    HIPCHK(hipStreamSynchronize(s));
+
+    int n_iter = NE;
+    for (int it = 0; it < NE; ++it) if (!hany[it]) { n_iter = it > 0 ? it : 1; break; }   // "no more leaves that meet the split requirements"
+    model->n_iter = n_iter;
+    model->trees.resize((size_t)n_iter * K);
+    for (size_t t = 0; t < (size_t)n_iter * K; ++t) {
+        Tree& tr = model->trees[t];
+        tr.L = hL[t]; const int n = tr.L - 1;
+        const size_t nb = t * (NL - 1), lb = t * NL;
+        tr.feat.assign(hfeat.begin() + nb, hfeat.begin() + nb + n); tr.theta.assign(htheta.begin() + nb, htheta.begin() + nb + n);
+        tr.dleft.assign(hdleft.begin() + nb, hdleft.begin() + nb + n); tr.left.assign(hleft.begin() + nb, hleft.begin() + nb + n);
+        tr.right.assign(hright.begin() + nb, hright.begin() + nb + n); tr.gain.assign(hgain.begin() + nb, hgain.begin() + nb + n);
+        tr.leaf_value.assign(hval.begin() + lb, hval.begin() + lb + tr.L); tr.leaf_count.assign(hcnt.begin() + lb, hcnt.begin() + lb + tr.L);
+    }
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ev_begin, ev_end)); stats->total_ms = ms;
+        stats->hist_launches = (int64_t)hist_ev.size();
+        for (size_t i = 0; i < hist_ev.size(); ++i) {
+            float m2 = 0.f; HIPCHK(hipEventElapsedTime(&m2, hist_ev[i].first, hist_ev[i].second));
+            stats->hist_ms += m2; if (hist_ev_root[i]) stats->root_ms += m2;
+            (void)hipEventDestroy(hist_ev[i].first); (void)hipEventDestroy(hist_ev[i].second);
+        }
+        // rows scanned: root = N per class tree; otherwise the smaller child of every split, which the
+        // trees record (leaf_count of both children is known at the end only for final leaves), so
+        // replay the growth order on the host from the stored counts.
+        int64_t rows = 0, root_rows = 0, bytes = 0;
+        for (int it = 0; it < NE; ++it) for (int k = 0; k < K; ++k) {
+            const size_t t = (size_t)it * K + k;
+            const int L = hL[t];
+            const bool root_done = n_train >= (int64_t)p.min_data_in_leaf * 2;
+            if (root_done) { rows += N; root_rows += N; bytes += N * ((int64_t)nchunk * 16 + 8); }
+            // subtree sizes by unfolding the splits in creation order
+            std::vector<int64_t> cntl(NL, 0); std::vector<int> depth(NL, 0);
+            cntl[0] = n_train;
+            std::vector<int64_t> fin(hcnt.begin() + t * NL, hcnt.begin() + t * NL + NL);
+            // final leaf counts -> internal counts: node j created leaf j+1 from some leaf; recover via children links
+            std::vector<int64_t> nodecnt(std::max(L - 1, 1), 0);
+            for (int j = L - 2; j >= 0; --j) {
+                auto sub = [&](int ch) -> int64_t { return ch < 0 ? fin[~ch] : nodecnt[ch]; };
+                nodecnt[j] = sub(hleft[t * (NL - 1) + j]) + sub(hright[t * (NL - 1) + j]);
+            }
+            std::vector<int> node_depth(std::max(L - 1, 1), 0);
+            for (int j = 0; j < L - 1; ++j) {
+                int lc = hleft[t * (NL - 1) + j], rc = hright[t * (NL - 1) + j];
+                if (lc >= 0) node_depth[lc] = node_depth[j] + 1;
+                if (rc >= 0) node_depth[rc] = node_depth[j] + 1;
+                auto sub = [&](int ch) -> int64_t { return ch < 0 ? fin[~ch] : nodecnt[ch]; };
+                const int64_t a = sub(lc), b = sub(rc);
+                const bool last = (j + 2 >= NL);
+                bool go = !last;
+                if (p.max_depth > 0 && node_depth[j] + 1 >= p.max_depth) go = false;
+                if (a < (int64_t)p.min_data_in_leaf * 2 && b < (int64_t)p.min_data_in_leaf * 2) go = false;
+                if (go) { int64_t sm = std::min(a, b); rows += sm; bytes += sm * ((int64_t)nchunk * 16 + 8 + 4); }
+            }
+            stats->trees += 1;
+        }
+        stats->hist_rows = rows; stats->root_rows = root_rows;
+        // algorithmic bytes use the USEFUL feature bytes (F), not the padded record
+        stats->hist_bytes = rows * ((int64_t)F + 8) + (rows - root_rows) * 4;
+        (void)bytes;
+    }
+    (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
+    return guard.release();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Predictor mirror
+// ---------------------------------------------------------------------------------------------
+DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    auto it = m->dev.find(device);
+    if (it != m->dev.end()) return it->second;
+    using namespace rg;
+    auto dm = new DeviceModel();
+    std::unique_ptr<DeviceModel> guard(dm);
+    int maxL = 2;
+    for (auto& t : m->trees) maxL = std::max(maxL, t.L);
+    dm->node_stride = maxL - 1; dm->leaf_stride = maxL;
+    const size_t NT = m->trees.size();
+    std::vector<PNode> nodes(std::max<size_t>(NT, 1) * dm->node_stride); std::vector<double> lv(std::max<size_t>(NT, 1) * dm->leaf_stride, 0.0);
+    for (size_t t = 0; t < NT; ++t) {
+        const Tree& tr = m->trees[t];
+        PNode* nd = nodes.data() + t * dm->node_stride;
+        if (tr.L <= 1) { nd[0].w0 = 0; nd[0].w1 = 0xFFFFFFFFu; /* both children = ~0 */ }
+        for (int j = 0; j < tr.L - 1; ++j) {
+            nd[j].w0 = (uint32_t)(tr.feat[j] & 0xFFFF) | ((uint32_t)(tr.theta[j] + 1) & 0x1FF) << 16 | (uint32_t)(tr.dleft[j] ? 1 : 0) << 25;
+            nd[j].w1 = ((uint32_t)tr.left[j] & 0xFFFFu) | ((uint32_t)tr.right[j] & 0xFFFFu) << 16;
+        }
+        for (int l = 0; l < tr.L; ++l) lv[t * dm->leaf_stride + l] = tr.leaf_value[l];
+    }
+    const int F = m->F;
+    std::vector<long long> lut_off(F + 1, 0); std::vector<int32_t> ncod(F), ident(F); std::vector<uint8_t> miss(F, 255);
+    for (int f = 0; f < F; ++f) { ncod[f] = m->feats[f].n_codes; ident[f] = f; lut_off[f + 1] = lut_off[f] + std::max(ncod[f], 1); }
+    std::vector<uint8_t> lut(lut_off[F]);
+    for (int f = 0; f < F; ++f) {
+        const Feat& ft = m->feats[f]; int b = 0;
+        for (int c = 0; c < ncod[f]; ++c) { while (b < ft.V - 1 && c > ft.ub[b]) ++b; lut[lut_off[f] + c] = (uint8_t)(ft.V > 0 ? b : 0); }
+    }
+    dm->nodes.alloc(nodes.size()); dm->nodes.upload(nodes.data(), nodes.size(), s);
+    dm->leaf_value.alloc(lv.size()); dm->leaf_value.upload(lv.data(), lv.size(), s);
+    dm->lut.alloc(lut.size()); dm->lut.upload(lut.data(), lut.size(), s);
+    dm->lut_off.alloc(F + 1); dm->lut_off.upload(lut_off.data(), F + 1, s);
+    dm->n_codes.alloc(F); dm->n_codes.upload(ncod.data(), F, s);
+    dm->miss.alloc(F); dm->miss.upload(miss.data(), F, s);
+    dm->ident.alloc(F); dm->ident.upload(ident.data(), F, s);
+    HIPCHK(hipStreamSynchronize(s));
+    m->dev[device] = dm;
+    return guard.release();
+}
+
+// score rows [row0, row0+n) of device codes (column-major, Ntab rows per column) with model m.
+// feat_col_dev: device array of the F column indices.  Outputs are device pointers (any may be null).
+void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_codes, long long Ntab, long long row0, long long n,
+                    const int32_t* d_feat_cols, double* d_proba, int32_t* d_label, double* d_top) {
+    using namespace rg;
+    if (n <= 0) return;
+    DeviceModel* dm = device_model(m, device, s);
+    const int F = m->F, nchunk = (F + 15) / 16, K = m->K;
+    DevBuf<uint4> rec((size_t)nchunk * n);
+    hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes, Ntab, row0, n,
+                       d_feat_cols ? d_feat_cols : dm->ident.p, dm->n_codes.p, dm->lut_off.p, dm->lut.p, dm->miss.p, F, nchunk, rec.p);
+    DevBuf<double> raw((size_t)K * n);
+    hipLaunchKernelGGL(k_predict_raw, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
+                       dm->nodes.p, dm->leaf_value.p, m->n_iter, K, dm->node_stride, dm->leaf_stride, raw.p);
+    hipLaunchKernelGGL(k_softmax_argmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw.p, n, m->objective, m->num_class, d_proba, d_label, d_top);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));   // rec/raw are freed on return
+}
+
+template <typename Fn>
+int guarded(Fn&& fn) {
+    try { return fn(); }
+    catch (const std::invalid_argument& e) { return fail(RGBM_ERR_PARAM, e.what()); }
+    catch (const std::out_of_range& e) { return fail(RGBM_ERR_LABEL, e.what()); }
+    catch (const std::domain_error& e) { return fail(RGBM_ERR_NO_DEVICE, e.what()); }
+    catch (const std::bad_alloc&) { return fail(RGBM_ERR_NOMEM, "out of host memory"); }
+    catch (const std::exception& e) { return fail(RGBM_ERR_HIP, e.what()); }
+}
+
+void put(std::vector<uint8_t>& b, const void* p, size_t n) { const uint8_t* c = (const uint8_t*)p; b.insert(b.end(), c, c + n); }
+
+std::vector<uint8_t> serialise(const rgbm_model& m) {
+    std::vector<uint8_t> b;
+    int32_t hdr[7] = {0x4D424752, 1, m.objective, m.num_class, m.K, m.n_iter, m.F};
+    put(b, hdr, sizeof(hdr));
+    for (const Feat& f : m.feats) { int32_t h3[3] = {f.n_codes, f.V, f.has_nan}; put(b, h3, sizeof(h3)); put(b, f.ub.data(), 4 * (size_t)f.V); }
+    for (const Tree& t : m.trees) {
+        const size_t n = (size_t)t.L - 1;
+        put(b, &t.L, 4);
+        put(b, t.feat.data(), 4 * n); put(b, t.theta.data(), 4 * n); put(b, t.dleft.data(), 4 * n);
+        put(b, t.left.data(), 4 * n); put(b, t.right.data(), 4 * n); put(b, t.gain.data(), 8 * n);
+        put(b, t.leaf_value.data(), 8 * (size_t)t.L); put(b, t.leaf_count.data(), 4 * (size_t)t.L);
+    }
+    return b;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+#define RGBM_EXPORT __attribute__((visibility("default")))
+
+RGBM_EXPORT int rgbm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+RGBM_EXPORT const char* rgbm_last_error(void) { return g_err.c_str(); }
+RGBM_EXPORT int rgbm_version(void) { return RGBM_VERSION; }
+
+RGBM_EXPORT int rgbm_table_create(const int32_t* codes, int64_t n, int32_t c, const int32_t* n_codes, int32_t device_id, rgbm_table** out) {
+    if (!codes || !n_codes || !out || n <= 0 || c <= 0) return fail(RGBM_ERR_ARG, "rgbm_table_create: bad argument");
+    return guarded([&]() {
+        use_device(device_id);
+        std::unique_ptr<rgbm_table> t(new rgbm_table());
+        t->device = device_id; t->n = n; t->c = c; t->n_codes.assign(n_codes, n_codes + c);
+        t->codes.alloc((size_t)n * c);
+        HIPCHK(hipMemcpy(t->codes.p, codes, (size_t)n * c * sizeof(int32_t), hipMemcpyHostToDevice));
+        *out = t.release();
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT void rgbm_table_free(rgbm_table* t) { if (t) { (void)hipSetDevice(t->device); delete t; } }
+
+RGBM_EXPORT int rgbm_table_read_column(const rgbm_table* t, int32_t col, int32_t* out) {
+    if (!t || !out || col < 0 || col >= t->c) return fail(RGBM_ERR_ARG, "rgbm_table_read_column: bad argument");
+    return guarded([&]() {
+        use_device(t->device);
+        HIPCHK(hipMemcpy(out, t->codes.p + (size_t)col * t->n, (size_t)t->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_table_train(const rgbm_table* t, int32_t target_col, const int32_t* feat_cols, int32_t f, const double* y_value,
+                                 const double* class_weight, const rgbm_params* p, rgbm_model** out, rgbm_train_stats* stats) {
+    if (!t || !feat_cols || !p || !out) return fail(RGBM_ERR_ARG, "rgbm_table_train: bad argument");
+    return guarded([&]() {
+        use_device(t->device);
+        *out = train_core(*t, target_col, feat_cols, f, y_value, class_weight, nullptr, nullptr, *p, stats);
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_train(const int32_t* X, int64_t n, int32_t f, const int32_t* n_codes, const int32_t* y_code, int32_t n_y_codes,
+                           const double* y_value, const double* class_weight, const double* sample_weight, const rgbm_params* p,
+                           rgbm_model** out, rgbm_train_stats* stats) {
+    if (!X || !n_codes || !y_code || !p || !out || n <= 0 || f <= 0 || n_y_codes <= 0) return fail(RGBM_ERR_ARG, "rgbm_train: bad argument");
+    return guarded([&]() {
+        use_device(p->device_id);
+        for (int64_t i = 0; i < n; ++i) if (y_code[i] < 0 || y_code[i] >= n_y_codes) throw std::out_of_range("y_code outside [0, n_y_codes)");
+        rgbm_table tab; tab.device = p->device_id; tab.n = n; tab.c = f + 1;
+        tab.n_codes.assign(n_codes, n_codes + f); tab.n_codes.push_back(n_y_codes);
+        tab.codes.alloc((size_t)n * (f + 1));
+        HIPCHK(hipMemcpy(tab.codes.p, X, (size_t)n * f * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(tab.codes.p + (size_t)n * f, y_code, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        std::vector<int32_t> fc(f); for (int i = 0; i < f; ++i) fc[i] = i;
+        HostLabelStats hls;
+        if (sample_weight) {   // row-order sums (numerics spec: only defined on the host-array path)
+            hls.valid = true; hls.tot.assign(n_y_codes, 0.0);
+            for (int64_t i = 0; i < n; ++i) {
+                double w = (class_weight ? class_weight[y_code[i]] : 1.0); w = w * sample_weight[i];
+                hls.tot[y_code[i]] += w; if (w > hls.w_max) hls.w_max = w;
+                if (y_value) hls.suml += y_value[y_code[i]] * w;
+            }
+        }
+        *out = train_core(tab, f, fc.data(), f, y_value, class_weight, sample_weight, &hls, *p, stats);
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_predict(const rgbm_model* m, const int32_t* X, int64_t n, int32_t f, int32_t device_id, double* out) {
+    if (!m || !X || !out || n < 0) return fail(RGBM_ERR_ARG, "rgbm_predict: bad argument");
+    if (f != m->F) return fail(RGBM_ERR_ARG, "rgbm_predict: feature count differs from the model's");
+    if (n == 0) return RGBM_OK;
+    return guarded([&]() {
+        use_device(device_id);
+        StreamGuard sg; hipStream_t s = sg.s;
+        DevBuf<int32_t> codes((size_t)n * f); codes.upload(X, (size_t)n * f, s);
+        const int ncol = m->objective == 2 ? 1 : m->num_class;
+        DevBuf<double> proba((size_t)n * ncol);
+        predict_device(const_cast<rgbm_model*>(m), device_id, s, codes.p, n, 0, n, nullptr, proba.p, nullptr, nullptr);
+        HIPCHK(hipMemcpy(out, proba.p, (size_t)n * ncol * sizeof(double), hipMemcpyDeviceToHost));
+        return RGBM_OK;
+    });
+}
+
+static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* target_col, const int32_t* feat_cols, const int32_t* feat_off,
+                        const int32_t* class_code, const int32_t* class_off, int32_t* d_codes, long long Ntab, long long row0, long long n,
+                        int device, hipStream_t s, int32_t* out_label, double* out_prob) {
+    using namespace rg;
+    DevBuf<int32_t> d_label(n); DevBuf<double> d_top(n);
+    for (int t = 0; t < T; ++t) {
+        rgbm_model* m = models[t];
+        const int F = feat_off[t + 1] - feat_off[t];
+        if (F != m->F) throw std::invalid_argument("chain: feature list length differs from the model's feature count");
+        DevBuf<int32_t> d_fc(F); d_fc.upload(feat_cols + feat_off[t], F, s);
+        predict_device(m, device, s, d_codes, Ntab, row0, n, d_fc.p, nullptr, d_label.p, d_top.p);
+        if (m->objective != 2) {
+            int ncc = class_off ? class_off[t + 1] - class_off[t] : m->num_class;
+            DevBuf<int32_t> d_cc(std::max(ncc, 1));
+            std::vector<int32_t> cc(std::max(ncc, 1), 0);
+            for (int i = 0; i < ncc; ++i) cc[i] = class_code ? class_code[class_off[t] + i] : i;
+            d_cc.upload(cc.data(), cc.size(), s);
+            hipLaunchKernelGGL(k_fill_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes + (long long)target_col[t] * Ntab + row0, n, d_label.p, d_cc.p, ncc);
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        if (out_label) HIPCHK(hipMemcpy(out_label + (size_t)t * n, d_label.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (out_prob) HIPCHK(hipMemcpy(out_prob + (size_t)t * n, d_top.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return RGBM_OK;
+}
+
+RGBM_EXPORT int rgbm_repair_chain(const rgbm_model* const* models, int32_t T, const int32_t* target_col, const int32_t* feat_cols,
+                                  const int32_t* feat_off, const int32_t* class_code, const int32_t* class_off, int32_t* table, int64_t n,
+                                  int32_t c, int32_t device_id, int32_t* out_label, double* out_prob) {
+    if (!models || T < 0 || !target_col || !feat_cols || !feat_off || !class_off || !table || n < 0 || c <= 0) return fail(RGBM_ERR_ARG, "rgbm_repair_chain: bad argument");
+    if (n == 0 || T == 0) return RGBM_OK;
+    return guarded([&]() {
+        use_device(device_id);
+        StreamGuard sg; hipStream_t s = sg.s;
+        DevBuf<int32_t> codes((size_t)n * c); codes.upload(table, (size_t)n * c, s);
+        chain_device(const_cast<rgbm_model* const*>(models), T, target_col, feat_cols, feat_off, class_code, class_off, codes.p, n, 0, n, device_id, s, out_label, out_prob);
+        HIPCHK(hipMemcpy(table, codes.p, (size_t)n * c * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_table_repair_chain(rgbm_table* t, const rgbm_model* const* models, int32_t T, const int32_t* target_col,
+                                        const int32_t* feat_cols, const int32_t* feat_off, int64_t row_begin, int64_t n_rows,
+                                        int32_t* out_label, double* out_prob) {
+    if (!t || !models || T < 0 || !target_col || !feat_cols || !feat_off || row_begin < 0 || n_rows < 0 || row_begin + n_rows > t->n)
+        return fail(RGBM_ERR_ARG, "rgbm_table_repair_chain: bad argument");
+    if (n_rows == 0 || T == 0) return RGBM_OK;
+    return guarded([&]() {
+        use_device(t->device);
+        StreamGuard sg;
+        return chain_device(const_cast<rgbm_model* const*>(models), T, target_col, feat_cols, feat_off, nullptr, nullptr, t->codes.p, t->n, row_begin, n_rows,
+                            t->device, sg.s, out_label, out_prob);
+    });
+}
+
+RGBM_EXPORT int rgbm_model_save(const rgbm_model* m, void* buf, size_t* len) {
+    if (!m || !len) return fail(RGBM_ERR_ARG, "rgbm_model_save: bad argument");
+    return guarded([&]() {
+        std::vector<uint8_t> b = serialise(*m);
+        if (!buf) { *len = b.size(); return RGBM_OK; }
+        if (*len < b.size()) { *len = b.size(); return fail(RGBM_ERR_ARG, "rgbm_model_save: buffer too small"); }
+        memcpy(buf, b.data(), b.size()); *len = b.size();
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_model_load(const void* buf, size_t len, rgbm_model** out) {
+    if (!buf || !out) return fail(RGBM_ERR_ARG, "rgbm_model_load: bad argument");
+    return guarded([&]() {
+        const uint8_t* p = (const uint8_t*)buf; const uint8_t* end = p + len;
+        auto need = [&](size_t n) { if ((size_t)(end - p) < n) throw std::length_error("truncated model"); };
+        try {
+            need(28); int32_t hdr[7]; memcpy(hdr, p, 28); p += 28;
+            if (hdr[0] != 0x4D424752 || hdr[1] != 1) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad magic/version");
+            std::unique_ptr<rgbm_model> m(new rgbm_model());
+            m->objective = hdr[2]; m->num_class = hdr[3]; m->K = hdr[4]; m->n_iter = hdr[5]; m->F = hdr[6];
+            if (m->F < 0 || m->K < 1 || m->n_iter < 0 || m->F > 65535) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad header");
+            m->feats.resize(m->F);
+            for (Feat& f : m->feats) {
+                need(12); int32_t h3[3]; memcpy(h3, p, 12); p += 12;
+                f.n_codes = h3[0]; f.V = h3[1]; f.has_nan = h3[2];
+                if (f.V < 0 || f.V > 255) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad bin count");
+                need(4 * (size_t)f.V); f.ub.resize(f.V); memcpy(f.ub.data(), p, 4 * (size_t)f.V); p += 4 * (size_t)f.V;
+            }
+            m->trees.resize((size_t)m->n_iter * m->K);
+            for (Tree& t : m->trees) {
+                need(4); memcpy(&t.L, p, 4); p += 4;
+                if (t.L < 1 || t.L > 32767) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad leaf count");
+                const size_t n = (size_t)t.L - 1;
+                need(n * 28 + (size_t)t.L * 12);
+                auto rd32 = [&](std::vector<int32_t>& v, size_t k) { v.resize(k); memcpy(v.data(), p, 4 * k); p += 4 * k; };
+                auto rd64 = [&](std::vector<double>& v, size_t k) { v.resize(k); memcpy(v.data(), p, 8 * k); p += 8 * k; };
+                rd32(t.feat, n); rd32(t.theta, n); rd32(t.dleft, n); rd32(t.left, n); rd32(t.right, n); rd64(t.gain, n);
+                rd64(t.leaf_value, t.L); rd32(t.leaf_count, t.L);
+                for (size_t j = 0; j < n; ++j) {
+                    if (t.feat[j] < 0 || t.feat[j] >= m->F) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: node feature out of range");
+                    auto okc = [&](int ch) { return ch < 0 ? (~ch) < t.L : ch < (int)n && ch > (int)j; };
+                    if (!okc(t.left[j]) || !okc(t.right[j])) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad child link");
+                }
+            }
+            *out = m.release();
+            return RGBM_OK;
+        } catch (const std::length_error&) { return fail(RGBM_ERR_FORMAT, "rgbm_model_load: truncated buffer"); }
+    });
+}
+
+RGBM_EXPORT void rgbm_model_free(rgbm_model* m) { delete m; }
+
+RGBM_EXPORT int rgbm_model_info(const rgbm_model* m, int32_t* info) {
+    if (!m || !info) return fail(RGBM_ERR_ARG, "rgbm_model_info: bad argument");
+    info[0] = m->objective; info[1] = m->num_class; info[2] = m->K; info[3] = m->n_iter; info[4] = m->F;
+    return RGBM_OK;
+}
+
+RGBM_EXPORT int rgbm_model_importance(const rgbm_model* m, int32_t type, double* out) {
+    if (!m || !out) return fail(RGBM_ERR_ARG, "rgbm_model_importance: bad argument");
+    for (int f = 0; f < m->F; ++f) out[f] = 0.0;
+    for (const Tree& t : m->trees) for (int j = 0; j < t.L - 1; ++j) out[t.feat[j]] += type == 0 ? 1.0 : t.gain[j];
+    return RGBM_OK;
+}
+
+}  // extern "C"

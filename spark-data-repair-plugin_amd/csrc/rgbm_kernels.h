@@ -1,0 +1,730 @@
+// rgbm_kernels.h -- hand-written HIP kernels for gfx950 (wave64, 160 KiB LDS/CU).
+//
+// Kernel inventory (LightGBM concept each one re-creates):
+//   k_count_codes    per-feature code frequencies of the training rows   (BinMapper::FindBin input)
+//   k_pack_bins      int32 codes -> u8 bin records, 16 features / 16 B    (Dataset construction)
+//   k_grad_*         scores -> quantised (g,h) per row and class          (ObjectiveFunction::GetGradients)
+//   k_hist           packed-u64 LDS histogram scan  *** the roofline kernel ***  (ConstructHistograms)
+//   k_split_find     parent-minus-child subtraction + per-feature threshold scan (FindBestThreshold)
+//   k_tree_step      argmax over features/leaves, Tree::Split bookkeeping
+//   k_partition      unstable two-cursor row partition                    (DataPartition::Split)
+//   k_finish_split   child ranges, BeforeFindBestSplit checks, smaller-child choice
+//   k_finalize_tree / k_score_update   shrinkage, AddBias, ScoreUpdater::AddScore
+//   k_predict_raw / k_softmax_argmax / k_fill_cells   GBDT::PredictRaw + chain fill (model.py:1118-1133)
+//
+// No path here is a dense contraction, so MFMA is unused by design; every kernel is an HBM scan
+// or an LDS/atomic-bound reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rgbm_device.h"
+#include "rgbm_numerics.h"
+
+namespace rg {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ------------------------------------------------------------------------------------------------
+// K0: code frequencies.  grid (gx, F), block 256.  Small dictionaries are privatised in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int COUNT_LDS_CODES = 8192;
+__global__ __launch_bounds__(256) void k_count_codes(const int32_t* __restrict__ codes, long long N,
+                                                     const int32_t* __restrict__ ycol /* training rows: ycol[row] >= 0; may be null */,
+                                                     const int32_t* __restrict__ feat_col, const int32_t* __restrict__ n_codes,
+                                                     const long long* __restrict__ cnt_off, unsigned int* __restrict__ cnt) {
+    __shared__ unsigned int lc[COUNT_LDS_CODES];
+    const int f = blockIdx.y;
+    const int32_t* col = codes + (long long)feat_col[f] * N;
+    const int nc = n_codes[f];
+    unsigned int* out = cnt + cnt_off[f];
+    const bool use_lds = nc <= COUNT_LDS_CODES;
+    if (use_lds) { for (int i = threadIdx.x; i < nc; i += 256) lc[i] = 0; __syncthreads(); }
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < N; r += (long long)gridDim.x * 256) {
+        if (ycol && ycol[r] < 0) continue;
+        int c = col[r];
+        if (c < 0 || c >= nc) continue;
+        if (use_lds) atomicAdd(&lc[c], 1u); else atomicAdd(&out[c], 1u);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc; i += 256) { unsigned v = lc[i]; if (v) atomicAdd(&out[i], v); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: bin_pack.  thread per row; one 16-byte record per (chunk,row).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_bins(const int32_t* __restrict__ codes, long long Ntab, long long row0, long long n,
+                                                   const int32_t* __restrict__ feat_col, const int32_t* __restrict__ n_codes,
+                                                   const long long* __restrict__ lut_off, const uint8_t* __restrict__ lut,
+                                                   const uint8_t* __restrict__ miss_bin, int F, int nchunk, uint4* __restrict__ rec) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int f = ch * 16 + j;
+            uint32_t b = 0;
+            if (f < F) {
+                int c = codes[(long long)feat_col[f] * Ntab + row0 + i];
+                b = (c < 0 || c >= n_codes[f]) ? miss_bin[f] : lut[lut_off[f] + c];
+            }
+            w[j >> 2] |= b << (8 * (j & 3));
+        }
+        rec[(long long)ch * n + i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+__global__ void k_iota_train(const int32_t* __restrict__ ycol, long long N, int32_t* __restrict__ out, unsigned int* __restrict__ counter) {
+    // unstable compaction of training rows (order is irrelevant: every sum downstream is an exact integer)
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool on = r < N && ycol[r] >= 0;
+    unsigned long long m = __ballot(on);
+    int lane = lane_id();
+    unsigned int base = 0;
+    if (lane == 0 && m) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = __shfl(base, 0);
+    if (on) out[base + __popcll(m & ((1ull << lane) - 1))] = (int32_t)r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: gradients.  thread per row (grid-stride); scores read coalesced per class.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_score(double* __restrict__ score, long long N, int K, const double* __restrict__ init) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    for (int k = 0; k < K; ++k) score[(long long)k * N + i] = init[k];
+}
+
+template <int OBJ>
+__global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+                                              const double* __restrict__ y_value, const double* __restrict__ class_w,
+                                              const double* __restrict__ sample_w, int2* __restrict__ gh, TrainConst c) {
+    const long long N = c.N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+        const int y = ycol[i];
+        if (y < 0) continue;   // not a training row: its gh stays 0 for ever
+        double wi = class_w ? class_w[y] : 1.0;
+        if (sample_w) wi = wi * sample_w[i];
+        if (OBJ == 0) {
+            double label = (y > 0) ? 1.0 : -1.0;
+            double response = -label / (1.0 + rg_exp(label * score[i]));
+            double abs_r = fabs(response);
+            double g = response * wi, h = abs_r * (1.0 - abs_r) * wi;
+            gh[i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+        } else if (OBJ == 2) {
+            double g = (score[i] - y_value[y]) * wi, h = wi;
+            gh[i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+        } else {
+            const int K = c.K;
+            double wmax = score[i];
+            for (int k = 1; k < K; ++k) { double s = score[(long long)k * N + i]; if (s > wmax) wmax = s; }
+            double wsum = 0.0;
+            for (int k = 0; k < K; ++k) wsum += rg_exp(score[(long long)k * N + i] - wmax);
+            for (int k = 0; k < K; ++k) {
+                double pk = rg_exp(score[(long long)k * N + i] - wmax) / wsum;
+                double g = ((y == k) ? (pk - 1.0) : pk) * wi;
+                double h = c.factor * pk * (1.0 - pk) * wi;
+                gh[(long long)k * N + i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: hist_build -- THE roofline kernel.
+//   grid (gx, K, nchunk), block 256.  Each lane owns one row per step: one dwordx4 load brings its
+//   16 bin codes, one dwordx2 load its (g,h); (g<<32 | h) is ONE 64-bit LDS atomic per feature
+//   into a per-workgroup packed histogram.  Low-cardinality features are replicated `rep` times
+//   (slot = bin*rep + lane%rep) so that lanes hitting the same bin do not serialise on one LDS
+//   address.  Every TILE_ROWS rows the packed 32+32-bit slots are drained into a 64+64-bit LDS
+//   histogram (no overflow: 2048*(2^20-1) < 2^31, 2048*(2^21-1) < 2^32), which is flushed to the
+//   leaf's global histogram with 64-bit atomics once per workgroup.  All sums are integers, so
+//   the result is independent of scheduling.
+//   Algorithmic bytes per scanned row: 16 B/chunk of bins (F useful) + 8 B (g,h) (+4 B row index
+//   off the root).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, const int2* __restrict__ gh,
+                                              const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1,
+                                              const int32_t* __restrict__ base_idx, const TreeState* __restrict__ state,
+                                              HistBin* __restrict__ pool, const FeatMeta* __restrict__ fmeta,
+                                              const ChunkMeta* __restrict__ cmeta, TrainConst c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int k = blockIdx.y, ch = blockIdx.z;
+    const TreeState st = state[k];
+    if (!st.do_hist) return;
+    const ChunkMeta cm = cmeta[ch];
+    unsigned long long* fast = reinterpret_cast<unsigned long long*>(smem);
+    HistBin* wide = reinterpret_cast<HistBin*>(smem + (size_t)cm.fast_slots * 8);
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < cm.fast_slots; i += 256) fast[i] = 0ull;
+    for (int i = tid; i < cm.wide_bins; i += 256) { wide[i].g = 0; wide[i].h = 0; }
+    __syncthreads();
+
+    // per-feature slot bases / replication shifts of this chunk (uniform -> scalar registers)
+    int fbase[16], fshift[16];
+    const FeatMeta* fm = fmeta + cm.first_feat;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < cm.nfeat) { fbase[j] = fm[j].fast_base; fshift[j] = fm[j].rep_shift; } else { fbase[j] = 0; fshift[j] = 0; }
+    }
+    const long long N = c.N;
+    const long long cnt = st.hist_is_root ? N : (long long)st.hist_count;
+    const int32_t* idx = st.hist_buf == 0 ? idx0 + (long long)k * c.n_train : (st.hist_buf == 1 ? idx1 + (long long)k * c.n_train : base_idx);
+    const uint4* recc = rec + (long long)ch * N;
+    const int2* ghk = gh + (long long)k * N;
+    const long long ntiles = (cnt + TILE_ROWS - 1) / TILE_ROWS;
+
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long p0 = t * TILE_ROWS;
+#pragma unroll 2
+        for (int s = 0; s < TILE_ROWS / 256; ++s) {
+            long long p = p0 + s * 256 + tid;
+            if (p < cnt) {
+                long long row = st.hist_is_root ? p : (long long)idx[st.hist_begin + p];
+                uint4 r = recc[row];
+                int2 g = ghk[row];
+                unsigned long long packed = ((unsigned long long)(long long)g.x << 32) + (unsigned long long)(unsigned int)g.y;
+                if (packed != 0ull) {
+                    uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (j < cm.nfeat) {
+                            uint32_t bin = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                            int slot = fbase[j] + (int)(bin << fshift[j]) + (lane & ((1 << fshift[j]) - 1));
+                            atomicAdd(&fast[slot], packed);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // drain packed -> wide
+        for (int j = 0; j < cm.nfeat; ++j) {
+            const int nslots = fm[j].nbins << fm[j].rep_shift;
+            for (int s2 = tid; s2 < nslots; s2 += 256) {
+                unsigned long long v = fast[fm[j].fast_base + s2];
+                if (v) {
+                    fast[fm[j].fast_base + s2] = 0ull;
+                    int bin = s2 >> fm[j].rep_shift;
+                    long long gq = (long long)(int)(v >> 32);
+                    long long hq = (long long)(unsigned int)(v & 0xFFFFFFFFull);
+                    HistBin* wb = &wide[fm[j].wide_off + bin];
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&wb->g), (unsigned long long)gq);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&wb->h), (unsigned long long)hq);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // flush to the leaf histogram being built (always the slot of the newest leaf; root: slot 0)
+    const int slot_leaf = st.hist_is_root ? 0 : st.right_leaf;
+    HistBin* dst = pool + ((long long)k * c.num_leaves + slot_leaf) * c.totbins;
+    for (int j = 0; j < cm.nfeat; ++j) {
+        for (int b = tid; b < fm[j].nbins; b += 256) {
+            HistBin v = wide[fm[j].wide_off + b];
+            HistBin* d = &dst[fm[j].hoff + b];
+            if (v.g) atomicAdd(reinterpret_cast<unsigned long long*>(&d->g), (unsigned long long)v.g);
+            if (v.h) atomicAdd(reinterpret_cast<unsigned long long*>(&d->h), (unsigned long long)v.h);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4+K5: histogram subtraction + per-feature threshold scan.  One wave per (class tree, feature):
+// lane l owns bins 4l..4l+3, integer prefix sums by wave scan, gains in double (rgbm_numerics.h),
+// wave arg-max with LightGBM's visiting-order tie-breaks.  grid (ceil(F/4), K), block 256.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_incl_scan(long long v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        long long o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+struct ScanBest { double gain; int theta; long long lg, lh; };
+
+// a beats b?  reverse scan: larger theta first on ties; forward scan: smaller theta first
+template <bool REVERSE>
+__device__ __forceinline__ bool scan_better(double ga, int ta, double gb, int tb) {
+    if (ga != gb) return ga > gb;
+    return REVERSE ? (ta > tb) : (ta < tb);
+}
+
+__device__ void scan_child(const long long (&bg)[4], const long long (&bh)[4], const FeatMeta& fm, long long Gq, long long Hq,
+                           long long num_data, const TrainConst& c, Cand* out) {
+    const int lane = lane_id();
+    const int V = fm.V;
+    const double keps = k_eps();
+    const double sum_gradient = (double)Gq * c.inv_sg;
+    const double sum_hessian = (double)Hq * c.inv_sh + 2 * keps;
+    const double gain_shift = leaf_gain(sum_gradient, sum_hessian, c.l1, c.l2);
+    const double min_gain_shift = gain_shift + c.min_gain_to_split;
+    const double cnt_factor = (double)num_data / sum_hessian;
+    const bool two_way = fm.has_nan && V >= 1;
+
+    // per-lane local values over VALUE bins only (NaN bin excluded from the scans)
+    long long lg[4], lh[4], lc[4];
+    long long tg = 0, th = 0, tc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int b = lane * 4 + j;
+        bool val = b < V;
+        lg[j] = val ? bg[j] : 0; lh[j] = val ? bh[j] : 0;
+        lc[j] = val ? round_int((double)bh[j] * c.inv_sh * cnt_factor) : 0;
+        tg += lg[j]; th += lh[j]; tc += lc[j];
+    }
+    long long ig = wave_incl_scan(tg), ih = wave_incl_scan(th), ic = wave_incl_scan(tc);
+    const long long TG = __shfl(ig, 63), TH = __shfl(ih, 63), TC = __shfl(ic, 63);
+    long long pg = ig - tg, ph = ih - th, pc = ic - tc;   // exclusive prefix at the lane's first bin
+
+    ScanBest rv = {-INFINITY, 0, 0, 0}, fw = {-INFINITY, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int b = lane * 4 + j;
+        if (b < V) {
+            // REVERSE candidate theta = b-1: right = value bins >= b (NaN rows stay left)
+            {
+                long long rg = TG - pg, rh = TH - ph, right_count = TC - pc;
+                double sum_right_hessian = (double)rh * c.inv_sh + keps;
+                long long left_count = num_data - right_count;
+                long long lhq = Hq - rh, lgq = Gq - rg;
+                double sum_left_hessian = (double)lhq * c.inv_sh + keps;
+                bool ok = !(right_count < c.min_data_in_leaf || sum_right_hessian < c.min_sum_hessian) &&
+                          !(left_count < c.min_data_in_leaf) && !(sum_left_hessian < c.min_sum_hessian);
+                if (ok) {
+                    double cur = leaf_gain((double)lgq * c.inv_sg, sum_left_hessian, c.l1, c.l2) +
+                                 leaf_gain((double)rg * c.inv_sg, sum_right_hessian, c.l1, c.l2);
+                    if (cur > min_gain_shift && scan_better<true>(cur, b - 1, rv.gain, rv.theta)) { rv.gain = cur; rv.theta = b - 1; rv.lg = lgq; rv.lh = lhq; }
+                }
+            }
+            pg += lg[j]; ph += lh[j]; pc += lc[j];   // now inclusive through b
+            if (two_way) {
+                // FORWARD candidate theta = b: left = value bins <= b (NaN rows go right)
+                long long lgq = pg, lhq = ph, left_count = pc;
+                double sum_left_hessian = (double)lhq * c.inv_sh + keps;
+                long long right_count = num_data - left_count;
+                long long rh = Hq - lhq, rg = Gq - lgq;
+                double sum_right_hessian = (double)rh * c.inv_sh + keps;
+                bool ok = !(left_count < c.min_data_in_leaf || sum_left_hessian < c.min_sum_hessian) &&
+                          !(right_count < c.min_data_in_leaf) && !(sum_right_hessian < c.min_sum_hessian);
+                if (ok) {
+                    double cur = leaf_gain((double)lgq * c.inv_sg, sum_left_hessian, c.l1, c.l2) +
+                                 leaf_gain((double)rg * c.inv_sg, sum_right_hessian, c.l1, c.l2);
+                    if (cur > min_gain_shift && scan_better<false>(cur, b, fw.gain, fw.theta)) { fw.gain = cur; fw.theta = b; fw.lg = lgq; fw.lh = lhq; }
+                }
+            }
+        }
+    }
+    // wave arg-max (butterfly: every lane ends with the winner)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double g2 = __shfl_xor(rv.gain, off); int t2 = __shfl_xor(rv.theta, off);
+        long long a2 = __shfl_xor(rv.lg, off), b2 = __shfl_xor(rv.lh, off);
+        if (scan_better<true>(g2, t2, rv.gain, rv.theta)) { rv.gain = g2; rv.theta = t2; rv.lg = a2; rv.lh = b2; }
+        g2 = __shfl_xor(fw.gain, off); t2 = __shfl_xor(fw.theta, off);
+        a2 = __shfl_xor(fw.lg, off); b2 = __shfl_xor(fw.lh, off);
+        if (scan_better<false>(g2, t2, fw.gain, fw.theta)) { fw.gain = g2; fw.theta = t2; fw.lg = a2; fw.lh = b2; }
+    }
+    if (lane == 0) {
+        Cand o; o.gain = -INFINITY; o.theta = 0; o.dleft = 1; o.left_gq = 0; o.left_hq = 0; o.left_out = 0.0; o.right_out = 0.0;
+        if (rv.gain > -INFINITY && rv.gain > o.gain + min_gain_shift) {
+            o.theta = rv.theta; o.dleft = 1; o.left_gq = rv.lg; o.left_hq = rv.lh;
+            double lH = (double)rv.lh * c.inv_sh + keps, rH = (double)(Hq - rv.lh) * c.inv_sh + keps;
+            o.left_out = leaf_output((double)rv.lg * c.inv_sg, lH, c.l1, c.l2);
+            o.right_out = leaf_output((double)(Gq - rv.lg) * c.inv_sg, rH, c.l1, c.l2);
+            o.gain = rv.gain - min_gain_shift;
+        }
+        if (fw.gain > -INFINITY && fw.gain > o.gain + min_gain_shift) {
+            o.theta = fw.theta; o.dleft = 0; o.left_gq = fw.lg; o.left_hq = fw.lh;
+            double lH = (double)fw.lh * c.inv_sh + keps, rH = (double)(Hq - fw.lh) * c.inv_sh + keps;
+            o.left_out = leaf_output((double)fw.lg * c.inv_sg, lH, c.l1, c.l2);
+            o.right_out = leaf_output((double)(Gq - fw.lg) * c.inv_sg, rH, c.l1, c.l2);
+            o.gain = fw.gain - min_gain_shift;
+        }
+        *out = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_split_find(HistBin* __restrict__ pool, const TreeState* __restrict__ state,
+                                                    Leaf* __restrict__ leaves, const FeatMeta* __restrict__ fmeta,
+                                                    const uint8_t* __restrict__ used /* [K][F] */, Cand* __restrict__ cand /* [K][2][F] */,
+                                                    TrainConst c) {
+    const int k = blockIdx.y;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= c.F) return;
+    const TreeState st = state[k];
+    if (!st.do_hist) return;
+    const int lane = lane_id();
+    Cand* ck = cand + (long long)k * 2 * c.F;
+    const FeatMeta fm = fmeta[f];
+    HistBin* pk = pool + (long long)k * c.num_leaves * c.totbins;
+    Leaf* lk = leaves + (long long)k * c.num_leaves;
+    long long ag[4], ah[4], bgv[4], bhv[4];
+    if (st.hist_is_root) {
+        const HistBin* h0 = pk + fm.hoff;
+        long long sg_ = 0, sh_ = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int b = lane * 4 + j;
+            if (b < fm.nbins) { HistBin v = h0[b]; ag[j] = v.g; ah[j] = v.h; } else { ag[j] = 0; ah[j] = 0; }
+            sg_ += ag[j]; sh_ += ah[j];
+        }
+        // leaf totals = sum over all bins of any one feature (every row sits in exactly one bin)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sg_ += __shfl_xor(sg_, off); sh_ += __shfl_xor(sh_, off); }
+        if (f == 0 && lane == 0) { lk[0].Gq = sg_; lk[0].Hq = sh_; }
+        if (!used[(long long)k * c.F + f]) { if (lane == 0) ck[f].gain = -INFINITY; return; }
+        scan_child(ag, ah, fm, sg_, sh_, (long long)lk[0].count, c, &ck[f]);
+        return;
+    }
+    // children of the last split: parent histogram lives in slot[left leaf], the freshly built
+    // smaller child in slot[right leaf]; rewrite both slots to hold (left, right).
+    HistBin* hl = pk + (long long)st.split_leaf * c.totbins + fm.hoff;
+    HistBin* hr = pk + (long long)st.right_leaf * c.totbins + fm.hoff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int b = lane * 4 + j;
+        if (b < fm.nbins) {
+            HistBin par = hl[b], built = hr[b];
+            HistBin l, r;
+            if (st.smaller_is_left) { l = built; r.g = par.g - built.g; r.h = par.h - built.h; }
+            else { r = built; l.g = par.g - built.g; l.h = par.h - built.h; }
+            hl[b] = l; hr[b] = r;
+            ag[j] = l.g; ah[j] = l.h; bgv[j] = r.g; bhv[j] = r.h;
+        } else { ag[j] = ah[j] = bgv[j] = bhv[j] = 0; }
+    }
+    if (!used[(long long)k * c.F + f]) { if (lane == 0) { ck[f].gain = -INFINITY; ck[c.F + f].gain = -INFINITY; } return; }
+    const Leaf L = lk[st.split_leaf], R = lk[st.right_leaf];
+    scan_child(ag, ah, fm, L.Gq, L.Hq, (long long)L.count, c, &ck[f]);
+    scan_child(bgv, bhv, fm, R.Gq, R.Hq, (long long)R.count, c, &ck[c.F + f]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tree_step: one wave per class tree.  (1) reduce the per-feature candidates of the freshly
+// searched leaves (SplitInfo::operator>: gain, then smaller feature); (2) pick the best leaf
+// (ArrayArgs::ArgMax); (3) Tree::Split bookkeeping and partition request.
+// ------------------------------------------------------------------------------------------------
+struct TreeOut {   // flat device arrays of every tree of the model, [(it*K+k)] major
+    int32_t* L; int32_t* feat; int32_t* theta; int32_t* dleft; int32_t* left; int32_t* right; double* gain;
+    double* leaf_value; int32_t* leaf_count;
+};
+
+__device__ __forceinline__ bool leaf_better(double ga, int fa, int la, double gb, int fb, int lb) {
+    if (ga != gb) return ga > gb;
+    int a = fa < 0 ? 0x7FFFFFFF : fa, b = fb < 0 ? 0x7FFFFFFF : fb;
+    if (a != b) return a < b;
+    return la < lb;
+}
+
+__device__ void reduce_leaf_best(const Cand* cf, int F, Leaf* leaf) {
+    const int lane = lane_id();
+    double bg = -INFINITY; int bf = -1;
+    for (int f = lane; f < F; f += 64) {
+        double g = cf[f].gain;
+        if (g > -INFINITY && leaf_better(g, f, 0, bg, bf, 0)) { bg = g; bf = f; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double g2 = __shfl_xor(bg, off); int f2 = __shfl_xor(bf, off);
+        if (leaf_better(g2, f2, 0, bg, bf, 0)) { bg = g2; bf = f2; }
+    }
+    if (lane == 0) {
+        if (bf >= 0) { leaf->best = cf[bf]; leaf->best_feature = bf; }
+        else { leaf->best.gain = -INFINITY; leaf->best_feature = -1; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tree_step(TreeState* __restrict__ state, Leaf* __restrict__ leaves, const Cand* __restrict__ cand,
+                                                  HistBin* __restrict__ pool, const FeatMeta* __restrict__ fmeta, TreeOut out, int it, TrainConst c) {
+    const int k = blockIdx.x, lane = lane_id();
+    TreeState* st = &state[k];
+    if (st->done) return;
+    Leaf* lk = leaves + (long long)k * c.num_leaves;
+    const Cand* ck = cand + (long long)k * 2 * c.F;
+    if (st->do_hist) {
+        if (st->hist_is_root) reduce_leaf_best(ck, c.F, &lk[0]);
+        else { reduce_leaf_best(ck, c.F, &lk[st->split_leaf]); reduce_leaf_best(ck + c.F, c.F, &lk[st->right_leaf]); }
+    }
+    __syncthreads();
+    const int L = st->L;
+    double bg = -INFINITY; int bf = -1, bl = 0x7FFFFFFF;
+    for (int l = lane; l < L; l += 64) {
+        double g = lk[l].best.gain; int f = lk[l].best_feature;
+        if (bl == 0x7FFFFFFF || leaf_better(g, f, l, bg, bf, bl)) { bg = g; bf = f; bl = l; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double g2 = __shfl_xor(bg, off); int f2 = __shfl_xor(bf, off), l2 = __shfl_xor(bl, off);
+        if (l2 != 0x7FFFFFFF && (bl == 0x7FFFFFFF || leaf_better(g2, f2, l2, bg, bf, bl))) { bg = g2; bf = f2; bl = l2; }
+    }
+    const long long tbase = (long long)it * c.K + k;
+    if (L >= c.num_leaves || !(bg > 0.0)) {
+        if (lane == 0) { st->done = 1; st->do_partition = 0; st->do_hist = 0; out.L[tbase] = L; }
+        return;
+    }
+    const int right_leaf = L, node = L - 1;
+    // zero the histogram slot the next hist pass will accumulate into
+    HistBin* zs = pool + ((long long)k * c.num_leaves + right_leaf) * c.totbins;
+    for (int i = lane; i < c.totbins; i += 64) { zs[i].g = 0; zs[i].h = 0; }
+    if (lane == 0) {
+        Leaf P = lk[bl];
+        const Cand sp = P.best;
+        const long long nb = tbase * (c.num_leaves - 1);
+        out.feat[nb + node] = bf; out.theta[nb + node] = sp.theta; out.dleft[nb + node] = sp.dleft; out.gain[nb + node] = sp.gain;
+        out.left[nb + node] = ~bl; out.right[nb + node] = ~right_leaf;
+        if (P.parent_node >= 0) { if (P.is_left) out.left[nb + P.parent_node] = node; else out.right[nb + P.parent_node] = node; }
+        out.leaf_value[tbase * c.num_leaves + bl] = sp.left_out;
+        out.leaf_value[tbase * c.num_leaves + right_leaf] = sp.right_out;
+        Leaf Lf = P, Rf = P;
+        Lf.parent_node = node; Lf.is_left = 1; Lf.depth = P.depth + 1; Lf.Gq = sp.left_gq; Lf.Hq = sp.left_hq;
+        Lf.best.gain = -INFINITY; Lf.best_feature = -1;
+        Rf.parent_node = node; Rf.is_left = 0; Rf.depth = P.depth + 1; Rf.Gq = P.Gq - sp.left_gq; Rf.Hq = P.Hq - sp.left_hq;
+        Rf.best.gain = -INFINITY; Rf.best_feature = -1;
+        lk[bl] = Lf; lk[right_leaf] = Rf;   // begin/count/buf are completed by k_finish_split
+        st->split_leaf = bl; st->right_leaf = right_leaf; st->L = L + 1;
+        st->do_partition = 1; st->do_hist = 0;
+        st->part_feature = bf; st->part_theta = sp.theta; st->part_dleft = sp.dleft;
+        st->part_nanbin = fmeta[bf].has_nan ? fmeta[bf].V : 255;
+        st->part_begin = P.begin; st->part_count = P.count; st->part_buf = P.buf;
+        st->cursor_left = 0; st->cursor_right = 0;
+        out.L[tbase] = L + 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: partition.  Unstable (order inside a leaf is irrelevant to integer sums): every workgroup
+// reserves output ranges from two global cursors; lefts fill from the front, rights from the back
+// of the leaf's range in the other ping-pong buffer.  grid (gx, K), block 256, 4 rows per thread.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_partition(const uint8_t* __restrict__ rec8, int32_t* __restrict__ idx0, int32_t* __restrict__ idx1,
+                                                   const int32_t* __restrict__ base_idx, TreeState* __restrict__ state, TrainConst c) {
+    __shared__ int wl[4], wr[4];
+    __shared__ unsigned int bases[2];
+    const int k = blockIdx.y;
+    TreeState* st = &state[k];
+    if (!st->do_partition) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cnt = st->part_count, beg = st->part_begin, pb = st->part_buf;
+    const int32_t* src = pb == 0 ? idx0 + (long long)k * c.n_train : (pb == 1 ? idx1 + (long long)k * c.n_train : base_idx);
+    int32_t* dst = (pb == 0 ? idx1 : idx0) + (long long)k * c.n_train;   // base list (2) -> buffer 0
+    const int f = st->part_feature, theta = st->part_theta, dleft = st->part_dleft, nanbin = st->part_nanbin;
+    const uint8_t* recf = rec8 + ((long long)(f >> 4) * c.N) * 16 + (f & 15);
+    const int ntiles = (cnt + 1023) / 1024;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int rows[4]; bool gl[4]; bool on[4];
+        int nl = 0, nr = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int p = t * 1024 + j * 256 + tid;
+            on[j] = p < cnt; gl[j] = false; rows[j] = 0;
+            if (on[j]) {
+                rows[j] = src[beg + p];
+                int bin = recf[(long long)rows[j] * 16];
+                gl[j] = (bin == nanbin) ? (dleft != 0) : (bin <= theta);
+                if (gl[j]) ++nl; else ++nr;
+            }
+        }
+        // exclusive scans of (nl, nr) across the workgroup
+        int sl = nl, sr = nr;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { int a = __shfl_up(sl, off), b = __shfl_up(sr, off); if (lane >= off) { sl += a; sr += b; } }
+        if (lane == 63) { wl[wv] = sl; wr[wv] = sr; }
+        __syncthreads();
+        int ol = sl - nl, orr = sr - nr, totl = 0, totr = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wv) { ol += wl[w]; orr += wr[w]; } totl += wl[w]; totr += wr[w]; }
+        if (tid == 0) { bases[0] = atomicAdd(&st->cursor_left, (unsigned)totl); bases[1] = atomicAdd(&st->cursor_right, (unsigned)totr); }
+        __syncthreads();
+        const int bl_ = (int)bases[0], br_ = (int)bases[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (on[j]) {
+                if (gl[j]) dst[beg + bl_ + ol++] = rows[j];
+                else dst[beg + cnt - 1 - (br_ + orr++)] = rows[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// one wave per class tree: complete the children's ranges and decide the next histogram pass
+__global__ __launch_bounds__(64) void k_finish_split(TreeState* __restrict__ state, Leaf* __restrict__ leaves, TreeOut out, int it, TrainConst c) {
+    const int k = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    TreeState* st = &state[k];
+    if (!st->do_partition) { st->do_hist = 0; return; }
+    Leaf* lk = leaves + (long long)k * c.num_leaves;
+    const int nl = (int)st->cursor_left, nr = st->part_count - nl;
+    const int nbuf = st->part_buf == 0 ? 1 : 0;
+    Leaf& Lf = lk[st->split_leaf]; Leaf& Rf = lk[st->right_leaf];
+    Lf.begin = st->part_begin; Lf.count = nl; Lf.buf = nbuf;
+    Rf.begin = st->part_begin + nl; Rf.count = nr; Rf.buf = nbuf;
+    const long long tbase = (long long)it * c.K + k;
+    out.leaf_count[tbase * c.num_leaves + st->split_leaf] = nl;
+    out.leaf_count[tbase * c.num_leaves + st->right_leaf] = nr;
+    st->do_partition = 0;
+    bool go = st->L < c.num_leaves;
+    if (c.max_depth > 0 && Lf.depth >= c.max_depth) go = false;
+    if (nr < c.min_data_in_leaf * 2 && nl < c.min_data_in_leaf * 2) go = false;
+    st->do_hist = go ? 1 : 0;
+    st->hist_is_root = 0;
+    st->smaller_is_left = nl < nr ? 1 : 0;
+    st->hist_begin = st->smaller_is_left ? Lf.begin : Rf.begin;
+    st->hist_count = st->smaller_is_left ? nl : nr;
+    st->hist_buf = nbuf;
+}
+
+__global__ __launch_bounds__(64) void k_init_iter(TreeState* __restrict__ state, Leaf* __restrict__ leaves, HistBin* __restrict__ pool,
+                                                  TreeOut out, int it, TrainConst c) {
+    const int k = blockIdx.x, lane = lane_id();
+    HistBin* z = pool + (long long)k * c.num_leaves * c.totbins;
+    for (int i = lane; i < c.totbins; i += 64) { z[i].g = 0; z[i].h = 0; }
+    if (lane == 0) {
+        TreeState s; memset(&s, 0, sizeof(s));
+        s.L = 1; s.done = 0; s.hist_is_root = 1; s.hist_begin = 0; s.hist_count = (int)c.n_train; s.hist_buf = 2;
+        s.do_hist = (c.n_train < (long long)c.min_data_in_leaf * 2) ? 0 : 1;
+        state[k] = s;
+        Leaf r; memset(&r, 0, sizeof(r));
+        r.begin = 0; r.count = (int)c.n_train; r.buf = 2; r.depth = 0; r.parent_node = -1; r.is_left = 0;
+        r.best.gain = -INFINITY; r.best_feature = -1;
+        leaves[(long long)k * c.num_leaves] = r;
+        const long long tbase = (long long)it * c.K + k;
+        out.L[tbase] = 1;
+        out.leaf_count[tbase * c.num_leaves] = (int)c.n_train;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: shrinkage + score update.  k_finalize_tree sorts the (<= num_leaves) leaf ranges; the update
+// kernel finds each position's leaf by binary search in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_finalize_tree(const TreeState* __restrict__ state, const Leaf* __restrict__ leaves, TreeOut out,
+                                                      const double* __restrict__ init, double* __restrict__ upd_value /* [K][NL] */,
+                                                      int32_t* __restrict__ sorted /* [K][NL][3] begin,count,leaf */, int32_t* __restrict__ any_split,
+                                                      int it, TrainConst c) {
+    const int k = blockIdx.x, lane = lane_id();
+    const int L = state[k].L;
+    const Leaf* lk = leaves + (long long)k * c.num_leaves;
+    const long long tbase = (long long)it * c.K + k;
+    double* lv = out.leaf_value + tbase * c.num_leaves;
+    double* uv = upd_value + (long long)k * c.num_leaves;
+    int32_t* so = sorted + (long long)k * c.num_leaves * 3;
+    if (L <= 1) {
+        if (lane == 0) { lv[0] = (it == 0) ? init[k] : 0.0; uv[0] = 0.0; so[0] = 0; so[1] = 0; so[2] = 0; }
+        return;
+    }
+    if (lane == 0) atomicOr(any_split + it, 1);
+    for (int l = lane; l < L; l += 64) {
+        double v = lv[l] * c.learning_rate;    // Tree::Shrinkage
+        uv[l] = v;
+        if (it == 0 && fabs(init[k]) > k_eps()) v += init[k];   // Tree::AddBias (model only; scores already hold init)
+        lv[l] = v;
+        int rank = 0;
+        const int b = lk[l].begin, n = lk[l].count;
+        for (int m = 0; m < L; ++m) {
+            const int b2 = lk[m].begin, n2 = lk[m].count;
+            if (b2 < b || (b2 == b && (n2 < n || (n2 == n && m < l)))) ++rank;
+        }
+        so[rank * 3] = b; so[rank * 3 + 1] = n; so[rank * 3 + 2] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_score_update(const TreeState* __restrict__ state, const Leaf* __restrict__ leaves,
+                                                      const int32_t* __restrict__ sorted, const double* __restrict__ upd_value,
+                                                      const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1,
+                                                      const int32_t* __restrict__ base_idx, double* __restrict__ score, TrainConst c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int k = blockIdx.y;
+    const int L = state[k].L;
+    if (L <= 1) return;
+    int32_t* sb = reinterpret_cast<int32_t*>(smem);        // [L] begin
+    int32_t* sl = sb + c.num_leaves;                       // [L] leaf
+    int32_t* sbuf = sl + c.num_leaves;                     // [L] buf
+    double* sv = reinterpret_cast<double*>(sbuf + c.num_leaves + (c.num_leaves & 1));
+    const int32_t* so = sorted + (long long)k * c.num_leaves * 3;
+    const Leaf* lk = leaves + (long long)k * c.num_leaves;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        int leaf = so[i * 3 + 2];
+        sb[i] = so[i * 3]; sl[i] = leaf; sbuf[i] = lk[leaf].buf; sv[i] = upd_value[(long long)k * c.num_leaves + leaf];
+    }
+    __syncthreads();
+    double* sk = score + (long long)k * c.N;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < c.n_train; p += (long long)gridDim.x * 256) {
+        int lo = 0, hi = L - 1;    // last i with sb[i] <= p
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (sb[mid] <= (int)p) lo = mid; else hi = mid - 1; }
+        const int bf = sbuf[lo];
+        const int32_t* src = bf == 0 ? idx0 + (long long)k * c.n_train : (bf == 1 ? idx1 + (long long)k * c.n_train : base_idx);
+        const int row = src[p];
+        sk[row] += sv[lo];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9: batched leaf walk.  grid (ceil(n/256), K), block 256: thread = (row, class); 8-byte nodes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_predict_raw(const uint8_t* __restrict__ rec8, long long n, const PNode* __restrict__ nodes,
+                                                     const double* __restrict__ leaf_value, int n_iter, int K, int node_stride, int leaf_stride,
+                                                     double* __restrict__ raw /* [K][n] */) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int it = 0; it < n_iter; ++it) {
+        const long long t = (long long)it * K + k;
+        const PNode* nd = nodes + t * node_stride;
+        int node = 0;
+        for (;;) {
+            const PNode p = nd[node];
+            const int f = p.w0 & 0xFFFF, theta = (int)((p.w0 >> 16) & 0x1FF) - 1, dleft = (p.w0 >> 25) & 1;
+            const int bin = rec8[((long long)(f >> 4) * n + i) * 16 + (f & 15)];
+            const bool go_left = (bin == 255) ? (dleft != 0) : (bin <= theta);
+            const int nx = go_left ? (int)(short)(p.w1 & 0xFFFF) : (int)(short)(p.w1 >> 16);
+            if (nx < 0) { s += leaf_value[t * leaf_stride + (~nx)]; break; }
+            node = nx;
+        }
+    }
+    raw[(long long)k * n + i] = s;
+}
+
+// ConvertOutput + arg-max (first maximum).  proba may be null (labels only).
+__global__ __launch_bounds__(256) void k_softmax_argmax(const double* __restrict__ raw, long long n, int objective, int K,
+                                                        double* __restrict__ proba /* [n][ncol] or null */, int32_t* __restrict__ label, double* __restrict__ top) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (objective == 2) { double v = raw[i]; if (proba) proba[i] = v; if (label) label[i] = -1; if (top) top[i] = v; return; }
+    if (objective == 0) {
+        double pr = 1.0 / (1.0 + rg_exp(-raw[i]));
+        double p0 = 1.0 - pr;
+        if (proba) { proba[i * 2] = p0; proba[i * 2 + 1] = pr; }
+        int best = (pr > p0) ? 1 : 0;
+        if (label) label[i] = best;
+        if (top) top[i] = best ? pr : p0;
+        return;
+    }
+    double wmax = raw[i];
+    for (int k = 1; k < K; ++k) { double s = raw[(long long)k * n + i]; if (s > wmax) wmax = s; }
+    double wsum = 0.0;
+    for (int k = 0; k < K; ++k) wsum += rg_exp(raw[(long long)k * n + i] - wmax);
+    int best = 0; double bp = -1.0;
+    for (int k = 0; k < K; ++k) {
+        double pk = rg_exp(raw[(long long)k * n + i] - wmax) / wsum;
+        if (proba) proba[i * K + k] = pk;
+        if (pk > bp) { bp = pk; best = k; }
+    }
+    if (label) label[i] = best;
+    if (top) top[i] = bp;
+}
+
+// K10: fill only NULL cells (pdf[y].where(pdf[y].notna(), predicted), model.py:1128,1133)
+__global__ __launch_bounds__(256) void k_fill_cells(int32_t* __restrict__ col, long long n, const int32_t* __restrict__ label,
+                                                    const int32_t* __restrict__ class_code, int n_class_codes) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (col[i] < 0) { int l = label[i]; if (l >= 0 && l < n_class_codes) col[i] = class_code[l]; }
+}
+
+}  // namespace rg

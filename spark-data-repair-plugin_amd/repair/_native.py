@@ -1,0 +1,247 @@
+"""ctypes binding of librepairgbm.so (include/rgbm.h) -- the only door to the HIP engine.
+
+There is deliberately no fallback: if the shared library is missing or no HIP device is usable
+the calls raise ``RepairGbmError`` (the caller in train.py turns a failed build into
+``PoorModel(None)`` exactly like the reference does, python/repair/train.py:227-229).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "lib", "librepairgbm.so")
+
+
+class RepairGbmError(RuntimeError):
+    pass
+
+
+class RgbmParams(C.Structure):
+    _fields_ = [
+        ("objective", C.c_int32), ("num_class", C.c_int32),
+        ("n_estimators", C.c_int32), ("num_leaves", C.c_int32), ("max_depth", C.c_int32), ("max_bin", C.c_int32),
+        ("min_data_in_leaf", C.c_int32), ("min_data_in_bin", C.c_int32), ("bagging_freq", C.c_int32), ("seed", C.c_int32),
+        ("device_id", C.c_int32), ("reserved", C.c_int32),
+        ("learning_rate", C.c_double), ("lambda_l1", C.c_double), ("lambda_l2", C.c_double), ("min_gain_to_split", C.c_double),
+        ("min_sum_hessian_in_leaf", C.c_double), ("bagging_fraction", C.c_double), ("feature_fraction", C.c_double),
+    ]
+
+
+class RgbmTrainStats(C.Structure):
+    _fields_ = [
+        ("hist_ms", C.c_double), ("total_ms", C.c_double), ("hist_launches", C.c_int64), ("hist_rows", C.c_int64),
+        ("hist_bytes", C.c_int64), ("root_rows", C.c_int64), ("root_ms", C.c_double), ("trees", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+PARAM_DEFAULTS = dict(objective=1, num_class=2, n_estimators=300, num_leaves=31, max_depth=7, max_bin=255,
+                      min_data_in_leaf=20, min_data_in_bin=3, bagging_freq=0, seed=42, device_id=0, reserved=0,
+                      learning_rate=0.01, lambda_l1=0.0, lambda_l2=0.0, min_gain_to_split=0.0,
+                      min_sum_hessian_in_leaf=1e-3, bagging_fraction=1.0, feature_fraction=1.0)
+
+
+def make_params(**kw):
+    d = dict(PARAM_DEFAULTS)
+    for k, v in kw.items():
+        if k not in d:
+            raise TypeError("unknown parameter %r" % k)
+        d[k] = v
+    return RgbmParams(**d)
+
+
+_lib = None
+
+
+def lib():
+    """Load librepairgbm.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        path = os.path.abspath(LIB_PATH)
+        if not os.path.exists(path):
+            raise RepairGbmError("librepairgbm.so is not built (%s); run `python __graft_entry__.py` or `make -C "
+                                 "spark-data-repair-plugin_amd/csrc`" % path)
+        l = C.CDLL(path)
+        l.rgbm_last_error.restype = C.c_char_p
+        for name in ("rgbm_device_count", "rgbm_version", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
+                     "rgbm_table_create", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
+                     "rgbm_model_save", "rgbm_model_load", "rgbm_model_info", "rgbm_model_importance"):
+            getattr(l, name).restype = C.c_int
+        l.rgbm_table_free.restype = None
+        l.rgbm_model_free.restype = None
+        _lib = l
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "rgbm_device_count", "rgbm_last_error", "rgbm_version", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
+    "rgbm_table_create", "rgbm_table_free", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
+    "rgbm_model_save", "rgbm_model_load", "rgbm_model_free", "rgbm_model_info", "rgbm_model_importance",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RepairGbmError("%s failed (%d): %s" % (what, rc, lib().rgbm_last_error().decode("utf-8", "replace")))
+
+
+def device_count():
+    return int(lib().rgbm_device_count())
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, np.int32)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, np.float64)
+
+
+class Model:
+    """Owning handle of an ``rgbm_model`` (host-resident trees; device mirrors are lazy)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None:
+            _lib.rgbm_model_free(h)
+
+    def info(self):
+        a = np.zeros(5, np.int32)
+        _check(lib().rgbm_model_info(self.h, _p(a, C.c_int32)), "rgbm_model_info")
+        return dict(objective=int(a[0]), num_class=int(a[1]), K=int(a[2]), n_iter=int(a[3]), F=int(a[4]))
+
+    def save(self):
+        n = C.c_size_t(0)
+        _check(lib().rgbm_model_save(self.h, None, C.byref(n)), "rgbm_model_save")
+        buf = np.zeros(max(n.value, 1), np.uint8)
+        _check(lib().rgbm_model_save(self.h, buf.ctypes.data_as(C.c_void_p), C.byref(n)), "rgbm_model_save")
+        return buf[:n.value].tobytes()
+
+    @staticmethod
+    def load(b):
+        h = C.c_void_p()
+        arr = np.frombuffer(b, np.uint8)
+        _check(lib().rgbm_model_load(arr.ctypes.data_as(C.c_void_p), C.c_size_t(len(b)), C.byref(h)), "rgbm_model_load")
+        return Model(h)
+
+    def importance(self, kind="gain"):
+        out = np.zeros(self.info()["F"], np.float64)
+        _check(lib().rgbm_model_importance(self.h, C.c_int32(0 if kind == "split" else 1), _p(out, C.c_double)), "rgbm_model_importance")
+        return out
+
+    def predict(self, X, device_id=0):
+        """X: [F][n] int32 codes (column-major). Returns [n][ncol] float64 (regression: [n][1])."""
+        X = _i32(X)
+        F, n = X.shape
+        inf = self.info()
+        ncol = 1 if inf["objective"] == 2 else inf["num_class"]
+        out = np.zeros((n, ncol), np.float64)
+        _check(lib().rgbm_predict(self.h, _p(X, C.c_int32), C.c_int64(n), C.c_int32(F), C.c_int32(device_id), _p(out, C.c_double)), "rgbm_predict")
+        return out
+
+
+def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample_weight=None, want_stats=False, **params):
+    """Fit one model from host arrays. X: [F][N] int32 column-major codes."""
+    X = _i32(X)
+    F, N = X.shape
+    n_codes, y_code = _i32(n_codes), _i32(y_code)
+    yv, cw, sw = _f64(y_value), _f64(class_weight), _f64(sample_weight)
+    p = make_params(**params)
+    h = C.c_void_p()
+    st = RgbmTrainStats()
+    _check(lib().rgbm_train(_p(X, C.c_int32), C.c_int64(N), C.c_int32(F), _p(n_codes, C.c_int32), _p(y_code, C.c_int32),
+                            C.c_int32(n_y_codes), _p(yv, C.c_double), _p(cw, C.c_double), _p(sw, C.c_double),
+                            C.byref(p), C.byref(h), C.byref(st) if want_stats else None), "rgbm_train")
+    m = Model(h)
+    return (m, st.as_dict()) if want_stats else m
+
+
+def _chain_args(models, feat_cols, class_codes):
+    T = len(models)
+    arr = (C.c_void_p * max(T, 1))(*[m.h for m in models])
+    fo = np.zeros(T + 1, np.int32)
+    co = np.zeros(T + 1, np.int32)
+    for t in range(T):
+        fo[t + 1] = fo[t] + len(feat_cols[t])
+        if class_codes is not None:
+            co[t + 1] = co[t] + len(class_codes[t])
+    fc = _i32(np.concatenate([np.asarray(f, np.int32) for f in feat_cols])) if T else np.zeros(1, np.int32)
+    cc = None
+    if class_codes is not None:
+        cc = _i32(np.concatenate([np.asarray(c, np.int32) for c in class_codes] + [np.zeros(1, np.int32)]))
+    return arr, fc, fo, cc, co
+
+
+def repair_chain(models, target_col, feat_cols, class_codes, table, device_id=0):
+    """Host-array chained repair. table: [C][n] int32, modified in place."""
+    T = len(models)
+    Cc, n = table.shape
+    assert table.dtype == np.int32 and table.flags.c_contiguous
+    arr, fc, fo, cc, co = _chain_args(models, feat_cols, class_codes)
+    tc = _i32(target_col)
+    lab = np.zeros((T, n), np.int32)
+    prob = np.zeros((T, n), np.float64)
+    _check(lib().rgbm_repair_chain(arr, C.c_int32(T), _p(tc, C.c_int32), _p(fc, C.c_int32), _p(fo, C.c_int32), _p(cc, C.c_int32),
+                                   _p(co, C.c_int32), _p(table, C.c_int32), C.c_int64(n), C.c_int32(Cc), C.c_int32(device_id),
+                                   _p(lab, C.c_int32), _p(prob, C.c_double)), "rgbm_repair_chain")
+    return lab, prob
+
+
+class Table:
+    """An int32 code table resident in HBM (``rgbm_table``)."""
+
+    def __init__(self, codes, n_codes, device_id=0):
+        codes = _i32(codes)
+        self.c, self.n = codes.shape
+        self.n_codes = _i32(n_codes)
+        self.device_id = device_id
+        h = C.c_void_p()
+        _check(lib().rgbm_table_create(_p(codes, C.c_int32), C.c_int64(self.n), C.c_int32(self.c), _p(self.n_codes, C.c_int32),
+                                       C.c_int32(device_id), C.byref(h)), "rgbm_table_create")
+        self.h = h
+
+    def close(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None:
+            _lib.rgbm_table_free(h)
+
+    __del__ = close
+
+    def train(self, target_col, feat_cols, y_value=None, class_weight=None, want_stats=False, **params):
+        fc = _i32(feat_cols)
+        yv, cw = _f64(y_value), _f64(class_weight)
+        params.setdefault("device_id", self.device_id)
+        p = make_params(**params)
+        h = C.c_void_p()
+        st = RgbmTrainStats()
+        _check(lib().rgbm_table_train(self.h, C.c_int32(target_col), _p(fc, C.c_int32), C.c_int32(len(fc)), _p(yv, C.c_double),
+                                      _p(cw, C.c_double), C.byref(p), C.byref(h), C.byref(st) if want_stats else None), "rgbm_table_train")
+        m = Model(h)
+        return (m, st.as_dict()) if want_stats else m
+
+    def repair_chain(self, models, target_col, feat_cols, row_begin=0, n_rows=None, want_prob=True):
+        T = len(models)
+        n_rows = self.n - row_begin if n_rows is None else n_rows
+        arr, fc, fo, _, _ = _chain_args(models, feat_cols, None)
+        tc = _i32(target_col)
+        lab = np.zeros((T, n_rows), np.int32)
+        prob = np.zeros((T, n_rows), np.float64) if want_prob else None
+        _check(lib().rgbm_table_repair_chain(self.h, arr, C.c_int32(T), _p(tc, C.c_int32), _p(fc, C.c_int32), _p(fo, C.c_int32),
+                                             C.c_int64(row_begin), C.c_int64(n_rows), _p(lab, C.c_int32), _p(prob, C.c_double)),
+               "rgbm_table_repair_chain")
+        return lab, prob
+
+    def read_column(self, col):
+        out = np.zeros(self.n, np.int32)
+        _check(lib().rgbm_table_read_column(self.h, C.c_int32(col), _p(out, C.c_int32)), "rgbm_table_read_column")
+        return out
