@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- repaired cells/sec of the repair-model hot path on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[2] -- synthetic 10M rows x 16 categorical columns,
+1 % injected NULLs (seed 42), every column a target attribute (what NullErrorDetector yields),
+the reference's fixed LightGBM parameters (train.py:102-115) + LightGBM defaults for the searched
+ones, training on ALL rows (model.max_training_row_num = N).  It is the largest single-GPU config;
+configs[0]/[1]/[4] are parity-test cases, configs[3] is the 8-GPU shape.
+
+A "step" is one boosting iteration of ALL target models (n_estimators = --steps; the default 300 is
+the reference's model.lgb.n_estimators, so the default run is the complete job).  The timed region
+covers training of every target model + the chained repair of every dirty row + the result
+exchange, with the encoded tables already resident in HBM.  With --gpus N the same job is sharded
+by target attribute (LPT) over N ranks ("scaling": "strong").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "spark-data-repair-plugin_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from tests.synth import make_table  # noqa: E402
+
+BASE_PARAMS = dict(num_leaves=31, max_depth=7, max_bin=255, min_data_in_leaf=20, min_data_in_bin=3,
+                   bagging_freq=0, seed=42, learning_rate=0.01, lambda_l1=0.0, lambda_l2=0.0,
+                   min_gain_to_split=0.0, min_sum_hessian_in_leaf=1e-3, bagging_fraction=1.0, feature_fraction=1.0)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(rows, cols, steps_full, budget_s=20.0):
+    """Oracle (kind "port", 1 thread) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from repair.engine import balanced_class_weight
+    n = min(rows, 60_000)
+    iters = 10
+    dirty, clean, cards = make_table(n, cols, seed=42)
+    t_train = t_infer = 0.0
+    models, feats_l, done = [], [], []
+    t_begin = time.perf_counter()
+    for t in range(cols):
+        feats = [c for c in range(cols) if c != t]
+        r = dirty[t] >= 0
+        K = int(cards[t])
+        cw = balanced_class_weight(np.bincount(dirty[t][r], minlength=K))
+        t0 = time.perf_counter()
+        m = O.train(np.ascontiguousarray(dirty[feats][:, r]), cards[feats], dirty[t][r], K, class_weight=cw,
+                    objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=iters,
+                    **{k: v for k, v in BASE_PARAMS.items()})
+        t_train += time.perf_counter() - t0
+        models.append(m); feats_l.append(feats); done.append(t)
+        if time.perf_counter() - t_begin > budget_s:
+            break
+    mask = (dirty[done] < 0).any(axis=0) if len(done) else np.zeros(n, bool)
+    dr = np.ascontiguousarray(dirty[:, mask])
+    cells = int((dr[done] < 0).sum())
+    t0 = time.perf_counter()
+    O.repair_chain(models, done, feats_l, [list(range(int(cards[t]))) for t in done], dr)
+    t_infer = time.perf_counter() - t0
+    scale = steps_full / float(iters)
+    value = cells / max((t_train + t_infer) * scale, 1e-9)
+    return dict(value=value, unit="repaired cells/sec", cores=1, kind="port",
+                sample="%d-row subsample x %d cols, targets %s of %d, %d of %d boosting iterations timed "
+                       "(train %.2fs + repair %.2fs), time scaled x%.1f" % (n, cols, done, cols, iters, steps_full, t_train, t_infer, scale))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300, help="boosting iterations per target model (reference default 300)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up boosting iterations")
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--cols", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from repair import dist as rdist
+    from repair.engine import HipEngine, run_job, model_params, balanced_class_weight
+
+    # ---- inputs (outside the timed region: detector + encoder outputs, resident in HBM)
+    dirty, clean, cards = make_table(a.rows, a.cols, seed=42)
+    targets = list(range(a.cols))
+    label_counts = {t: np.bincount(dirty[t][dirty[t] >= 0], minlength=int(cards[t])) for t in targets}
+    dirty_mask = (dirty < 0).any(axis=0)
+    dirty_rows = np.ascontiguousarray(dirty[:, dirty_mask])
+    n_cells = int((dirty_rows < 0).sum())
+    eng = HipEngine(device_id=local_rank)
+    train_tab = eng.upload(dirty, cards)
+    dirty_tab = eng.upload(dirty_rows, cards)
+    truth = clean[:, dirty_mask]
+    null_cells = dirty_rows < 0
+    del dirty
+
+    # ---- warm-up: W boosting iterations of one model (kernel load, allocator, clocks)
+    if a.warmup > 0:
+        t = targets[min(4, len(targets) - 1)]
+        feats = [c for c in targets if c != t]
+        p = dict(BASE_PARAMS, n_estimators=a.warmup)
+        m = eng.train(train_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
+        warm = eng.upload(dirty_rows[:, :min(4096, dirty_rows.shape[1])], cards)
+        eng.repair_chain(warm, [m], [t], [feats], 0, warm.n)
+        del warm, m
+
+    # ---- timed region
+    params = dict(BASE_PARAMS, n_estimators=a.steps)
+    rdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run_job(eng, train_tab, dirty_tab, cards, targets, label_counts, params, want_stats=True)
+    torch.cuda.synchronize(); rdist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = rdist.max_over_ranks(elapsed)
+
+    # ---- roofline inputs: hist_build algorithmic bytes / its summed launch time (HIP events on its stream)
+    hist_ms = sum(s["hist_ms"] for s in res["stats"]); hist_bytes = sum(s["hist_bytes"] for s in res["stats"])
+    hist_launches = sum(s["hist_launches"] for s in res["stats"])
+    root_ms = sum(s["root_ms"] for s in res["stats"]); root_bytes = sum(s["root_rows"] for s in res["stats"]) * (a.cols - 1 + 8)
+    hist_ms_all = rdist.sum_over_ranks(hist_ms); hist_bytes_all = rdist.sum_over_ranks(hist_bytes)
+    launches_all = rdist.sum_over_ranks(hist_launches)
+    train_s = rdist.max_over_ranks(res["times"]["train"]); infer_s = rdist.max_over_ranks(res["times"]["infer"])
+
+    if rank == 0:
+        labels = res["labels"]
+        fixed = 0
+        for i, t in enumerate(targets):
+            nz = null_cells[t]
+            fixed += int((labels[i][nz] == truth[t][nz]).sum())
+        achieved = hist_bytes_all / max(hist_ms_all, 1e-9) * 1e-6
+        out = {
+            "metric": "repaired cells/sec", "value": n_cells / elapsed, "unit": "cells/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3 / a.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64 fixed-point histograms / f64 scores",
+            "data": "synthetic",
+            "config": {"workload": "synthetic %dM rows x %d categorical cols, 1%% NULLs, seed 42 (BASELINE configs[2]); %d target "
+                                   "attributes, n_estimators=%d, train on all rows" % (a.rows // 1_000_000, a.cols, len(targets), a.steps),
+                       "rows": a.rows, "cols": a.cols, "targets": len(targets), "dirty_rows": int(dirty_rows.shape[1]),
+                       "error_cells": n_cells, "parallelism": "target-sharded x%d" % world},
+            "model_train_sec": train_s, "repair_sec": infer_s, "elapsed_sec": elapsed,
+            "repair_accuracy_vs_clean": fixed / max(n_cells, 1),
+            "roofline": {"bound": "hbm", "kernel": "rg::k_hist", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": int(launches_all), "avg_launch_us": hist_ms_all * 1e3 / max(launches_all, 1),
+                         "alg_bytes_per_launch": hist_bytes_all / max(launches_all, 1),
+                         "root_scan_GBps_rank0": root_bytes / max(root_ms, 1e-9) * 1e-6},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.rows, a.cols, a.steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

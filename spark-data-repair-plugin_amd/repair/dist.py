@@ -1,0 +1,144 @@
+"""Multi-GPU sharding of the repair hot path: one process per GPU, torch.distributed (backend
+"nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+What the reference does with Spark (python/repair/model.py):
+  * model-parallel training, one task per target attribute (`_build_repair_stat_models_in_parallel`,
+    model.py:817-926, models come back pickled, :910,:921)            -> ``assign_targets`` (LPT)
+  * `sparkContext.broadcast(models)` (model.py:1069)                  -> ``exchange_blobs`` (all-gather
+    of the serialised models: a few MB, latency-bound, no all-reduce anywhere on this path)
+  * data-parallel inference over random row groups (model.py:1054-1058,1142)
+                                                                      -> ``shard_rows`` + ``gather_rows``
+The chain semantics of `_repair` (a later model reads cells repaired by an earlier one) stay intact
+because every rank holds ALL models and runs the whole chain on its own rows.
+"""
+import numpy as np
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except Exception:  # pragma: no cover - torch always importable here
+        pass
+    return None
+
+
+def world():
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+
+
+def assign_targets(costs, world_size):
+    """Longest-processing-time-first assignment of target attributes to ranks.
+
+    costs: list of (target, cost) -- cost ~ trees per iteration * training rows.
+    Returns a list (per rank) of target lists; deterministic (ties by original order)."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i][1]), i))
+    loads = [0.0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda j: (loads[j], j))
+        out[r].append(costs[i][0])
+        loads[r] += float(costs[i][1])
+    return out
+
+
+def shard_rows(n_rows, world_size, rank):
+    """Contiguous, balanced row shard [begin, begin+count) of rank."""
+    base, rem = divmod(int(n_rows), int(world_size))
+    begin = rank * base + min(rank, rem)
+    return begin, base + (1 if rank < rem else 0)
+
+
+def _tensor_device():
+    import torch
+    d = _dist()
+    if d is not None and d.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def exchange_blobs(local):
+    """All-gather a dict {key(int) -> bytes} so that every rank ends up with the union."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return dict(local)
+    import torch
+    dev = _tensor_device()
+    ws = d.get_world_size()
+    keys = sorted(local)
+    # header: number of blobs, then (key, length) pairs
+    head = np.array([len(keys)] + [v for k in keys for v in (k, len(local[k]))], np.int64)
+    n_head = torch.tensor([head.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    d.all_gather(sizes, n_head)
+    payload = np.concatenate([head.view(np.uint8)] + [np.frombuffer(local[k], np.uint8) for k in keys]) if keys else head.view(np.uint8)
+    n_pay = torch.tensor([payload.size], dtype=torch.int64, device=dev)
+    pays = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    d.all_gather(pays, n_pay)
+    mx = int(max(int(p.item()) for p in pays))
+    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    buf[:payload.size] = torch.from_numpy(payload.copy()).to(dev)
+    bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(ws)]
+    d.all_gather(bufs, buf)
+    out = {}
+    for r in range(ws):
+        raw = bufs[r].cpu().numpy()
+        nh = int(sizes[r].item())
+        h = raw[:nh * 8].view(np.int64)
+        off = nh * 8
+        for i in range(int(h[0])):
+            k, ln = int(h[1 + 2 * i]), int(h[2 + 2 * i])
+            out[k] = raw[off:off + ln].tobytes()
+            off += ln
+    return out
+
+
+def gather_rows(local, n_rows_total):
+    """All-gather row shards: local [T][rows_of_rank] -> [T][n_rows_total] (shard order = rank order)."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return np.asarray(local)
+    import torch
+    dev = _tensor_device()
+    ws, rank = d.get_world_size(), d.get_rank()
+    local = np.ascontiguousarray(local)
+    T = local.shape[0]
+    mx = max(shard_rows(n_rows_total, ws, r)[1] for r in range(ws))
+    pad = np.zeros((T, mx), local.dtype)
+    pad[:, :local.shape[1]] = local
+    t = torch.from_numpy(pad).to(dev)
+    outs = [torch.zeros_like(t) for _ in range(ws)]
+    d.all_gather(outs, t)
+    res = np.zeros((T, n_rows_total), local.dtype)
+    for r in range(ws):
+        b, c = shard_rows(n_rows_total, ws, r)
+        res[:, b:b + c] = outs[r].cpu().numpy()[:, :c]
+    return res
+
+
+def barrier():
+    d = _dist()
+    if d is not None:
+        d.barrier()
+
+
+def max_over_ranks(x):
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return float(x)
+    import torch
+    t = torch.tensor([float(x)], dtype=torch.float64, device=_tensor_device())
+    d.all_reduce(t, op=d.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(x):
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return float(x)
+    import torch
+    t = torch.tensor([float(x)], dtype=torch.float64, device=_tensor_device())
+    d.all_reduce(t, op=d.ReduceOp.SUM)
+    return float(t.item())

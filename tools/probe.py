@@ -1,0 +1,30 @@
+"""Perf probe: train a few boosting iterations on a synthetic table through the resident-table path."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spark-data-repair-plugin_amd"))
+from tests.synth import make_table, balanced_weights
+from repair import _native as N
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=10_000_000)
+ap.add_argument("--cols", type=int, default=16)
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--targets", type=str, default="0,4,10")
+ap.add_argument("--stats", type=int, default=1)
+a = ap.parse_args()
+t0 = time.time()
+dirty, clean, cards = make_table(a.rows, a.cols, seed=42)
+print("gen %.1fs" % (time.time() - t0), flush=True)
+t0 = time.time(); tab = N.Table(dirty, cards); print("upload %.2fs" % (time.time() - t0), flush=True)
+for t in [int(x) for x in a.targets.split(",")]:
+    feats = [c for c in range(a.cols) if c != t]
+    K = int(cards[t]); cw = balanced_weights(dirty[t], K)
+    for rep in range(2):
+        t0 = time.time()
+        m, st = tab.train(t, feats, class_weight=cw, want_stats=bool(a.stats), objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=a.iters)
+        dt = time.time() - t0
+        ktrees = 1 if K == 2 else K
+        print("target %d K=%d: %.3fs wall, %.1f ms/iter, %.2f ms/tree | hist %.1f ms (%d launches) root %.1f ms | rows %.3g bytes %.3g -> hist %.1f GB/s, root %.1f GB/s" % (
+            t, K, dt, dt * 1e3 / a.iters, dt * 1e3 / a.iters / ktrees, st["hist_ms"], st["hist_launches"], st["root_ms"], st["hist_rows"], st["hist_bytes"],
+            st["hist_bytes"] / max(st["hist_ms"], 1e-9) * 1e-6, st["root_rows"] * (len(feats) + 8) / max(st["root_ms"], 1e-9) * 1e-6), flush=True)
