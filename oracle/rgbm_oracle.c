@@ -545,13 +545,20 @@ ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_c
         for (int64_t i = 0; i < N; ++i) {
             double v = class_weight ? class_weight[y_code[i]] : 1.0;
             if (sample_weight) v = v * sample_weight[i];
-            w[i] = v;
+            w[i] = (double)(float)v;   /* LightGBM Metadata keeps weights as float32 (label_t) */
         }
     }
     double w_max = 0.0;
     if (w) { for (int64_t i = 0; i < N; ++i) if (w[i] > w_max) w_max = w[i]; } else w_max = 1.0;
     if (!(w_max > 0.0)) w_max = 1.0;
 
+    /* LightGBM keeps labels as float32 (label_t): regression targets are rounded once here */
+    double* yv32 = NULL;
+    if (obj == 2) {
+        yv32 = (double*)malloc(sizeof(double) * (n_y_codes > 0 ? n_y_codes : 1));
+        for (int c = 0; c < n_y_codes; ++c) yv32[c] = (double)(float)y_value[c];
+        y_value = yv32;
+    }
     /* BoostFromScore.  Label totals are defined order-free: without per-row sample weights the
      * weight of label c is cnt[c] * class_weight[c]; sums run over labels in ascending order.
      * (With sample weights they are row-order sums -- host-array path only.) */
@@ -565,7 +572,7 @@ ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_c
         double* tot = (double*)calloc(nl, sizeof(double));
         for (int64_t i = 0; i < N; ++i) ++cnt[y_code[i]];
         if (sample_weight) { for (int64_t i = 0; i < N; ++i) tot[y_code[i]] += w[i]; }
-        else { for (int c = 0; c < nl; ++c) tot[c] = (double)cnt[c] * (class_weight ? class_weight[c] : 1.0); }
+        else { for (int c = 0; c < nl; ++c) tot[c] = (double)cnt[c] * (class_weight ? (double)(float)class_weight[c] : 1.0); }
         double sumw = 0.0;
         for (int c = 0; c < nl; ++c) sumw += tot[c];
         if (obj == 2) {
@@ -734,7 +741,7 @@ ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_c
     *out = m;
     free(t.bins); free(t.hoff); free(t.trivial); free(w); free(init); free(score); free(gq); free(hq);
     free(idx); free(bag); free(leaf_begin); free(leaf_cnt); free(used); free(rec); free(bcols); free(in_bag);
-    free(bag_rands); free(valid); free(samp);
+    free(bag_rands); free(valid); free(samp); free(yv32);
     return 0;
 }
 

@@ -246,6 +246,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (obj == 1 && n_y > p.num_class) throw std::out_of_range("target has more label codes than num_class");
     if (obj == 0 && n_y > 2) throw std::out_of_range("binary objective with more than 2 label codes");
     if (obj == 2 && !y_value) throw std::out_of_range("regression needs the y_value dictionary");
+    std::vector<double> yv32;   // LightGBM keeps labels as float32: round the regression dictionary once
+    if (obj == 2) { yv32.resize(std::max(n_y, 1)); for (int c = 0; c < n_y; ++c) yv32[c] = (double)(float)y_value[c]; y_value = yv32.data(); }
     StreamGuard sg_; hipStream_t s = sg_.s;
     hipEvent_t ev_begin, ev_end; HIPCHK(hipEventCreate(&ev_begin)); HIPCHK(hipEventCreate(&ev_end));
     HIPCHK(hipEventRecord(ev_begin, s));
@@ -315,8 +317,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (hls && hls->valid) { tot = hls->tot; tot.resize(nl, 0.0); w_max = hls->w_max; }
     else {
         for (int c = 0; c < n_y; ++c) {
-            tot[c] = (double)ycnt[c] * (class_weight ? class_weight[c] : 1.0);
-            if (ycnt[c]) w_max = std::max(w_max, class_weight ? class_weight[c] : 1.0);
+            const double cw32 = class_weight ? (double)(float)class_weight[c] : 1.0;   // float32 weights (LightGBM label_t)
+            tot[c] = (double)ycnt[c] * cw32;
+            if (ycnt[c]) w_max = std::max(w_max, cw32);
         }
     }
     if (!(w_max > 0.0)) w_max = 1.0;
@@ -672,9 +675,9 @@ RGBM_EXPORT int rgbm_train(const int32_t* X, int64_t n, int32_t f, const int32_t
         if (sample_weight) {   // row-order sums (numerics spec: only defined on the host-array path)
             hls.valid = true; hls.tot.assign(n_y_codes, 0.0);
             for (int64_t i = 0; i < n; ++i) {
-                double w = (class_weight ? class_weight[y_code[i]] : 1.0); w = w * sample_weight[i];
+                double w = (class_weight ? class_weight[y_code[i]] : 1.0); w = w * sample_weight[i]; w = (double)(float)w;
                 hls.tot[y_code[i]] += w; if (w > hls.w_max) hls.w_max = w;
-                if (y_value) hls.suml += y_value[y_code[i]] * w;
+                if (y_value) hls.suml += (double)(float)y_value[y_code[i]] * w;
             }
         }
         *out = train_core(tab, f, fc.data(), f, y_value, class_weight, sample_weight, &hls, *p, stats);

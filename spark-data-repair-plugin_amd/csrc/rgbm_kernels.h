@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
         if (y < 0) continue;   // not a training row: its gh stays 0 for ever
         double wi = class_w ? class_w[y] : 1.0;
         if (sample_w) wi = wi * sample_w[i];
+        wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
         if (OBJ == 0) {
             double label = (y > 0) ? 1.0 : -1.0;
             double response = -label / (1.0 + rg_exp(label * score[i]));

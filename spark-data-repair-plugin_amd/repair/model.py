@@ -1,0 +1,627 @@
+"""RepairModel -- the reference's fluent repair API (python/repair/model.py) on a Spark-free host,
+with its hot path (`_build_repair_models` 955-1052, `_build_repair_stat_models_in_series` 768-815,
+`_repair` 1062-1143) running on the MI355X engine through `repair.gbm` / librepairgbm.so.
+
+Kept verbatim from the reference: setter names and validation messages, `option()` keys, `run()`
+flags and their exclusivity rules, the output schemas
+  (row_id, attribute, current_value, repaired[, prob | pmf | score]),
+the estimator protocol of the per-attribute models (PoorModel / FunctionalDepModel / stat model),
+"train on all rows with error cells NULLed, drop rows whose target is NULL", the fill-only-NULL
+chain over target attributes, integral rounding, and "a failed build becomes PoorModel(None)".
+Inputs are pandas DataFrames (or names registered with `repair.session.register_table`).
+"""
+import copy
+import heapq
+import json
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import pandas as pd
+
+from repair import session
+from repair.costs import UpdateCostFunction
+from repair.encode import is_integral_column, is_numeric_column
+from repair.errors import ConstraintErrorDetector, ErrorDetector, ErrorModel, RegExErrorDetector, parse_constraint, load_constraints
+from repair.train import build_model, compute_class_nrow_stdv, rebalance_training_data, train_option_keys
+from repair.utils import argtype_check, elapsed_time, get_option_value, job_group, setup_logger, to_list_str
+
+_logger = setup_logger()
+
+DataFrame = pd.DataFrame
+
+
+class PoorModel():
+    """Model to return the same value regardless of an input value (reference model.py:44-61)."""
+
+    def __init__(self, v: Any) -> None:
+        self.v = v
+
+    @property
+    def classes_(self) -> Any:
+        return np.array([self.v])
+
+    def predict(self, X: pd.DataFrame) -> Any:
+        return [self.v] * len(X)
+
+    def predict_proba(self, X: pd.DataFrame) -> Any:
+        return [np.array([1.0])] * len(X)
+
+
+class FunctionalDepModel():
+    """sklearn-like model that follows a functional dependency x -> y (reference model.py:64-100)."""
+
+    def __init__(self, x: str, fd_map: Dict[str, str]) -> None:
+        self.fd_map = fd_map
+        self.classes = sorted(set(fd_map.values()), key=str)   # deterministic (the reference's set order is hash-dependent)
+        self.x = x
+        self.fd_keypos_map = {c: i for i, c in enumerate(self.classes)}
+
+    @property
+    def classes_(self) -> Any:
+        return np.array(self.classes)
+
+    def predict(self, X: pd.DataFrame) -> Any:
+        return [self.fd_map[x] if x in self.fd_map else None for x in X[self.x]]
+
+    def predict_proba(self, X: pd.DataFrame) -> Any:
+        pmf = []
+        for x in X[self.x]:
+            if x in self.fd_map:
+                probs = np.zeros(len(self.classes))
+                probs[self.fd_keypos_map[self.fd_map[x]]] = 1.0
+                pmf.append(probs)
+            else:
+                _logger.warning('Unknown "%s" domain value found: %s' % (self.x, x))
+                pmf.append(None)
+        return pmf
+
+
+class RepairModel():
+    """Interface to detect error cells in given input data and build statistical models to repair them."""
+
+    from collections import namedtuple
+    _option = namedtuple("_option", "key default_value type_class validator err_msg")
+
+    _opt_max_training_row_num = _option("model.max_training_row_num", 10000, int, lambda v: v >= 10, "`{}` should be greater than and equal to 10")
+    _opt_max_training_column_num = _option("model.max_training_column_num", 65536, int, lambda v: v >= 2, "`{}` should be greater than 1")
+    _opt_small_domain_threshold = _option("model.small_domain_threshold", 12, int, lambda v: v >= 3, "`{}` should be greater than 2")
+    _opt_repair_by_regex_disabled = _option("model.rule.repair_by_regex.disabled", True, bool, None, None)
+    _opt_repair_by_nearest_values_disabled = _option("model.rule.repair_by_nearest_values.disabled", True, bool, None, None)
+    _opt_merge_threshold = _option("model.rule.merge_threshold", 2.0, float, None, None)
+    _opt_repair_by_functional_deps_disabled = _option("model.rule.repair_by_functional_deps.disabled", False, bool, None, None)
+    _opt_max_domain_size = _option("model.rule.max_domain_size", 1000, int, lambda v: v > 10, "`{}` should be greater than 10")
+    _opt_cost_weight = _option("repair.pmf.cost_weight", 0.1, float, lambda v: v > 0.0, "`{}` should be positive")
+    _opt_prob_threshold = _option("repair.pmf.prob_threshold", 0.0, float, None, None)
+    _opt_prob_top_k = _option("repair.pmf.prob_top_k", 32, int, lambda v: v >= 3, "`{}` should be greater than 2")
+    # new in this engine: which HIP device trains/predicts
+    _opt_gpu_device_id = _option("model.gpu.device_id", 0, int, lambda v: v >= 0, "`{}` should be non-negative")
+
+    option_keys = set([o.key for o in (
+        _opt_max_training_row_num, _opt_max_training_column_num, _opt_small_domain_threshold, _opt_repair_by_regex_disabled,
+        _opt_repair_by_nearest_values_disabled, _opt_merge_threshold, _opt_repair_by_functional_deps_disabled,
+        _opt_max_domain_size, _opt_cost_weight, _opt_prob_threshold, _opt_prob_top_k, _opt_gpu_device_id)] +
+        list(ErrorModel.option_keys) + list(train_option_keys))
+
+    def __init__(self) -> None:
+        self.db_name: str = ""
+        self.input: Optional[Union[str, DataFrame]] = None
+        self.row_id: Optional[str] = None
+        self.targets: List[str] = []
+        self.error_cells: Optional[Union[str, DataFrame]] = None
+        self.error_detectors: List[ErrorDetector] = []
+        self.discrete_thres: int = 80
+        self.parallel_stat_training_enabled: bool = False
+        self.training_data_rebalancing_enabled: bool = False
+        self.repair_by_rules: bool = False
+        self.repair_delta: Optional[int] = None
+        self.repair_validation_enabled: bool = False
+        self.cf: Optional[UpdateCostFunction] = None
+        self.opts: Dict[str, str] = {}
+
+    # ------------------------------------------------------------------ fluent setters
+    @argtype_check  # type: ignore
+    def setDbName(self, db_name: str) -> "RepairModel":
+        if isinstance(self.input, DataFrame):
+            raise ValueError("Can not specify a database name when input is `DataFrame`")
+        self.db_name = db_name
+        return self
+
+    @argtype_check  # type: ignore
+    def setTableName(self, table_name: str) -> "RepairModel":
+        if not table_name:
+            raise ValueError("`table_name` should have at least character")
+        self.input = table_name
+        return self
+
+    @argtype_check  # type: ignore
+    def setInput(self, input: Union[str, DataFrame]) -> "RepairModel":
+        if type(input) is str:
+            self.setTableName(input)
+        else:
+            self.db_name = ""
+            self.input = input
+        return self
+
+    @argtype_check  # type: ignore
+    def setRowId(self, row_id: str) -> "RepairModel":
+        if not row_id:
+            raise ValueError("`row_id` should have at least character")
+        self.row_id = row_id
+        return self
+
+    @argtype_check  # type: ignore
+    def setTargets(self, attrs: List[str]) -> "RepairModel":
+        if len(attrs) == 0:
+            raise ValueError("`attrs` should have at least one attribute")
+        self.targets = attrs
+        return self
+
+    @argtype_check  # type: ignore
+    def setErrorCells(self, error_cells: Union[str, DataFrame]) -> "RepairModel":
+        if type(error_cells) is str and not error_cells:
+            raise ValueError("`error_cells` should have at least character")
+        if self.row_id is None:
+            raise ValueError("`setRowId` should be called before specifying error cells")
+        df = session.resolve(error_cells)
+        if not all(c in df.columns for c in [self._row_id, "attribute"]):
+            raise ValueError("Error cells should have `%s` and `attribute` in columns" % self.row_id)
+        self.error_cells = error_cells
+        return self
+
+    @argtype_check  # type: ignore
+    def setErrorDetectors(self, detectors: List[ErrorDetector]) -> "RepairModel":
+        self.error_detectors = detectors
+        return self
+
+    @argtype_check  # type: ignore
+    def setDiscreteThreshold(self, thres: int) -> "RepairModel":
+        if int(thres) < 2:
+            raise ValueError("`thres` should be bigger than 1, got %s" % thres)
+        self.discrete_thres = thres
+        return self
+
+    @argtype_check  # type: ignore
+    def setParallelStatTrainingEnabled(self, enabled: bool) -> "RepairModel":
+        self.parallel_stat_training_enabled = enabled
+        return self
+
+    @argtype_check  # type: ignore
+    def setTrainingDataRebalancingEnabled(self, enabled: bool) -> "RepairModel":
+        self.training_data_rebalancing_enabled = enabled
+        return self
+
+    @argtype_check  # type: ignore
+    def setRepairByRules(self, enabled: bool) -> "RepairModel":
+        self.repair_by_rules = enabled
+        return self
+
+    @argtype_check  # type: ignore
+    def setRepairDelta(self, delta: int) -> "RepairModel":
+        if delta <= 0:
+            raise ValueError("Repair delta should be positive, got %s" % delta)
+        self.repair_delta = int(delta)
+        return self
+
+    @argtype_check  # type: ignore
+    def setUpdateCostFunction(self, cf: UpdateCostFunction) -> "RepairModel":
+        self.cf = cf
+        return self
+
+    @argtype_check  # type: ignore
+    def option(self, key: str, value: str) -> "RepairModel":
+        if key not in self.option_keys:
+            raise ValueError("Non-existent key specified: key=%s" % key)
+        self.opts[key] = value
+        return self
+
+    def _get_option_value(self, *args) -> Any:  # type: ignore
+        return get_option_value(self.opts, *args)
+
+    @property
+    def _row_id(self) -> str:
+        return str(self.row_id)
+
+    @property
+    def _repair_by_nearest_values_enabled(self) -> bool:
+        return not bool(self._get_option_value(*self._opt_repair_by_nearest_values_disabled)) and self.repair_by_rules and self.cf is not None
+
+    @property
+    def _repair_by_regex_enabled(self) -> bool:
+        return not bool(self._get_option_value(*self._opt_repair_by_regex_disabled)) and self.repair_by_rules
+
+    @property
+    def _repair_by_functional_deps_enabled(self) -> bool:
+        return not bool(self._get_option_value(*self._opt_repair_by_functional_deps_disabled)) and self.repair_by_rules
+
+    # ------------------------------------------------------------------ input checks
+    def _check_input_table(self) -> Tuple[DataFrame, List[str]]:
+        """RepairApi.checkInputTable (RepairApi.scala:34-67)."""
+        df = session.resolve(self.input)
+        rid = self._row_id
+        if rid not in df.columns:
+            raise ValueError("Column '%s' does not exist in the input table" % rid)
+        if len(df.columns) < 3:
+            raise ValueError("A least three columns (`%s` columns + two more ones) in the input table" % rid)
+        if df[rid].nunique(dropna=False) != len(df):
+            raise ValueError("Uniqueness does not hold in column '%s' of the input table (# of distinct '%s': %d, # of rows: %d)" % (
+                rid, rid, df[rid].nunique(dropna=False), len(df)))
+        continous = [c for c in df.columns if c != rid and is_numeric_column(df[c])]
+        _logger.info("input_table: (%d rows x %d columns)" % (len(df), len(df.columns) - 1))
+        return df.reset_index(drop=True), continous
+
+    def _detect_errors(self, input_df: DataFrame, continous_columns: List[str]) -> Any:
+        ec = None
+        if self.error_cells is not None:
+            ec = session.resolve(self.error_cells)[[self._row_id, "attribute"]]
+        em = ErrorModel(row_id=self._row_id, targets=self.targets, discrete_thres=self.discrete_thres,
+                        error_detectors=self.error_detectors, error_cells=ec, opts=self.opts)
+        return em.detect(input_df, continous_columns)
+
+    def _prepare_repair_base_cells(self, input_df: DataFrame, error_cells_df: DataFrame, target_columns: List[str]) -> DataFrame:
+        """RepairApi.convertErrorCellsToNull (RepairApi.scala:171-211)."""
+        base = input_df.copy()
+        pos = pd.Series(np.arange(len(base)), index=base[self._row_id].to_numpy())
+        for a, grp in error_cells_df.groupby("attribute"):
+            if a in target_columns:
+                rows = pos.reindex(grp[self._row_id].to_numpy()).dropna().to_numpy(np.int64)
+                col = base[a].astype(object) if not is_numeric_column(base[a]) else base[a].astype("float64") if not is_integral_column(base[a]) else base[a].astype("Int64")
+                col.iloc[rows] = None if not is_numeric_column(base[a]) else pd.NA if is_integral_column(base[a]) else np.nan
+                base[a] = col
+        return base
+
+    # ------------------------------------------------------------------ rule models
+    def _get_functional_deps(self, target_columns: List[str]) -> Optional[Dict[str, List[str]]]:
+        dets = [d for d in self.error_detectors if isinstance(d, ConstraintErrorDetector)]
+        if len(dets) != 1:
+            if len(dets) > 1:
+                _logger.warning("Multiple constraint classes not supported for detecting functional deps")
+            return None
+        ced = dets[0]
+        tg = [c for c in target_columns if c in ced.targets] if ced.targets else target_columns
+        deps: Dict[str, List[str]] = {}
+        for stmt in load_constraints(ced.constraint_path, ced.constraints):
+            try:
+                ps = parse_constraint(stmt)
+            except Exception:
+                continue
+            # X -> Y  ==  EQ(t1.X,t2.X) & IQ(t1.Y,t2.Y)
+            if len(ps) == 2 and ps[0].op == "EQ" and ps[1].op == "IQ" and ps[0].constant is None and ps[1].constant is None \
+                    and ps[0].left == ps[0].right and ps[1].left == ps[1].right and ps[1].left in tg:
+                deps.setdefault(ps[1].left, []).append(ps[0].left)
+        return deps or None
+
+    def _build_rule_model(self, train_df: DataFrame, x: str, y: str) -> Any:
+        sub = train_df[[x, y]].dropna()
+        g = sub.groupby(x)[y].agg(lambda s: s.iloc[0] if s.nunique() == 1 else None).dropna()
+        return FunctionalDepModel(x, {k: v for k, v in g.items()})
+
+    # ------------------------------------------------------------------ hot path: training
+    def _select_features(self, pairwise_attr_stats: Dict[str, Any], y: str, features: List[str]) -> List[str]:
+        max_cols = int(self._get_option_value(*self._opt_max_training_column_num))
+        if max_cols < len(features) and y in pairwise_attr_stats:
+            heap: List[Tuple[float, str]] = []
+            for f, corr in map(tuple, pairwise_attr_stats[y]):
+                if f in features:
+                    heapq.heappush(heap, (float(corr), f))
+            top: List[Tuple[float, str]] = []
+            for corr, f in [heapq.heappop(heap) for _ in range(len(heap))]:
+                if len(top) <= 1 or (corr >= 0.0 and len(top) < max_cols):
+                    top.append((corr, f))
+            features = [f for _, f in top]
+        return features
+
+    def _sample_training_data_from(self, df: DataFrame) -> DataFrame:
+        """model.py:755-766; the reference's Bernoulli sample is unseeded, this one is seeded (42)."""
+        max_rows = int(self._get_option_value(*self._opt_max_training_row_num))
+        if len(df) > max_rows:
+            _logger.info("To reduce training data, extracts %s%% samples from %d rows" % (100.0 * max_rows / len(df), len(df)))
+            return df.sample(n=max_rows, random_state=42)
+        return df
+
+    def _build_repair_stat_models_in_series(self, models: Dict[str, Any], train_df: DataFrame, target_columns: List[str],
+                                            continous_columns: List[str], num_class_map: Dict[str, int],
+                                            feature_map: Dict[str, List[str]]) -> Dict[str, Any]:
+        opts = dict(self.opts)
+        for y in [c for c in target_columns if c not in models]:
+            index = len(models) + 1
+            df = train_df[train_df[y].notna()]
+            if len(df) == 0:
+                _logger.info("Skipping %d/%d model... type=classfier y=%s num_class=%s" % (index, len(target_columns), y, num_class_map[y]))
+                models[y] = (PoorModel(None), feature_map[y], None)
+                continue
+            train_pdf = self._sample_training_data_from(df)
+            is_discrete = y not in continous_columns
+            X = train_pdf[feature_map[y]]
+            X, y_ = rebalance_training_data(X, train_pdf[y], y) if is_discrete and self.training_data_rebalancing_enabled else (X, train_pdf[y])
+            _logger.info("Building %d/%d model... type=%s y=%s features=%s #rows=%d%s" % (
+                index, len(target_columns), "classfier" if is_discrete else "regressor", y, to_list_str(feature_map[y]), len(train_pdf),
+                " #class=%d" % num_class_map[y] if num_class_map[y] > 0 else ""))
+            (model, score), elapsed = build_model(X, y_, is_discrete, num_class_map[y], n_jobs=-1, opts=opts)
+            if model is None:
+                model = PoorModel(None)
+            _logger.info("Finishes building '%s' model...  score=%s elapsed=%ss (class stdv=%s)" % (
+                y, score, elapsed, compute_class_nrow_stdv(y_, is_discrete)))
+            models[y] = (model, feature_map[y], None)
+        return models
+
+    def _resolve_prediction_order(self, models: Dict[str, Any], target_columns: List[str]) -> List[Any]:
+        ordered, pending = [], list(target_columns)
+        for y in target_columns:
+            if not isinstance(models[y][0], FunctionalDepModel):
+                ordered.append((y, models[y])); pending.remove(y)
+        while pending:
+            before = len(pending)
+            for y in list(pending):
+                if models[y][1][0] not in pending:
+                    ordered.append((y, models[y])); pending.remove(y)
+            assert len(pending) < before
+        return ordered
+
+    @job_group(name="repair model training")
+    def _build_repair_models(self, train_df: DataFrame, target_columns: List[str], continous_columns: List[str],
+                             domain_stats: Dict[str, int], pairwise_attr_stats: Dict[str, Any]) -> List[Any]:
+        train_df = train_df.drop(columns=[self._row_id])
+        functional_deps = self._get_functional_deps(target_columns) if self._repair_by_functional_deps_enabled else None
+        _logger.info("[Repair Model Training Phase] Building %d models to repair the cells in %s" % (len(target_columns), to_list_str(target_columns)))
+        models: Dict[str, Any] = {}
+        num_class_map: Dict[str, int] = {}
+        for y in target_columns:
+            input_columns = [c for c in train_df.columns if c != y]
+            is_discrete = y not in continous_columns
+            num_class_map[y] = int(train_df[y].nunique(dropna=True)) if is_discrete else 0
+            if is_discrete and num_class_map[y] <= 1:
+                v = train_df[y].dropna().iloc[0] if num_class_map[y] == 1 else None
+                models[y] = (PoorModel(v), input_columns, None)
+            if y not in models and functional_deps is not None and y in functional_deps:
+                max_dom = int(self._get_option_value(*self._opt_max_domain_size))
+                fx = [x for x in functional_deps[y] if x in domain_stats and int(domain_stats[x]) < max_dom]
+                if fx:
+                    models[y] = (self._build_rule_model(train_df, fx[0], y), [fx[0]], None)
+        if len(models) != len(target_columns):
+            feature_map = {y: self._select_features(pairwise_attr_stats, y, [c for c in train_df.columns if c != y])
+                           for y in target_columns if y not in models}
+            # one process drives one GPU: the reference's "parallel" mode (model.py:817-926) is a
+            # scheduling choice with identical maths, so both settings train here in series.
+            models = self._build_repair_stat_models_in_series(models, train_df, target_columns, continous_columns, num_class_map, feature_map)
+        assert len(models) == len(target_columns)
+        if any(isinstance(m, FunctionalDepModel) for m, _, _ in models.values()):
+            return self._resolve_prediction_order(models, target_columns)
+        return [(y, models[y]) for y in target_columns]
+
+    # ------------------------------------------------------------------ hot path: inference
+    @job_group(name="repairing")
+    def _repair(self, models: List[Any], continous_columns: List[str], dirty_rows_df: DataFrame, error_cells_df: DataFrame,
+                compute_repair_candidate_prob: bool, maximal_likelihood_repair: bool) -> Tuple[DataFrame, Dict[str, Any]]:
+        """The body of the reference's grouped-map UDF `repair` (model.py:1095-1135) on the whole dirty frame."""
+        _logger.info("[Repairing Phase] Computing %d repair updates in %d rows..." % (len(error_cells_df), len(dirty_rows_df)))
+        pdf = dirty_rows_df.copy()
+        need_pmf = compute_repair_candidate_prob or maximal_likelihood_repair
+        pmfs: Dict[str, Any] = {}
+        for y, (model, features, _) in models:
+            X = pdf[features]
+            isnull = pdf[y].isna().to_numpy()
+            if need_pmf and y not in continous_columns:
+                predicted = model.predict_proba(X)
+                # the reference stores a JSON pmf in the cell; later models then see an unknown category,
+                # i.e. the cell stays "missing" for them -- so the column is left NULL here
+                pmfs[y] = (list(np.asarray(model.classes_).tolist()), predicted, isnull)
+            else:
+                predicted = np.asarray(model.predict(X), dtype=object if y not in continous_columns else None)
+                if y in continous_columns and is_integral_column(dirty_rows_df[y]):
+                    predicted = np.round(predicted.astype(np.float64))
+                col = pdf[y].astype(object) if y not in continous_columns else pdf[y].astype("float64")
+                col = col.where(~isnull, pd.Series(predicted, index=col.index))
+                if y in continous_columns and is_integral_column(dirty_rows_df[y]):
+                    col = col.astype("Int64")
+                pdf[y] = col
+        return pdf, pmfs
+
+    # ------------------------------------------------------------------ result shaping
+    def _flatten_join(self, repaired_rows_df: DataFrame, error_cells_df: DataFrame) -> DataFrame:
+        rid = self._row_id
+        pos = pd.Series(np.arange(len(repaired_rows_df)), index=repaired_rows_df[rid].to_numpy())
+        rp = pos.reindex(error_cells_df[rid].to_numpy()).to_numpy(np.int64)
+        vals = np.empty(len(error_cells_df), object)
+        for a, idx in error_cells_df.groupby("attribute").indices.items():
+            v = repaired_rows_df[a].to_numpy(dtype=object)[rp[idx]]
+            vals[idx] = [None if pd.isna(x) else _to_str(x) for x in v]
+        return error_cells_df.assign(repaired=vals)
+
+    def _compute_repair_pmf(self, pmfs: Dict[str, Any], repaired_rows_df: DataFrame, dirty_rows_df: DataFrame,
+                            error_cells_df: DataFrame, continous_columns: List[str]) -> DataFrame:
+        rid = self._row_id
+        thres = float(self._get_option_value(*self._opt_prob_threshold))
+        top_k = int(self._get_option_value(*self._opt_prob_top_k))
+        weight = float(self._get_option_value(*self._opt_cost_weight))
+        pos = pd.Series(np.arange(len(dirty_rows_df)), index=dirty_rows_df[rid].to_numpy())
+        rows = []
+        for r in error_cells_df.itertuples(index=False):
+            rowid, attr, cur = r[0], r[1], r[2]
+            i = int(pos[rowid])
+            if attr in continous_columns:
+                v = repaired_rows_df[attr].iloc[i]
+                rows.append((rowid, attr, {"value": cur, "prob": 0.0}, [{"class": None if pd.isna(v) else _to_str(v), "prob": 1.0}]))
+                continue
+            classes, predicted, _ = pmfs[attr]
+            probs = predicted[i]
+            if probs is None:
+                cls, pr = [], []
+            else:
+                cls, pr = [_to_str(c) for c in classes], [float(p) for p in np.asarray(probs)[:len(classes)]]
+            if self.cf is not None and pr and (not self.cf.targets or attr in self.cf.targets):
+                costs = [self.cf.compute(cur, c) for c in cls] if cur else None
+                if costs is not None:
+                    pr = [p * (1.0 / (1.0 + weight * c)) if c is not None else p for p, c in zip(pr, costs)]
+                norm = sum(pr)
+                pr = [p / norm for p in pr] if norm > 0 else pr
+            cur_prob = pr[cls.index(cur)] if cur in cls else 0.0
+            order = sorted(range(len(cls)), key=lambda j: -pr[j])   # stable: ties keep class order
+            pmf = [{"class": cls[j], "prob": pr[j]} for j in order if pr[j] > thres][:top_k]
+            rows.append((rowid, attr, {"value": cur, "prob": cur_prob}, pmf))
+        return pd.DataFrame(rows, columns=[rid, "attribute", "current_value", "pmf"])
+
+    def _compute_score(self, pmf_df: DataFrame) -> DataFrame:
+        assert self.cf is not None
+        out = []
+        for r in pmf_df.itertuples(index=False):
+            cur, pmf = r.current_value, r.pmf
+            rep = pmf[0] if pmf else {"class": None, "prob": 0.0}
+            base = cur["value"] if cur["value"] is not None else rep["class"]
+            cost = self.cf.compute(base, rep["class"])
+            p_cur = cur["prob"] if cur["prob"] > 0.0 else 1e-6
+            score = float(np.log(rep["prob"] / p_cur)) * (1.0 / (1.0 + (cost if cost is not None else 256.0))) if rep["prob"] > 0 else float("-inf")
+            out.append((r[0], r.attribute, cur["value"], rep["class"], score))
+        return pd.DataFrame(out, columns=[self._row_id, "attribute", "current_value", "repaired", "score"])
+
+    def _maximal_likelihood_repair(self, score_df: DataFrame, error_cells_df: DataFrame) -> DataFrame:
+        assert self.repair_delta is not None
+        n = len(error_cells_df)
+        percent = min(1.0, 1.0 - self.repair_delta / n)
+        thres = float(np.percentile(score_df["score"].to_numpy(np.float64), percent * 100.0)) if n else 0.0
+        top = score_df[score_df["score"] >= thres].drop(columns=["score"])
+        _logger.info("[Repairing Phase] %d repair updates (delta=%d) selected among %d candidates" % (len(top), self.repair_delta, n))
+        return top
+
+    def _repair_attrs(self, updates: DataFrame, base: DataFrame) -> DataFrame:
+        """RepairMiscApi.repairAttrsFrom: apply (row_id, attribute, repaired) updates to a table."""
+        out = base.copy()
+        pos = pd.Series(np.arange(len(out)), index=out[self._row_id].to_numpy())
+        for a, grp in updates.groupby("attribute"):
+            rows = pos.reindex(grp[self._row_id].to_numpy()).to_numpy(np.int64)
+            col = out[a].astype(object) if not is_numeric_column(out[a]) else out[a].astype("float64")
+            vals = grp["repaired"].to_numpy(dtype=object)
+            if is_numeric_column(base[a]):
+                vals = pd.to_numeric(pd.Series(vals), errors="coerce").to_numpy()
+            col.iloc[rows] = vals
+            out[a] = col
+        return out
+
+    def _repair_by_nearest_values(self, repair_base_df: DataFrame, error_cells_df: DataFrame, target_columns: List[str]) -> Tuple[DataFrame, DataFrame]:
+        assert self.cf is not None
+        targets = [c for c in target_columns if c in self.cf.targets] if self.cf.targets else target_columns
+        merge_thres = float(self._get_option_value(*self._opt_merge_threshold))
+        rep = np.empty(len(error_cells_df), object)
+        dom = {c: list(pd.unique(repair_base_df[c].dropna())) for c in targets}
+        for i, r in enumerate(error_cells_df.itertuples(index=False)):
+            rep[i] = None
+            r = type('R', (), dict(attribute=r[1], current_value=r[2]))
+            if r.attribute in dom and r.current_value:
+                costs = sorted(((self.cf.compute(r.current_value, _to_str(v)), _to_str(v)) for v in dom[r.attribute]),
+                               key=lambda t: (t[0] is None, t[0]))
+                costs = [c for c in costs if c[0] is not None]
+                if costs and costs[0][0] <= merge_thres and (len(costs) == 1 or costs[0][0] < costs[1][0]):
+                    rep[i] = costs[0][1]
+        done = pd.notna(pd.Series(rep)).to_numpy()
+        repaired = error_cells_df[done].assign(repaired=rep[done])
+        return error_cells_df[~done], repaired
+
+    # ------------------------------------------------------------------ pipeline
+    @elapsed_time  # type: ignore
+    def _run(self, input_df: DataFrame, continous_columns: List[str], detect_errors_only: bool,
+             compute_repair_candidate_prob: bool, compute_repair_prob: bool, compute_repair_score: bool,
+             repair_data: bool, maximal_likelihood_repair: bool) -> DataFrame:
+        rid = self._row_id
+        # 1. Error Detection Phase
+        _logger.info("[Error Detection Phase] Detecting errors in a table... ")
+        error_cells_df, target_columns, pairwise_attr_stats, domain_stats = self._detect_errors(input_df, continous_columns)
+        if detect_errors_only:
+            return error_cells_df
+        if len(error_cells_df) == 0:
+            _logger.info("Any error cell not found, so the input data is already clean")
+            return input_df if repair_data else error_cells_df.assign(repaired=pd.Series([], dtype=object))
+        if len(target_columns) == 0:
+            raise ValueError("At least one valid discretizable feature is needed to repair error cells, but no such feature found")
+        error_cells_df = error_cells_df[error_cells_df["attribute"].isin(target_columns)].reset_index(drop=True)
+
+        # 2. Repair Model Training Phase
+        repair_base_df = self._prepare_repair_base_cells(input_df, error_cells_df, target_columns)
+        repaired_by_rules_df = None
+        if self.repair_by_rules:
+            repaired_by_rules_df = error_cells_df.iloc[0:0].assign(repaired=pd.Series([], dtype=object))
+            if self._repair_by_regex_enabled and any(isinstance(d, RegExErrorDetector) for d in self.error_detectors):
+                _logger.warning("regex-structure repair (RegexStructureRepair.scala) is outside the accelerated path and not available")
+            if self._repair_by_nearest_values_enabled:
+                error_cells_df, by_nv = self._repair_by_nearest_values(repair_base_df, error_cells_df, target_columns)
+                repaired_by_rules_df = pd.concat([repaired_by_rules_df, by_nv], ignore_index=True)
+            repair_base_df = self._repair_attrs(repaired_by_rules_df, repair_base_df)
+        dirty_ids = set(error_cells_df[rid].tolist())
+        is_dirty = repair_base_df[rid].isin(dirty_ids).to_numpy()
+        clean_rows_df, dirty_rows_df = repair_base_df[~is_dirty], repair_base_df[is_dirty].reset_index(drop=True)
+        models = self._build_repair_models(repair_base_df, target_columns, continous_columns, domain_stats, pairwise_attr_stats)
+
+        # 3. Repair Phase
+        repaired_rows_df, pmfs = self._repair(models, continous_columns, dirty_rows_df, error_cells_df,
+                                              compute_repair_candidate_prob, maximal_likelihood_repair)
+        if compute_repair_candidate_prob and not maximal_likelihood_repair:
+            assert not self._repair_by_nearest_values_enabled, "repairing data by nearest values not supported in this path"
+            pmf_df = self._compute_repair_pmf(pmfs, repaired_rows_df, dirty_rows_df, error_cells_df, continous_columns)
+            pmf_df = pmf_df.assign(current_value=[c["value"] for c in pmf_df["current_value"]])
+            if compute_repair_prob:
+                return pd.DataFrame({rid: pmf_df[rid], "attribute": pmf_df["attribute"], "current_value": pmf_df["current_value"],
+                                     "repaired": [p[0]["class"] if p else None for p in pmf_df["pmf"]],
+                                     "prob": [p[0]["prob"] if p else None for p in pmf_df["pmf"]]})
+            return pmf_df
+        if maximal_likelihood_repair:
+            assert len(continous_columns) == 0
+            pmf_df = self._compute_repair_pmf(pmfs, repaired_rows_df, dirty_rows_df, error_cells_df, [])
+            score_df = self._compute_score(pmf_df)
+            if compute_repair_score:
+                return score_df
+            top = self._maximal_likelihood_repair(score_df, error_cells_df)
+            if not repair_data:
+                return top
+            repaired_rows_df = self._repair_attrs(top, dirty_rows_df)
+        if repair_data:
+            clean_df = pd.concat([clean_rows_df, repaired_rows_df], ignore_index=True)
+            assert len(clean_df) == len(input_df)
+            return clean_df
+        cand = self._flatten_join(repaired_rows_df, error_cells_df)
+        keep = cand["repaired"].isna() | ~((cand["current_value"] == cand["repaired"]) | (cand["current_value"].isna() & cand["repaired"].isna()))
+        cand = cand[keep.to_numpy()].reset_index(drop=True)
+        if self.repair_by_rules and repaired_by_rules_df is not None:
+            cand = pd.concat([cand, repaired_by_rules_df], ignore_index=True)
+        return cand
+
+    def run(self, detect_errors_only: bool = False, compute_repair_candidate_prob: bool = False,
+            compute_repair_prob: bool = False, compute_repair_score: bool = False, repair_data: bool = False,
+            maximal_likelihood_repair: bool = False) -> DataFrame:
+        """Starts processing to detect error cells in given input data and build a statistical model to
+        repair them (reference model.py:1421-1537: same flags, same exclusivity rules, same messages)."""
+        if self.input is None or self.row_id is None:
+            raise ValueError("`setInput` and `setRowId` should be called before repairing")
+        if maximal_likelihood_repair and self.repair_delta is None:
+            raise ValueError("`setRepairDelta` should be called when enabling maximal likelihood repairing")
+        if maximal_likelihood_repair and self.cf is None:
+            raise ValueError("`setUpdateCostFunction` should be called when enabling maximal likelihood repairing")
+        if maximal_likelihood_repair and len(self.cf.targets) > 0:  # type: ignore
+            raise ValueError("`UpdateCostFunction.targets` cannot be used when enabling maximal likelihood repairing")
+        flags = [("detect_errors_only", detect_errors_only), ("compute_repair_candidate_prob", compute_repair_candidate_prob),
+                 ("compute_repair_prob", compute_repair_prob), ("compute_repair_score", compute_repair_score), ("repair_data", repair_data)]
+        selected = [n for n, v in flags if v]
+        if len(selected) > 1:
+            raise ValueError("%s cannot be set to true simultaneously" % to_list_str(selected, sep="/", quote=True))
+        if self._repair_by_nearest_values_enabled and (maximal_likelihood_repair or compute_repair_candidate_prob or compute_repair_prob or compute_repair_score):
+            raise ValueError("Cannot repair data by nearest values when enabling `maximal_likelihood_repair`, "
+                             "`compute_repair_candidate_prob`, `compute_repair_prob`, or `compute_repair_score`")
+        if compute_repair_prob or compute_repair_score:
+            compute_repair_candidate_prob = True
+        if compute_repair_score:
+            maximal_likelihood_repair = True
+        input_df, continous_columns = self._check_input_table()
+        if maximal_likelihood_repair and len(continous_columns) != 0:
+            raise ValueError("Cannot enable the maximal likelihood repair mode when continous attributes found")
+        if self.targets and len(set(self.targets) & set(input_df.columns)) == 0:
+            raise ValueError("Target attributes not found in the input table: %s" % to_list_str(self.targets))
+        self.opts.setdefault("model.gpu.device_id", self.opts.get("model.gpu.device_id", "0"))
+        df, elapsed = self._run(input_df, continous_columns, detect_errors_only, compute_repair_candidate_prob,
+                                compute_repair_prob, compute_repair_score, repair_data, maximal_likelihood_repair)
+        _logger.info("!!!Total Processing time is %s(s)!!!" % elapsed)
+        return df
+
+
+def _to_str(v: Any) -> str:
+    if isinstance(v, (float, np.floating)):
+        return repr(float(v))
+    if isinstance(v, (np.integer,)):
+        return str(int(v))
+    return str(v)

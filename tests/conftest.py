@@ -11,3 +11,18 @@ for p in (ROOT, os.path.join(ROOT, "spark-data-repair-plugin_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def oracle_backend():
+    """Routes repair.gbm to the CPU oracle for the duration of a (CPU-only) test."""
+    from repair import gbm
+    from tests.helpers import OracleBackend
+    prev = gbm.set_backend(OracleBackend)
+    yield OracleBackend
+    gbm.set_backend(prev)
+
+
+@pytest.fixture(autouse=True)
+def _testing_env(monkeypatch):
+    monkeypatch.setenv("REPAIR_TESTING", "1")   # bad option values raise (reference: SPARK_TESTING)

@@ -1,0 +1,90 @@
+"""Shared test helpers: golden fixture loading and the oracle-backed compute backend.
+
+The oracle backend exposes the same train()/Model API as repair._native so the product's host code
+(repair.gbm / repair.model) can be exercised on CPU-only machines.  It lives under tests/ because
+only tests may touch oracle/.
+"""
+import gzip
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with gzip.open(os.path.join(GOLDEN, name + ".json.gz"), "rt", encoding="utf-8") as f:
+        return json.load(f)
+
+
+def frame(t, dtypes=True):
+    df = pd.DataFrame(t["rows"], columns=t["columns"])
+    if dtypes and "dtypes" in t:
+        for c, d in t["dtypes"].items():
+            if d.startswith("int") and df[c].isna().any():
+                df[c] = df[c].astype("Int64")
+            elif d.startswith(("int", "float")):
+                df[c] = df[c].astype(d)
+    return df
+
+
+class OracleBackend:
+    """Drop-in for the `repair._native` module surface used by repair.gbm (test infrastructure)."""
+    from oracle import oracle as _O
+
+    class Model(_O.OracleModel):
+        def importance(self, kind="gain"):
+            # feature importances are not part of the oracle; split counts from the serialised trees
+            return np.zeros(self.info()["F"], np.float64)
+
+        @staticmethod
+        def load(b):
+            m = OracleBackend._O.OracleModel.load(b)
+            m.__class__ = OracleBackend.Model
+            return m
+
+        def predict(self, X, device_id=None):
+            return OracleBackend._O.OracleModel.predict(self, X)
+
+    @staticmethod
+    def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample_weight=None, **params):
+        params.pop("device_id", None)
+        m = OracleBackend._O.train(X, n_codes, y_code, n_y_codes, y_value=y_value, class_weight=class_weight,
+                                   sample_weight=sample_weight, **params)
+        m.__class__ = OracleBackend.Model
+        return m
+
+
+class OracleEngine:
+    """repair.engine-compatible engine on the CPU oracle (for the gloo multi-rank tests)."""
+    name = "oracle"
+
+    class _Table:
+        def __init__(self, codes, n_codes):
+            self.codes = np.ascontiguousarray(codes, np.int32).copy()
+            self.n_codes = np.asarray(n_codes, np.int32)
+            self.c, self.n = self.codes.shape
+
+    def upload(self, codes, n_codes):
+        return OracleEngine._Table(codes, n_codes)
+
+    def train(self, table, target, feats, class_weight, params, y_value=None, want_stats=False):
+        from oracle import oracle as O
+        rows = table.codes[target] >= 0
+        p = {k: v for k, v in params.items() if k != "device_id"}
+        m = O.train(np.ascontiguousarray(table.codes[feats][:, rows]), table.n_codes[feats], table.codes[target][rows],
+                    int(table.n_codes[target]), y_value=y_value, class_weight=class_weight, **p)
+        return (m, {"hist_ms": 0.0, "hist_bytes": 0, "hist_launches": 0, "root_ms": 0.0, "root_rows": 0}) if want_stats else m
+
+    def load_model(self, blob):
+        from oracle import oracle as O
+        return O.OracleModel.load(blob)
+
+    def repair_chain(self, table, models, targets, feats, row_begin, n_rows):
+        from oracle import oracle as O
+        sub = np.ascontiguousarray(table.codes[:, row_begin:row_begin + n_rows])
+        lab, prob = O.repair_chain(models, targets, feats, [list(range(int(table.n_codes[t]))) for t in targets], sub)
+        table.codes[:, row_begin:row_begin + n_rows] = sub
+        return lab, prob
