@@ -46,13 +46,14 @@ def main():
         "constraints": open(os.path.join(REF, "testdata/hospital_constraints.txt")).read(),
     })
     dump("boston", {
-        "source": "testdata/boston.csv, bin/testdata/boston_clean.csv; schema python/repair/tests/test_model_perf.py:74-76",
-        "input": table("testdata/boston.csv"),
+        "source": "bin/testdata/boston.csv, testdata/boston.csv, bin/testdata/boston_clean.csv; schema python/repair/tests/test_model_perf.py:74-76",
+        "input": table("bin/testdata/boston.csv"),             # what test_model_perf.py loads ($REPAIR_TESTDATA)
+        "input_testdata": table("testdata/boston.csv"),        # BASELINE.json configs[4]
         "clean": table("bin/testdata/boston_clean.csv"),
     })
     dump("iris", {
-        "source": "testdata/iris.csv, bin/testdata/iris_clean.csv",
-        "input": table("testdata/iris.csv"),
+        "source": "bin/testdata/iris.csv, bin/testdata/iris_clean.csv",
+        "input": table("bin/testdata/iris.csv"),
         "clean": table("bin/testdata/iris_clean.csv"),
     })
     dump("inline_goldens", {

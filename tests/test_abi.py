@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads, exports every symbol include/rgbm.h declares, and fails loudly
+(no CPU fallback) when no HIP device is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "rgbm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgbm_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    from repair import _native
+    lib = _native.lib()
+    names = _declared()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), "include/rgbm.h declares %s but librepairgbm.so does not export it" % n
+    assert sorted(_native.EXPORTED_SYMBOLS) == names
+
+
+def test_no_oracle_symbols_or_cpu_fallback_in_product():
+    from repair import _native
+    lib = _native.lib()
+    assert not hasattr(lib, "orc_train")
+    # product sources never reference oracle/
+    pkg = os.path.join(ROOT, "spark-data-repair-plugin_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "librgbm_oracle" not in txt, f
+
+
+def test_fails_loudly_without_gpu():
+    from repair import _native
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_native.RepairGbmError, match="no HIP device"):
+        _native.train(np.zeros((2, 10), np.int32), [1, 1], np.zeros(10, np.int32), 2, objective=0)
+    with pytest.raises(_native.RepairGbmError):
+        _native.Table(np.zeros((2, 10), np.int32), [1, 1])
+    from repair.engine import HipEngine
+    with pytest.raises(_native.RepairGbmError, match="no CPU fallback"):
+        HipEngine(0)
+
+
+def test_model_blob_roundtrip_and_validation():
+    """rgbm_model_save/load work on the host (no GPU needed) and reject corrupt input."""
+    from oracle import oracle as O
+    from repair import _native
+    rng = np.random.default_rng(0)
+    X = rng.integers(0, 5, (3, 500)).astype(np.int32); y = (X[0] + X[1]) % 3
+    blob = O.train(X, [5, 5, 5], y, 3, objective=1, num_class=3, n_estimators=5, min_data_in_leaf=5).save()
+    m = _native.Model.load(blob)            # shared serialisation format
+    assert m.save() == blob
+    assert m.info() == dict(objective=1, num_class=3, K=3, n_iter=5, F=3)
+    assert m.importance("split").sum() > 0
+    with pytest.raises(_native.RepairGbmError):
+        _native.Model.load(blob[:40])
+    bad = bytearray(blob); bad[0] ^= 0xFF
+    with pytest.raises(_native.RepairGbmError):
+        _native.Model.load(bytes(bad))
+
+
+def test_params_struct_layout_matches_oracle():
+    from oracle import oracle as O
+    from repair import _native
+    assert [f[0] for f in O.OrcParams._fields_] == [f[0] for f in _native.RgbmParams._fields_]
+    assert ctypes.sizeof(O.OrcParams) == ctypes.sizeof(_native.RgbmParams) == 104

@@ -1,0 +1,71 @@
+"""CPU: the N>1 path -- target-sharded training, model all-gather, row-sharded chained repair and the
+result all-gather -- on 2 gloo ranks.  The sharding/communication code is the product's
+(repair.dist / repair.engine.run_job); the per-rank compute is the CPU oracle because no GPU exists
+here.  Result must equal the single-process run bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from tests.synth import make_table
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARAMS = dict(num_leaves=15, max_depth=7, max_bin=255, min_data_in_leaf=20, min_data_in_bin=3, bagging_freq=0, seed=42,
+              learning_rate=0.2, lambda_l1=0.0, lambda_l2=0.0, min_gain_to_split=0.0, min_sum_hessian_in_leaf=1e-3,
+              bagging_fraction=1.0, feature_fraction=1.0, n_estimators=6)
+
+
+def _job():
+    from repair.engine import run_job
+    from tests.helpers import OracleEngine
+    dirty, clean, cards = make_table(6000, 6, seed=21, null_ratio=0.03)
+    targets = [0, 2, 3, 5]
+    counts = {t: np.bincount(dirty[t][dirty[t] >= 0], minlength=int(cards[t])) for t in targets}
+    mask = (dirty[targets] < 0).any(axis=0)
+    eng = OracleEngine()
+    res = run_job(eng, eng.upload(dirty, cards), eng.upload(np.ascontiguousarray(dirty[:, mask]), cards), cards, targets, counts, PARAMS)
+    return res
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spark-data-repair-plugin_amd"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = _job()
+        q.put((rank, res["labels"], res["probs"], sorted(res["models"].items()), res["my_targets"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_assign_targets_lpt_and_row_shards():
+    from repair import dist
+    out = dist.assign_targets([(0, 1), (1, 3), (2, 4), (3, 6), (4, 8), (5, 64)], 2)
+    assert sorted(sum(out, [])) == [0, 1, 2, 3, 4, 5] and out[0] == [5]
+    assert dist.assign_targets([(7, 5.0)], 4) == [[7], [], [], []]
+    shards = [dist.shard_rows(10, 4, r) for r in range(4)]
+    assert shards == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert dist.shard_rows(0, 2, 1) == (0, 0)
+
+
+def test_two_rank_gloo_job_equals_single_process():
+    import torch.multiprocessing as mp
+    single = _job()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(outs[0][4] + outs[1][4]) == [0, 2, 3, 5] and outs[0][4] and outs[1][4]   # both ranks trained something
+    for rank, labels, probs, models, _ in outs:
+        assert np.array_equal(labels, single["labels"])
+        assert np.array_equal(probs, single["probs"])
+        assert models == sorted(single["models"].items())
