@@ -163,11 +163,6 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
     f.V = greedy_find_bin(dv, dc, mb, seen, p.min_data_in_bin, f.ub);
 }
 
-inline int code_to_bin(const Feat& f, int32_t c) {
-    int lo = 0, hi = f.V - 1;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (c <= f.ub[mid]) hi = mid; else lo = mid + 1; }
-    return lo;
-}
 
 // LightGBM utils/random.h (as remembered)
 struct LgbRand {
@@ -205,7 +200,8 @@ void check_params(const rgbm_params& p) {
     if (!(p.learning_rate > 0.0)) throw std::invalid_argument("learning_rate must be positive");
     if (p.objective == 1 && p.num_class < 2) throw std::invalid_argument("multiclass needs num_class >= 2");
     if (p.min_data_in_leaf < 0 || p.lambda_l1 < 0 || p.lambda_l2 < 0) throw std::invalid_argument("negative regularisation / min_data_in_leaf");
-    if (p.bagging_freq > 0 && p.bagging_fraction < 1.0) throw std::invalid_argument("bagging (subsample < 1) is not implemented in the HIP trainer yet");
+    if (p.bagging_fraction <= 0.0 || p.bagging_fraction > 1.0) throw std::invalid_argument("bagging_fraction must be in (0, 1]");
+    if (p.feature_fraction <= 0.0 || p.feature_fraction > 1.0) throw std::invalid_argument("feature_fraction must be in (0, 1]");
 }
 
 void use_device(int device_id) {
@@ -405,6 +401,25 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     }
     DevBuf<uint8_t> d_used(used.size()); d_used.upload(used.data(), used.size(), s);
 
+    // bagging state (GBDT::Bagging): stable training-row order, one LCG per 1024 positions
+    const bool use_bagging = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
+    DevBuf<int32_t> d_sorted_rows, d_oob; DevBuf<unsigned int> d_blk, d_rand, d_bagcnt; DevBuf<uint8_t> d_inbag;
+    if (use_bagging) {
+        const long long nblk = (N + 1023) / 1024;
+        d_blk.alloc(nblk); d_sorted_rows.alloc(n_train); d_oob.alloc(n_train); d_inbag.alloc(N); d_bagcnt.alloc(2);
+        hipLaunchKernelGGL(k_block_count, dim3((unsigned)nblk), dim3(256), 0, s, d_ycol, (long long)N, d_blk.p);
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, d_blk.p, nblk);
+        hipLaunchKernelGGL(k_stable_compact, dim3((unsigned)nblk), dim3(256), 0, s, d_ycol, (long long)N, d_blk.p, d_sorted_rows.p);
+        const long long nrb = (n_train + 1023) / 1024;
+        LgbRand sr2((uint32_t)p.seed); sr2.rnd16();
+        const int bagging_seed = sr2.rnd16();
+        std::vector<unsigned int> st(nrb);
+        for (long long b = 0; b < nrb; ++b) st[b] = (unsigned int)(bagging_seed + b);
+        d_rand.alloc(nrb); d_rand.upload(st.data(), nrb, s);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    const unsigned int* n_in_ptr = use_bagging ? d_bagcnt.p : nullptr;
+
     if (lds_hist > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
     if (lds_hist > 160 * 1024) throw std::invalid_argument("histogram working set exceeds LDS");
 
@@ -428,10 +443,17 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     // ---- 5. boosting iterations: everything below is enqueue-only
     for (int it = 0; it < NE; ++it) {
         const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw = sample_weight_host ? d_sw.p : nullptr;
-        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, d_gh.p, tc);
-        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, d_gh.p, tc);
-        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, d_gh.p, tc);
-        hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, it, tc);
+        if (use_bagging && it % p.bagging_freq == 0) {
+            const long long nrb = (n_train + 1023) / 1024;
+            d_bagcnt.zero(s);
+            hipLaunchKernelGGL(k_bagging, dim3((unsigned)((nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, (long long)n_train, p.bagging_fraction, d_sorted_rows.p, d_inbag.p);
+            hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((n_train + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, (long long)n_train, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
+        }
+        const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
+        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, tc);
+        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, tc);
+        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, tc);
+        hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);
         const uint8_t* usedp = d_used.p + (size_t)it * K * F;
         for (int step = 0; step < NL - 1; ++step) {
             launch_hist(step == 0);
@@ -441,7 +463,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             hipLaunchKernelGGL(k_finish_split, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, to, it, tc);
         }
         hipLaunchKernelGGL(k_finalize_tree, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, to, d_init.p, d_upd.p, d_sorted.p, d_any.p, it, tc);
-        hipLaunchKernelGGL(k_score_update, dim3(upd_gx, K), dim3(256), upd_lds, s, d_state.p, d_leaves.p, d_sorted.p, d_upd.p, d_idx0.p, d_idx1.p, d_base.p, d_score.p, tc);
+        hipLaunchKernelGGL(k_score_update, dim3(upd_gx, K), dim3(256), upd_lds, s, d_state.p, d_leaves.p, d_sorted.p, d_upd.p, d_idx0.p, d_idx1.p, d_base.p, d_score.p, n_in_ptr, tc);
+        if (use_bagging)
+            hipLaunchKernelGGL(k_score_update_oob, dim3(upd_gx, K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(d_rec.p), d_oob.p, d_bagcnt.p,
+                               d_state.p, to, d_fmeta.p, d_upd.p, d_score.p, it, tc);
     }
     HIPCHK(hipGetLastError());
 

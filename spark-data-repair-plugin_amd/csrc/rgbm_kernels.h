@@ -23,6 +23,11 @@ namespace rg {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+struct TreeOut {   // flat device arrays of every tree of the model, [(it*K+k)] major
+    int32_t* L; int32_t* feat; int32_t* theta; int32_t* dleft; int32_t* left; int32_t* right; double* gain;
+    double* leaf_value; int32_t* leaf_count;
+};
+
 // ------------------------------------------------------------------------------------------------
 // K0: code frequencies.  grid (gx, F), block 256.  Small dictionaries are privatised in LDS.
 // ------------------------------------------------------------------------------------------------
@@ -99,11 +104,17 @@ __global__ __launch_bounds__(256) void k_init_score(double* __restrict__ score, 
 template <int OBJ>
 __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, const int32_t* __restrict__ ycol,
                                               const double* __restrict__ y_value, const double* __restrict__ class_w,
-                                              const double* __restrict__ sample_w, int2* __restrict__ gh, TrainConst c) {
+                                              const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
+                                              int2* __restrict__ gh, TrainConst c) {
     const long long N = c.N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const int y = ycol[i];
         if (y < 0) continue;   // not a training row: its gh stays 0 for ever
+        if (row_in_bag && !row_in_bag[i]) {   // out of bag this round: contributes nothing to any histogram
+            const int K = (OBJ == 1) ? c.K : 1;
+            for (int k = 0; k < K; ++k) gh[(long long)k * N + i] = make_int2(0, 0);
+            continue;
+        }
         double wi = class_w ? class_w[y] : 1.0;
         if (sample_w) wi = wi * sample_w[i];
         wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
@@ -409,10 +420,6 @@ __global__ __launch_bounds__(256) void k_split_find(HistBin* __restrict__ pool, 
 // searched leaves (SplitInfo::operator>: gain, then smaller feature); (2) pick the best leaf
 // (ArrayArgs::ArgMax); (3) Tree::Split bookkeeping and partition request.
 // ------------------------------------------------------------------------------------------------
-struct TreeOut {   // flat device arrays of every tree of the model, [(it*K+k)] major
-    int32_t* L; int32_t* feat; int32_t* theta; int32_t* dleft; int32_t* left; int32_t* right; double* gain;
-    double* leaf_value; int32_t* leaf_count;
-};
 
 __device__ __forceinline__ bool leaf_better(double ga, int fa, int la, double gb, int fb, int lb) {
     if (ga != gb) return ga > gb;
@@ -580,22 +587,23 @@ __global__ __launch_bounds__(64) void k_finish_split(TreeState* __restrict__ sta
 }
 
 __global__ __launch_bounds__(64) void k_init_iter(TreeState* __restrict__ state, Leaf* __restrict__ leaves, HistBin* __restrict__ pool,
-                                                  TreeOut out, int it, TrainConst c) {
+                                                  TreeOut out, const unsigned int* __restrict__ n_in_ptr, int it, TrainConst c) {
     const int k = blockIdx.x, lane = lane_id();
+    const long long n_in = n_in_ptr ? (long long)n_in_ptr[0] : c.n_train;
     HistBin* z = pool + (long long)k * c.num_leaves * c.totbins;
     for (int i = lane; i < c.totbins; i += 64) { z[i].g = 0; z[i].h = 0; }
     if (lane == 0) {
         TreeState s; memset(&s, 0, sizeof(s));
-        s.L = 1; s.done = 0; s.hist_is_root = 1; s.hist_begin = 0; s.hist_count = (int)c.n_train; s.hist_buf = 2;
-        s.do_hist = (c.n_train < (long long)c.min_data_in_leaf * 2) ? 0 : 1;
+        s.L = 1; s.done = 0; s.hist_is_root = 1; s.hist_begin = 0; s.hist_count = (int)n_in; s.hist_buf = 2;
+        s.do_hist = (n_in < (long long)c.min_data_in_leaf * 2) ? 0 : 1;
         state[k] = s;
         Leaf r; memset(&r, 0, sizeof(r));
-        r.begin = 0; r.count = (int)c.n_train; r.buf = 2; r.depth = 0; r.parent_node = -1; r.is_left = 0;
+        r.begin = 0; r.count = (int)n_in; r.buf = 2; r.depth = 0; r.parent_node = -1; r.is_left = 0;
         r.best.gain = -INFINITY; r.best_feature = -1;
         leaves[(long long)k * c.num_leaves] = r;
         const long long tbase = (long long)it * c.K + k;
         out.L[tbase] = 1;
-        out.leaf_count[tbase * c.num_leaves] = (int)c.n_train;
+        out.leaf_count[tbase * c.num_leaves] = (int)n_in;
     }
 }
 
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(64) void k_finalize_tree(const TreeState* __restric
 __global__ __launch_bounds__(256) void k_score_update(const TreeState* __restrict__ state, const Leaf* __restrict__ leaves,
                                                       const int32_t* __restrict__ sorted, const double* __restrict__ upd_value,
                                                       const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1,
-                                                      const int32_t* __restrict__ base_idx, double* __restrict__ score, TrainConst c) {
+                                                      const int32_t* __restrict__ base_idx, double* __restrict__ score, const unsigned int* __restrict__ n_in_ptr, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int k = blockIdx.y;
     const int L = state[k].L;
@@ -654,13 +662,133 @@ __global__ __launch_bounds__(256) void k_score_update(const TreeState* __restric
     }
     __syncthreads();
     double* sk = score + (long long)k * c.N;
-    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < c.n_train; p += (long long)gridDim.x * 256) {
+    const long long n_in = n_in_ptr ? (long long)n_in_ptr[0] : c.n_train;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n_in; p += (long long)gridDim.x * 256) {
         int lo = 0, hi = L - 1;    // last i with sb[i] <= p
         while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (sb[mid] <= (int)p) lo = mid; else hi = mid - 1; }
         const int bf = sbuf[lo];
         const int32_t* src = bf == 0 ? idx0 + (long long)k * c.n_train : (bf == 1 ? idx1 + (long long)k * c.n_train : base_idx);
         const int row = src[p];
         sk[row] += sv[lo];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K8: bagging (GBDT::Bagging / BaggingHelper).  LightGBM draws one LCG float per training row in
+// blocks of 1024 rows, each block owning its own generator seeded bagging_seed + block; the
+// generator state survives between bagging events.  Positions are ranks among the training rows in
+// ascending row order, so a stable compaction of the training rows comes first.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_block_count(const int32_t* __restrict__ ycol, long long N, unsigned int* __restrict__ blk_cnt) {
+    // one workgroup per 1024 table rows
+    __shared__ unsigned int ws[4];
+    const long long base = (long long)blockIdx.x * 1024;
+    unsigned int c = 0;
+    for (int j = 0; j < 4; ++j) { long long r = base + j * 256 + threadIdx.x; if (r < N && ycol[r] >= 0) ++c; }
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(1024) void k_block_scan(unsigned int* __restrict__ blk_cnt, long long nblk) {
+    // single workgroup: in-place exclusive scan of the per-block counts
+    __shared__ unsigned int part[1024];
+    __shared__ unsigned int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long b0 = 0; b0 < nblk; b0 += 1024) {
+        long long i = b0 + threadIdx.x;
+        unsigned int v = i < nblk ? blk_cnt[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            unsigned int t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblk) blk_cnt[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stable_compact(const int32_t* __restrict__ ycol, long long N, const unsigned int* __restrict__ blk_off,
+                                                        int32_t* __restrict__ sorted_rows) {
+    __shared__ unsigned int wsum[16];
+    const long long base = (long long)blockIdx.x * 1024;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned int pre[4]; bool on[4];
+    for (int j = 0; j < 4; ++j) {
+        long long r = base + j * 256 + threadIdx.x;
+        on[j] = r < N && ycol[r] >= 0;
+        unsigned long long m = __ballot(on[j]);
+        pre[j] = __popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) wsum[j * 4 + wv] = __popcll(m);
+    }
+    __syncthreads();
+    unsigned int off = blk_off[blockIdx.x];
+    for (int j = 0; j < 4; ++j) {
+        unsigned int o = off;
+        for (int q = 0; q < j * 4 + wv; ++q) o += wsum[q];
+        if (on[j]) sorted_rows[o + pre[j]] = (int32_t)(base + j * 256 + threadIdx.x);
+    }
+}
+
+__global__ void k_bagging(unsigned int* __restrict__ rand_state, long long n_train, double fraction, const int32_t* __restrict__ sorted_rows,
+                          uint8_t* __restrict__ row_in_bag /* [N], only training rows are written */) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long p0 = b * 1024;
+    if (p0 >= n_train) return;
+    unsigned int x = rand_state[b];
+    const long long p1 = p0 + 1024 < n_train ? p0 + 1024 : n_train;
+    for (long long p = p0; p < p1; ++p) {
+        x = 214013u * x + 2531011u;
+        float f = (float)((x >> 16) & 0x7FFF) / 32768.0f;
+        row_in_bag[sorted_rows[p]] = ((double)f < fraction) ? 1 : 0;
+    }
+    rand_state[b] = x;
+}
+
+// unstable split of the training rows into the bag list and the out-of-bag list
+__global__ __launch_bounds__(256) void k_bag_lists(const int32_t* __restrict__ sorted_rows, long long n_train, const uint8_t* __restrict__ row_in_bag,
+                                                   int32_t* __restrict__ bag, int32_t* __restrict__ oob, unsigned int* __restrict__ counters /* [2] */) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int row = 0; bool in = false, out = false;
+    if (p < n_train) { row = sorted_rows[p]; in = row_in_bag[row] != 0; out = !in; }
+    unsigned long long mi = __ballot(in), mo = __ballot(out);
+    unsigned int bi = 0, bo = 0;
+    if (lane == 0) { if (mi) bi = atomicAdd(&counters[0], (unsigned)__popcll(mi)); if (mo) bo = atomicAdd(&counters[1], (unsigned)__popcll(mo)); }
+    bi = __shfl(bi, 0); bo = __shfl(bo, 0);
+    if (in) bag[bi + __popcll(mi & ((1ull << lane) - 1))] = row;
+    if (out) oob[bo + __popcll(mo & ((1ull << lane) - 1))] = row;
+}
+
+// out-of-bag score update by tree traversal on the training bins (ScoreUpdater::AddScore(tree, oob))
+__global__ __launch_bounds__(256) void k_score_update_oob(const uint8_t* __restrict__ rec8, const int32_t* __restrict__ oob, const unsigned int* __restrict__ counters,
+                                                          const TreeState* __restrict__ state, TreeOut out, const FeatMeta* __restrict__ fmeta,
+                                                          const double* __restrict__ upd_value, double* __restrict__ score, int it, TrainConst c) {
+    const int k = blockIdx.y;
+    if (state[k].L <= 1) return;
+    const long long n_oob = counters[1];
+    const long long tbase = (long long)it * c.K + k;
+    const long long nb = tbase * (c.num_leaves - 1);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_oob; i += (long long)gridDim.x * 256) {
+        const int row = oob[i];
+        int node = 0;
+        for (;;) {
+            const int f = out.feat[nb + node];
+            const int bin = rec8[((long long)(f >> 4) * c.N + row) * 16 + (f & 15)];
+            const bool miss = fmeta[f].has_nan && bin == fmeta[f].V;
+            const bool go_left = miss ? (out.dleft[nb + node] != 0) : (bin <= out.theta[nb + node]);
+            const int nx = go_left ? out.left[nb + node] : out.right[nb + node];
+            if (nx < 0) { score[(long long)k * c.N + row] += upd_value[(long long)k * c.num_leaves + (~nx)]; break; }
+            node = nx;
+        }
     }
 }
 

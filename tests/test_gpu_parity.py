@@ -146,3 +146,63 @@ def test_table_path_and_chain_match_oracle():
     for i, t in enumerate(targets):
         nul = dirty[t] < 0
         assert (ref[t][nul] == clean[t][nul]).mean() > 0.7
+
+
+@pytest.mark.parametrize("kw", [
+    dict(bagging_fraction=0.7, bagging_freq=1),
+    dict(bagging_fraction=0.55, bagging_freq=3, feature_fraction=0.5),
+    dict(feature_fraction=0.3),
+    dict(bagging_fraction=0.9, bagging_freq=2, feature_fraction=0.8, lambda_l1=0.5, lambda_l2=2.0, min_gain_to_split=0.01,
+         num_leaves=63, max_depth=-1, min_data_in_leaf=7, min_sum_hessian_in_leaf=0.05),
+])
+def test_sampling_and_regularisation_params_bit_exact(kw):
+    """The reference's searched parameters (train.py:148-156): subsample, subsample_freq, colsample_bytree, ..."""
+    dirty, clean, cards = make_table(9000, 9, seed=17, null_ratio=0.02)
+    tgt = 6
+    feats = [c for c in range(9) if c != tgt]
+    rows = dirty[tgt] >= 0
+    X = np.ascontiguousarray(dirty[feats][:, rows]); y = dirty[tgt][rows]; K = int(cards[tgt])
+    mo, mg = _both(X, cards[feats], y, K, 1, cw=balanced_weights(y, K), n_estimators=12, learning_rate=0.15, **kw)
+    _assert_same(mo, mg, X)
+
+
+def test_bagging_on_table_path_with_null_targets():
+    from oracle import oracle as O
+    from repair import _native as N
+    dirty, clean, cards = make_table(7000, 6, seed=19, null_ratio=0.05)
+    t = 2; feats = [c for c in range(6) if c != t]; rows = dirty[t] >= 0; K = int(cards[t])
+    kw = dict(objective=1, num_class=K, n_estimators=9, learning_rate=0.2, bagging_fraction=0.6, bagging_freq=2, feature_fraction=0.7)
+    cw = balanced_weights(dirty[t], K)
+    mo = O.train(np.ascontiguousarray(dirty[feats][:, rows]), cards[feats], dirty[t][rows], K, class_weight=cw, **kw)
+    mg = N.Table(dirty, cards).train(t, feats, class_weight=cw, **kw)
+    assert mo.save() == mg.save()
+
+
+def test_sample_weight_path_bit_exact():
+    rng = np.random.default_rng(23)
+    dirty, clean, cards = make_table(5000, 6, seed=23)
+    X = np.ascontiguousarray(dirty[:5]); y = clean[5]; K = int(cards[5])
+    sw = rng.uniform(0.2, 3.0, X.shape[1])
+    mo, mg = _both(X, cards[:5], y, K, 1, cw=balanced_weights(y, K), sw=sw, n_estimators=10, learning_rate=0.2)
+    _assert_same(mo, mg, X)
+
+
+def test_build_model_hp_search_runs_on_gpu_and_matches_oracle_backend():
+    """train.build_model (hp search + CV + final fit) end to end on the HIP backend == oracle backend."""
+    import pandas as pd
+    from repair import gbm
+    from repair.train import build_model
+    from tests.helpers import OracleBackend
+    rng = np.random.default_rng(29)
+    X = pd.DataFrame({"a": rng.choice(list("xyz"), 600), "b": rng.choice(list("pqrs"), 600), "c": rng.integers(0, 6, 600)})
+    y = pd.Series(np.where(X.a == "x", "A", np.where(X.b == "p", "B", "C")))
+    opts = {"model.hp.max_evals": "4", "model.lgb.n_estimators": "25", "model.lgb.learning_rate": "0.2", "model.hp.no_progress_loss": "3"}
+    (mg, sg), _ = build_model(X, y, True, 3, n_jobs=-1, opts=opts)
+    prev = gbm.set_backend(OracleBackend)
+    try:
+        (mo, so), _ = build_model(X, y, True, 3, n_jobs=-1, opts=opts)
+    finally:
+        gbm.set_backend(prev)
+    assert mg is not None and mo is not None and sg == so
+    assert mg.booster_bytes_ == mo.booster_bytes_
+    assert np.array_equal(mg.predict_proba(X), mo.predict_proba(X))
