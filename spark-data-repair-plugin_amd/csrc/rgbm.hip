@@ -25,6 +25,7 @@
 
 #include "../../include/rgbm.h"
 #include "rgbm_kernels.h"
+#include "rgbm_level.h"
 
 #define RGBM_VERSION 100   // numerics spec v1.00
 
@@ -363,16 +364,69 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint4> d_rec((size_t)nchunk * N);
     hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tab.codes.p, (long long)N, 0ll, (long long)N,
                        d_cols.p, d_ncod.p, d_lut_off.p, d_lut.p, d_miss.p, F, nchunk, d_rec.p);
-    DevBuf<int32_t> d_base(n_train); DevBuf<unsigned int> d_counter(1); d_counter.zero(s);
-    hipLaunchKernelGGL(k_iota_train, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, (long long)N, d_base.p, d_counter.p);
+    // grower choice: the level-synchronous streaming grower (rgbm_level.h) whenever it applies; RGBM_GROWER=leafwise
+    // forces the index-list grower (both are HIP; they produce identical models)
+    const char* genv = getenv("RGBM_GROWER");
+    const bool level_mode = p.max_depth >= 1 && p.max_depth <= LV_MAX_DEPTH && F <= 255 && !(genv && strcmp(genv, "leafwise") == 0);
+    const bool use_bagging = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
+    DevBuf<int32_t> d_base; DevBuf<unsigned int> d_counter(1); d_counter.zero(s);
+    if (!level_mode || use_bagging) {
+        d_base.alloc(n_train);
+        hipLaunchKernelGGL(k_iota_train, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, (long long)N, d_base.p, d_counter.p);
+    }
     DevBuf<int2> d_gh((size_t)K * N); d_gh.zero(s);
     DevBuf<double> d_score((size_t)K * N), d_init(K);
     d_init.upload(init.data(), K, s);
     hipLaunchKernelGGL(k_init_score, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_score.p, (long long)N, K, d_init.p);
-    DevBuf<int32_t> d_idx0((size_t)K * n_train), d_idx1((size_t)K * n_train);
-    DevBuf<HistBin> d_pool((size_t)K * NL * tc.totbins);
-    DevBuf<TreeState> d_state(K); DevBuf<Leaf> d_leaves((size_t)K * NL); DevBuf<Cand> d_cand((size_t)K * 2 * F);
-    DevBuf<double> d_upd((size_t)K * NL); DevBuf<int32_t> d_sorted((size_t)K * NL * 3), d_any(NE); d_any.zero(s);
+    DevBuf<int32_t> d_idx0, d_idx1, d_sorted, d_any(NE); d_any.zero(s);
+    DevBuf<HistBin> d_pool; DevBuf<TreeState> d_state; DevBuf<Leaf> d_leaves; DevBuf<Cand> d_cand; DevBuf<double> d_upd;
+    if (!level_mode) {
+        d_idx0.alloc((size_t)K * n_train); d_idx1.alloc((size_t)K * n_train);
+        d_pool.alloc((size_t)K * NL * tc.totbins);
+        d_state.alloc(K); d_leaves.alloc((size_t)K * NL); d_cand.alloc((size_t)K * 2 * F);
+        d_upd.alloc((size_t)K * NL); d_sorted.alloc((size_t)K * NL * 3);
+    }
+    // level grower state
+    LevelConst lc; memset(&lc, 0, sizeof(lc));
+    DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
+    DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_err; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
+    int n_hnodes = 1;
+    std::vector<int> lv_groups(LV_MAX_DEPTH + 1, 1);
+    if (level_mode) {
+        const long long ntiles = (N + LV_TILE - 1) / LV_TILE;
+        // workgroups per (class tree, chunk): one 1024-thread workgroup per CU; pick the count that fills whole
+        // rounds of 256 CUs best, with <= 2^22 rows per workgroup (32-bit carry words) and >= 1 tile each
+        const long long per = (long long)K * nchunk;
+        long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
+        long long gx = gmin; double best_eff = -1.0;
+        for (long long g = gmin; g < gmin + 512 && g <= std::max(gmin, ntiles); ++g) {
+            const long long tot = g * per, rounds = (tot + 255) / 256;
+            const double eff = (double)tot / (double)(rounds * 256);
+            if (eff > best_eff + 1e-9) { best_eff = eff; gx = g; }
+            if (tot >= 256 && eff >= 0.999) break;
+        }
+        gx = std::min<long long>(gx, std::max<long long>(gmin, ntiles));
+        lc.gx = (int)gx; lc.max_built = 1 << std::max(0, p.max_depth - 2); lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
+        lc.num_leaves = NL; lc.max_depth = p.max_depth; lc.min_data_in_leaf = p.min_data_in_leaf; lc.N = N; lc.NS = (N + 15) & ~15ll;
+        n_hnodes = (1 << p.max_depth) - 1;
+        d_node_a.alloc((size_t)K * lc.NS); d_node_b.alloc((size_t)K * lc.NS);
+        d_plan.alloc(K); d_layout.alloc((size_t)K * nchunk); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
+        d_part.alloc((size_t)K * gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
+        d_count.alloc((size_t)K * 256); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
+        for (int level = 1; level < p.max_depth; ++level) {   // worst-case histogram groups of pass `level`
+            const int n_exp = 1 << (level - 1);
+            long long npg = n_exp;
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
+                long long fit = (LV_LDS_BYTES - lv_fixed_bytes(cmeta[ch], n_exp, fm)) / lv_node_bytes(fm, cmeta[ch], 0);
+                if (fit < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
+                npg = std::min(npg, fit);
+            }
+            lv_groups[level] = (int)((n_exp + npg - 1) / npg);
+        }
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+    }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
     DevBuf<double> t_gain(NT * (NL - 1)), t_val(NT * NL);
@@ -402,7 +456,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint8_t> d_used(used.size()); d_used.upload(used.data(), used.size(), s);
 
     // bagging state (GBDT::Bagging): stable training-row order, one LCG per 1024 positions
-    const bool use_bagging = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
     DevBuf<int32_t> d_sorted_rows, d_oob; DevBuf<unsigned int> d_blk, d_rand, d_bagcnt; DevBuf<uint8_t> d_inbag;
     if (use_bagging) {
         const long long nblk = (N + 1023) / 1024;
@@ -420,8 +473,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     }
     const unsigned int* n_in_ptr = use_bagging ? d_bagcnt.p : nullptr;
 
-    if (lds_hist > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
-    if (lds_hist > 160 * 1024) throw std::invalid_argument("histogram working set exceeds LDS");
+    if (!level_mode) {
+        if (lds_hist > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
+        if (lds_hist > 160 * 1024) throw std::invalid_argument("histogram working set exceeds LDS");
+    }
 
     const long long root_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
     const int hist_gx = (int)std::max<long long>(1, std::min<long long>(root_tiles, (1536 + (long long)K * nchunk - 1) / ((long long)K * nchunk)));
@@ -440,6 +495,19 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         if (stats) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
 
+    const int score_gx = (int)std::max<long long>(1, std::min<long long>((N + 1023) / 1024, (2048 + K - 1) / K));
+    const int lv_dbg = getenv("RGBM_LV_DEBUG") ? atoi(getenv("RGBM_LV_DEBUG")) << 8 : 0;
+    auto launch_pass = [&](bool root, int with_hist, int gz) {
+        hipEvent_t a = nullptr, b = nullptr;
+        const bool timed = stats && with_hist;
+        if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
+        if (root) hipLaunchKernelGGL(k_level_pass<true>, dim3(lc.gx, K, gz), dim3(LV_THREADS), LV_LDS_BYTES, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
+                                     (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
+        else hipLaunchKernelGGL(k_level_pass<false>, dim3(lc.gx, K, gz), dim3(LV_THREADS), LV_LDS_BYTES, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
+                                use_bagging ? d_inbag.p : (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
+        if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
+    };
+
     // ---- 5. boosting iterations: everything below is enqueue-only
     for (int it = 0; it < NE; ++it) {
         const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw = sample_weight_host ? d_sw.p : nullptr;
@@ -450,11 +518,30 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((n_train + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, (long long)n_train, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
         }
         const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
-        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, tc);
-        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, tc);
-        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, tc);
-        hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);
+        uint8_t* node0 = level_mode ? d_node_a.p : nullptr;
+        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
         const uint8_t* usedp = d_used.p + (size_t)it * K * F;
+        if (level_mode) {
+            d_count.zero(s);
+            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_fmeta.p, d_cmeta.p, n_in_ptr, (long long)n_train, lc);
+            launch_pass(true, 1, nchunk);
+            hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, d_part.p, d_lpool.p, d_plan.p, d_snodes.p, d_count.p, d_fmeta.p,
+                               usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, lc);
+            for (int level = 1; level <= p.max_depth; ++level) {
+                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
+                const bool with_hist = level < p.max_depth;
+                launch_pass(false, with_hist ? 1 : 0, with_hist ? nchunk * lv_groups[level] : 1);
+                if (with_hist)
+                    hipLaunchKernelGGL(k_level_split<false>, dim3((F + 3) / 4, 1 << (level - 1), K), dim3(256), 0, s, d_part.p, d_lpool.p, d_plan.p, d_snodes.p,
+                                       d_count.p, d_fmeta.p, usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, lc);
+            }
+            hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, to, d_init.p, d_ndelta.p, d_any.p, d_err.p, it, tc);
+            hipLaunchKernelGGL(k_level_score, dim3(score_gx, K), dim3(256), 0, s, d_node_a.p, d_node_b.p, d_plan.p, to, d_ndelta.p, d_score.p, it, lc, K);
+            continue;
+        }
+        hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);
         for (int step = 0; step < NL - 1; ++step) {
             launch_hist(step == 0);
             hipLaunchKernelGGL(k_split_find, dim3((F + 3) / 4, K), dim3(256), 0, s, d_pool.p, d_state.p, d_leaves.p, d_fmeta.p, usedp, d_cand.p, tc);
@@ -477,8 +564,11 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     t_dleft.download(hdleft.data(), hdleft.size(), s); t_left.download(hleft.data(), hleft.size(), s); t_right.download(hright.data(), hright.size(), s);
     t_cnt.download(hcnt.data(), hcnt.size(), s); t_gain.download(hgain.data(), hgain.size(), s); t_val.download(hval.data(), hval.size(), s);
     d_any.download(hany.data(), NE, s);
+    int32_t h_err = 0; unsigned long long h_statrows = 0;
+    if (level_mode) { d_err.download(&h_err, 1, s); d_statrows.download(&h_statrows, 1, s); }
     HIPCHK(hipEventRecord(ev_end, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (h_err) throw std::runtime_error("level grower: a node outside the speculative expansion was selected (expansion bound violated)");
 
     int n_iter = NE;
     for (int it = 0; it < NE; ++it) if (!hany[it]) { n_iter = it > 0 ? it : 1; break; }   // "no more leaves that meet the split requirements"
@@ -501,6 +591,17 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             float m2 = 0.f; HIPCHK(hipEventElapsedTime(&m2, hist_ev[i].first, hist_ev[i].second));
             stats->hist_ms += m2; if (hist_ev_root[i]) stats->root_ms += m2;
             (void)hipEventDestroy(hist_ev[i].first); (void)hipEventDestroy(hist_ev[i].second);
+        }
+        if (level_mode) {
+            // rows whose (g,h) were accumulated: counted on the device (k_level_split); root passes = trees with a searched root
+            int64_t root_rows = 0;
+            const bool root_done = n_train >= (int64_t)p.min_data_in_leaf * 2;
+            for (int it = 0; it < NE; ++it) for (int k = 0; k < K; ++k) { if (root_done && !use_bagging) root_rows += n_train; stats->trees += 1; }
+            if (use_bagging) root_rows = 0;   // bag sizes vary; not tracked separately
+            stats->hist_rows = (int64_t)h_statrows; stats->root_rows = root_rows;
+            stats->hist_bytes = (int64_t)h_statrows * ((int64_t)F + 8);
+            (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
+            return guard.release();
         }
         // rows scanned: root = N per class tree; otherwise the smaller child of every split, which the
         // trees record (leaf_count of both children is known at the end only for final leaves), so

@@ -105,10 +105,16 @@ template <int OBJ>
 __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, const int32_t* __restrict__ ycol,
                                               const double* __restrict__ y_value, const double* __restrict__ class_w,
                                               const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
-                                              int2* __restrict__ gh, TrainConst c) {
+                                              int2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
+                                              long long NS, TrainConst c) {
     const long long N = c.N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const int y = ycol[i];
+        if (node0) {   // every training row restarts in node 0 (the root); all other rows never take part
+            const int KK = (OBJ == 1) ? c.K : 1;
+            const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
+            for (int k = 0; k < KK; ++k) node0[(long long)k * NS + i] = v;
+        }
         if (y < 0) continue;   // not a training row: its gh stays 0 for ever
         if (row_in_bag && !row_in_bag[i]) {   // out of bag this round: contributes nothing to any histogram
             const int K = (OBJ == 1) ? c.K : 1;

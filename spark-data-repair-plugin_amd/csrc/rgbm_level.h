@@ -1,0 +1,658 @@
+// rgbm_level.h -- the level-synchronous ("streaming") tree grower for gfx950.
+//
+// LightGBM grows a tree leaf-wise (best-first).  Re-creating that literally on a GPU means one
+// partition + one small gathered histogram pass per split: 150 dependent launches per boosting
+// iteration, random 16-byte gathers and launch-latency-bound small leaves (measured round 1:
+// k_partition 50 %, k_hist 24 % of the time, profiles/r01a_*).  This grower produces the SAME tree,
+// bit for bit, from at most max_depth+1 fully coalesced streaming passes over the row block:
+//
+//   * every row carries the id of the speculative node it sits in (u8 [K][N], ping-pong);
+//   * pass L routes every row from its depth-(L-1) node to the depth-L child (one byte compare on
+//     the record that is loaded anyway), counts rows per child exactly, and accumulates the
+//     histogram of ONE child per expanded parent (the other is parent - child: sums are exact
+//     integers, so which child is built never changes a bit of the result);
+//   * k_level_split scans both children of every expanded parent (same FindBestThreshold code as
+//     the leaf-wise path);
+//   * k_level_plan decides which nodes of the new level to expand.  A node is expanded unless it
+//     PROVABLY cannot be split by best-first growth: with pm(X) = min gain on the path root..X,
+//     every known node Y with pm(Y) > pm(X) is split before X (induction on the best-first
+//     queue), so X is dead once num_leaves-1 such nodes exist.  Expansion is a superset of the
+//     final tree, never a subset;
+//   * k_level_replay runs LightGBM's best-first selection (ArrayArgs::ArgMax + Tree::Split
+//     numbering) over the speculative nodes and emits the tree in exactly the leaf-wise order.
+//
+// Used when 1 <= max_depth <= 7 and F <= 255 (the reference fixes max_depth = 7, train.py:109);
+// every other configuration takes the leaf-wise path of rgbm_kernels.h.
+//
+// LDS per workgroup (1024 threads, one workgroup per CU): route table | child counters |
+// packed 32+32-bit histogram slots [built node][feature][bin][replica] | 32-bit carry words per
+// bin.  Packed slots are drained every 2048 rows: bits >= 2^11 move to the carry words, so
+// neither field can overflow (2048 * (2^20-1) + 2047 < 2^31, 2048 * (2^21-1) + 2047 < 2^32).
+#pragma once
+#include "rgbm_kernels.h"
+
+namespace rg {
+
+constexpr int LV_INACTIVE = 255;     // node id of rows that do not take part (target cell NULL)
+constexpr int LV_MAX_EXP = 64;       // expanded parents per level (depth <= 6)
+constexpr int LV_MAX_BUILT = 32;     // built children per level (parents of depth <= 5)
+constexpr int LV_CNT_REP = 16;
+constexpr int LV_THREADS = 1024;
+constexpr int LV_TILE = 2048;
+constexpr int LV_LDS_BYTES = 160 * 1024;
+constexpr int LV_CARRY_SHIFT = 11;
+constexpr int LV_MAX_DEPTH = 7;
+constexpr int LV_MAX_LEAVES = 128;
+
+struct SNode {   // speculative node of one class tree
+    long long Gq, Hq;
+    double pmin;                       // min gain on the path root..this node
+    int32_t count, depth, parent, is_left;
+    int32_t left, right;               // child ids, -1 = not expanded
+    int32_t best_feature, searched;
+    int32_t hslot, pad;                // histogram pool slot (-1: depth == max_depth)
+    Cand best;
+};
+
+struct LvPlan {   // per class tree; rewritten by k_level_init / k_level_plan
+    int32_t n_nodes, lvl_first, lvl_end, n_exp, n_built, n_groups, npg, buf, buf_in, done, error, child_first, n_hslots, pad;
+    long long n_in;
+    uint8_t exp[LV_MAX_EXP];           // expanded parents (ascending node id)
+    uint8_t built_is_left[LV_MAX_EXP];
+    uint32_t route0[256];              // feature | (theta+1)<<8 | nanbin<<16 | expanded<<24 | dleft<<25
+    uint32_t route1[256];              // left | right<<8 | left built slot<<16 | right built slot<<24  (0xFF = none)
+};
+
+struct LvLayout {   // per (class tree, chunk): packed-slot layout of the coming pass
+    int32_t spn;                       // packed slots per built node
+    int32_t sh[16], fbase[16];
+};
+
+struct LevelConst {
+    int32_t gx, max_built, nchunk, K, F, totbins, num_leaves, max_depth, min_data_in_leaf, pad;
+    long long N, NS;   // rows; row stride of the node-id arrays (multiple of 16)
+};
+
+__device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
+    uint32_t w = (j < 8) ? ((j < 4) ? r.x : r.y) : ((j < 12) ? r.z : r.w);
+    return (w >> (8 * (j & 3))) & 0xFFu;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed-slot layout for `ng` built nodes of one chunk inside `avail` bytes of LDS
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline int lv_cap_shift(int nbins) { int s = 0; while (s < 5 && (nbins << (s + 1)) <= 256) ++s; return s; }
+
+__host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int s) {
+    int t = 0;
+    for (int j = 0; j < nfeat; ++j) { int cs = lv_cap_shift(fm[j].nbins); t += fm[j].nbins << (s < cs ? s : cs); }
+    return t;
+}
+
+// bytes one built node needs in chunk `cm` at replication cap s (packed slots + carry words + slot->bin map share)
+__host__ __device__ inline long long lv_node_bytes(const FeatMeta* fm, const ChunkMeta& cm, int s) {
+    return (long long)lv_slots(fm, cm.nfeat, s) * 8 + (long long)cm.wide_bins * 8;
+}
+
+__host__ __device__ inline long long lv_fixed_bytes(const ChunkMeta& cm, int n_exp, const FeatMeta* fm) {
+    // route tables + child counters + (wide->slot, wide->hoff) tables + slot->wide map at the largest layout + alignment slack
+    return 2048 + 16 + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + (long long)lv_slots(fm, cm.nfeat, 5) * 2 + 64;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_level_init: per class tree, start of a boosting iteration
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, SNode* __restrict__ nodes,
+                                                   const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
+                                                   const unsigned int* __restrict__ n_in_ptr, long long n_train, LevelConst c) {
+    const int k = blockIdx.x, lane = lane_id();
+    LvPlan* pp = &plan[k];
+    const long long n_in = n_in_ptr ? (long long)n_in_ptr[0] : n_train;
+    for (int i = lane; i < 256; i += 64) { pp->route0[i] = 0; pp->route1[i] = 0xFFFFFFFFu; }
+    if (lane < c.nchunk) {
+        const ChunkMeta cm = cmeta[lane];
+        const FeatMeta* fm = fmeta + cm.first_feat;
+        LvLayout L;
+        const long long avail = LV_LDS_BYTES - lv_fixed_bytes(cm, 0, fm);
+        int s = 5;
+        while (s > 0 && lv_node_bytes(fm, cm, s) > avail) --s;
+        int off = 0;
+        for (int j = 0; j < 16; ++j) {
+            if (j < cm.nfeat) { int cs = lv_cap_shift(fm[j].nbins); L.sh[j] = s < cs ? s : cs; L.fbase[j] = off; off += fm[j].nbins << L.sh[j]; }
+            else { L.sh[j] = 0; L.fbase[j] = 0; }
+        }
+        L.spn = off;
+        layout[(long long)k * c.nchunk + lane] = L;
+    }
+    if (lane == 0) {
+        pp->n_nodes = 1; pp->lvl_first = 0; pp->lvl_end = 1; pp->n_exp = 0; pp->n_built = 1; pp->n_groups = 1; pp->npg = 1;
+        pp->buf = 0; pp->buf_in = 0; pp->error = 0; pp->child_first = 1; pp->n_hslots = 1; pp->n_in = n_in;
+        pp->done = (n_in < (long long)c.min_data_in_leaf * 2) ? 1 : 0;   // BeforeFindBestSplit on the root
+        SNode r; memset(&r, 0, sizeof(r));
+        r.count = (int)n_in; r.depth = 0; r.parent = -1; r.left = -1; r.right = -1; r.best_feature = -1; r.searched = 0; r.hslot = 0;
+        r.best.gain = -INFINITY; r.pmin = -INFINITY;
+        nodes[(long long)k * 256] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_level_pass: THE roofline kernel of this grower.  grid (gx, K, nchunk * groups), block 1024.
+//   ROOT: every active row sits in node 0, whose histogram is built (no routing, no counting).
+//   else: route + count (chunk 0 / group 0 blocks write the new node ids) + histogram of the
+//         built children that belong to this block's group.
+// Algorithmic bytes per accumulated row: F bin bytes + 8 B (g,h); the pass also streams the node
+// ids (1 B in, 1 B out) and the records of rows it only routes.
+// ------------------------------------------------------------------------------------------------
+template <bool ROOT>
+__global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
+                                                           uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
+                                                           const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
+                                                           const LvLayout* __restrict__ layout, HistBin* __restrict__ part,
+                                                           int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta,
+                                                           const ChunkMeta* __restrict__ cmeta, int with_hist, LevelConst c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int k = blockIdx.y, ch = blockIdx.z % c.nchunk, grp = blockIdx.z / c.nchunk;
+    const LvPlan* pp = &plan[k];
+    if (pp->done) return;
+    const int n_exp = ROOT ? 0 : pp->n_exp;
+    const int dbg = with_hist >> 8;   // timing experiments only (RGBM_LV_DEBUG): 1 = no drain, 2 = no atomics, 4 = no count/store
+    with_hist &= 0xFF;
+    const int n_built = with_hist ? pp->n_built : 0;
+    const int npg = pp->npg;
+    const bool writer = !ROOT && ch == 0 && grp == 0;
+    const int g0 = grp * npg;
+    int ng = n_built - g0; if (ng > npg) ng = npg; if (ng < 0) ng = 0;
+    if (grp >= pp->n_groups && !writer) return;
+    if (ng == 0 && !writer) return;
+
+    const ChunkMeta cm = cmeta[ch];
+    const FeatMeta* fm = fmeta + cm.first_feat;
+    const LvLayout lay = layout[(long long)k * c.nchunk + ch];
+    const int spn = lay.spn, wb = cm.wide_bins;
+    const int tid = threadIdx.x, lane = tid & 63;
+
+    // ---- LDS carve-up
+    uint32_t* route0 = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* route1 = route0 + 256;
+    volatile int32_t* drain_flag = reinterpret_cast<volatile int32_t*>(route1 + 256);   // [4] (16 B)
+    int32_t* cnt = reinterpret_cast<int32_t*>(route1 + 256) + 4;
+    const int ncnt = 2 * n_exp * LV_CNT_REP;
+    int32_t* wide_g = cnt + ncnt;
+    uint32_t* wide_h = reinterpret_cast<uint32_t*>(wide_g + (size_t)ng * wb);
+    uint32_t* w_slot = wide_h + (size_t)ng * wb;          // [wb] first packed slot of the bin | sh << 24
+    uint32_t* w_hoff = w_slot + wb;                       // [wb] offset of the bin inside a node histogram
+    uint16_t* s2w = reinterpret_cast<uint16_t*>(w_hoff + wb);   // [spn] packed slot -> carry-word index
+    size_t off = reinterpret_cast<unsigned char*>(s2w + spn) - smem;
+    off = (off + 15) & ~(size_t)15;
+    unsigned long long* fast = reinterpret_cast<unsigned long long*>(smem + off);
+
+    if (!ROOT) for (int i = tid; i < 256; i += LV_THREADS) { route0[i] = pp->route0[i]; route1[i] = pp->route1[i]; }
+    if (tid < 4) drain_flag[tid] = 0;
+    for (int i = tid; i < ncnt; i += LV_THREADS) cnt[i] = 0;
+    for (int i = tid; i < ng * wb; i += LV_THREADS) { wide_g[i] = 0; wide_h[i] = 0u; }
+    for (int i = tid; i < ng * spn; i += LV_THREADS) fast[i] = 0ull;
+    for (int j = 0; j < cm.nfeat; ++j) {
+        const int nb = fm[j].nbins, sh = lay.sh[j], fb = lay.fbase[j], wo = fm[j].wide_off;
+        for (int b = tid; b < nb; b += LV_THREADS) { w_slot[wo + b] = (uint32_t)(fb + (b << sh)) | ((uint32_t)sh << 24); w_hoff[wo + b] = (uint32_t)(fm[j].hoff + b); }
+        for (int s = tid; s < (nb << sh); s += LV_THREADS) s2w[fb + s] = (uint16_t)((wo + (s >> sh)) | (sh > 0 ? 0x8000 : 0));
+    }
+    int fbase[16], fshift[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { fbase[j] = lay.fbase[j]; fshift[j] = lay.sh[j]; }
+    __syncthreads();
+
+    const long long N = c.N;
+    const uint8_t* node_in = (pp->buf_in ? node_b : node_a) + (long long)k * c.NS;
+    uint8_t* node_out = (pp->buf ? node_b : node_a) + (long long)k * c.NS;
+    if (ROOT) node_in = (pp->buf ? node_b : node_a) + (long long)k * c.NS;
+    const uint4* recc = rec + (long long)ch * N;
+    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
+    const int2* ghk = gh + (long long)k * N;
+    const int child_first = pp->child_first;
+    const long long ntiles = (N + LV_TILE - 1) / LV_TILE;
+
+    // Packed-slot overflow control without per-tile barriers.  Every lane keeps the sums of |g| and h it has
+    // added since the last drain; a field of any slot is at most 2047 (drain remainder) + the sum over all 1024
+    // lanes, so it cannot overflow while every lane stays within LB_G / LB_H.  A lane that would exceed its
+    // budget raises the drain flag; waves poll the flag once per row step and rendezvous at a barrier, drain
+    // cooperatively and continue.  Drains are rare for small gradients (multiclass), at worst every 2 rows/lane.
+    constexpr unsigned LB_G = ((1u << 31) - 2048u) / LV_THREADS, LB_H = (unsigned)((((1ull << 32) - 2048ull)) / LV_THREADS);
+    unsigned acc_g = 0, acc_h = 0;
+    auto drain = [&]() {
+        // move the bits above 2^11 of both fields into the per-bin carry words
+        for (int li = 0; li < ng; ++li) {
+            for (int s2 = tid; s2 < spn; s2 += LV_THREADS) {
+                const size_t i = (size_t)li * spn + s2;
+                const unsigned long long v = fast[i];
+                const int g32 = (int)(v >> 32);
+                const unsigned int h32 = (unsigned int)(v & 0xFFFFFFFFull);
+                const int cg = g32 >> LV_CARRY_SHIFT;
+                const unsigned int chh = h32 >> LV_CARRY_SHIFT;
+                if (cg != 0 || chh != 0u) {
+                    fast[i] = ((unsigned long long)(unsigned int)(g32 & ((1 << LV_CARRY_SHIFT) - 1)) << 32) | (unsigned long long)(h32 & ((1u << LV_CARRY_SHIFT) - 1u));
+                    const int sw = (int)s2w[s2];
+                    const int wi = li * wb + (sw & 0x7FFF);
+                    if (sw & 0x8000) { if (cg != 0) atomicAdd(&wide_g[wi], cg); if (chh != 0u) atomicAdd(&wide_h[wi], chh); }
+                    else { wide_g[wi] += cg; wide_h[wi] += chh; }   // un-replicated bin: this thread is its only writer
+                }
+            }
+        }
+    };
+    // every wave that reaches a rendezvous executes exactly: barrier, [flag set: drain, barrier, clear, barrier]
+    auto rendezvous = [&]() -> bool {
+        __syncthreads();
+        if (!drain_flag[0]) return false;
+        drain();
+        __syncthreads();
+        if (tid == 0) drain_flag[0] = 0;
+        __syncthreads();
+        acc_g = 0; acc_h = 0;
+        return true;
+    };
+
+    // Software pipeline: the loads of tile t+gridDim.x are in flight while tile t's LDS atomics run
+    // (one workgroup per CU, so nothing else would hide the HBM latency).
+    constexpr int RPT = LV_TILE / LV_THREADS;
+    int cur_n[RPT], nxt_n[RPT], cur_ib[RPT], nxt_ib[RPT]; uint4 cur_r[RPT], nxt_r[RPT]; int2 cur_g[RPT], nxt_g[RPT];
+    auto fetch = [&](long long t, int (&fn)[RPT], uint4 (&fr)[RPT], int2 (&fg)[RPT], int (&fib)[RPT]) {
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) {
+            const long long row = t * LV_TILE + (long long)s * LV_THREADS + tid;
+            fn[s] = LV_INACTIVE; fib[s] = 1; fr[s] = make_uint4(0, 0, 0, 0); fg[s] = make_int2(0, 0);
+            if (t < ntiles && row < N) {
+                fn[s] = node_in[row]; fr[s] = recc[row]; fg[s] = ghk[row];
+                if (!ROOT && inbag) fib[s] = inbag[row];
+            }
+        }
+    };
+    fetch(blockIdx.x, cur_n, cur_r, cur_g, cur_ib);
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long p0 = t * LV_TILE;
+        fetch(t + gridDim.x, nxt_n, nxt_r, nxt_g, nxt_ib);
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) {
+            const long long row = p0 + (long long)s * LV_THREADS + tid;
+            const int n = (row < N) ? cur_n[s] : LV_INACTIVE;
+            const uint4 r = cur_r[s];
+            const int2 g = cur_g[s];
+            int li = -1;
+            if (n != LV_INACTIVE) {
+                int bs;
+                if (ROOT) bs = 0;
+                else {
+                    int child = n; bs = 0xFF;
+                    const uint32_t w0 = route0[n];
+                    if (w0 & (1u << 24)) {
+                        const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
+                        const int bin = ((f >> 4) == ch) ? (int)rec_byte(r, f & 15) : (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
+                        const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
+                        const uint32_t w1 = route1[n];
+                        child = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
+                        bs = left ? (int)((w1 >> 16) & 0xFFu) : (int)(w1 >> 24);
+                        if (writer && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                    }
+                    if (writer && !(dbg & 4)) node_out[row] = (uint8_t)child;
+                }
+                if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
+            } else if (writer && row < N) node_out[row] = (uint8_t)LV_INACTIVE;
+            const unsigned long long packed = ((unsigned long long)(long long)g.x << 32) + (unsigned long long)(unsigned int)g.y;
+            const bool need = li >= 0 && packed != 0ull && !(dbg & 2);
+            const unsigned ag = (unsigned)(g.x < 0 ? -g.x : g.x), ah = (unsigned)g.y;
+            if (ng > 0) {
+                // poll / raise the drain flag (wave-uniform decisions)
+                const bool over = need && (acc_g + ag > LB_G || acc_h + ah > LB_H);
+                if (__any(over)) { if (lane == 0) drain_flag[0] = 1; rendezvous(); }
+                else if (drain_flag[0]) rendezvous();
+            }
+            if (need) {
+                acc_g += ag; acc_h += ah;
+                unsigned long long* fb = fast + (size_t)li * spn;
+                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j < cm.nfeat) {
+                        const uint32_t bin = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                        const int slot = fbase[j] + (int)(bin << fshift[j]) + (lane & ((1 << fshift[j]) - 1));
+                        atomicAdd(&fb[slot], packed);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) { cur_n[s] = nxt_n[s]; cur_r[s] = nxt_r[s]; cur_g[s] = nxt_g[s]; cur_ib[s] = nxt_ib[s]; }
+    }
+    // epilogue rendezvous: leave only when every wave has finished its rows and no drain is pending
+    if (ng > 0) { while (rendezvous()) {} } else __syncthreads();
+    // ---- flush this workgroup's partial histograms (plain stores: no global atomics, no zeroing)
+    for (int li = 0; li < ng; ++li) {
+        HistBin* dst = part + (((long long)k * c.gx + blockIdx.x) * c.max_built + (g0 + li)) * c.totbins;
+        for (int b = tid; b < wb; b += LV_THREADS) {
+            const uint32_t ws = w_slot[b];
+            const int sh = (int)(ws >> 24), s0 = (int)(ws & 0xFFFFFFu);
+            long long tg = (long long)wide_g[li * wb + b] << LV_CARRY_SHIFT;
+            long long th = (long long)(unsigned long long)wide_h[li * wb + b] << LV_CARRY_SHIFT;
+            const unsigned long long* fb = fast + (size_t)li * spn + s0;
+            for (int r2 = 0; r2 < (1 << sh); ++r2) { const unsigned long long v = fb[r2]; tg += (long long)(int)(v >> 32); th += (long long)(unsigned int)(v & 0xFFFFFFFFull); }
+            HistBin o; o.g = tg; o.h = th;
+            dst[w_hoff[b]] = o;
+        }
+    }
+    if (writer) {
+        for (int ci = tid; ci < 2 * n_exp; ci += LV_THREADS) {
+            int tot = 0;
+            for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
+            if (tot) atomicAdd(&count[(long long)k * 256 + child_first + ci], tot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_level_split: sum the workgroup partials of the built child, derive the sibling by subtraction,
+// scan both (FindBestThreshold).  grid (ceil(F/4), ROOT ? 1 : max parents, K), block 256.
+// ------------------------------------------------------------------------------------------------
+template <bool ROOT>
+__global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__ part, HistBin* __restrict__ pool, LvPlan* __restrict__ plan,
+                                                     SNode* __restrict__ nodes, const int32_t* __restrict__ count,
+                                                     const FeatMeta* __restrict__ fmeta, const uint8_t* __restrict__ used /* [K][F] */,
+                                                     Cand* __restrict__ cand /* [K][256][F] */, unsigned long long* __restrict__ stat_rows,
+                                                     int n_hnodes, TrainConst c, LevelConst lc) {
+    const int k = blockIdx.z, pi = blockIdx.y;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const LvPlan* pp = &plan[k];
+    if (pp->done) return;
+    if (!ROOT && pi >= pp->n_exp) return;
+    if (f >= c.F) return;
+    const int lane = lane_id();
+    const FeatMeta fm = fmeta[f];
+    SNode* nk = nodes + (long long)k * 256;
+    Cand* ck = cand + (long long)k * 256 * c.F;
+    HistBin* pk = pool + (long long)k * n_hnodes * c.totbins;
+    const bool is_used = used[(long long)k * c.F + f] != 0;
+    long long ag[4], ah[4];
+    const int bslot = ROOT ? 0 : pi;
+    // built child = sum of the gx workgroup partials
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ag[j] = 0; ah[j] = 0; }
+    for (int x = 0; x < lc.gx; ++x) {
+        const HistBin* src = part + (((long long)k * lc.gx + x) * lc.max_built + bslot) * c.totbins + fm.hoff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int b = lane * 4 + j; if (b < fm.nbins) { const HistBin v = src[b]; ag[j] += v.g; ah[j] += v.h; } }
+    }
+    if (ROOT) {
+        HistBin* h0 = pk + fm.hoff;
+        long long sg_ = 0, sh_ = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int b = lane * 4 + j; if (b < fm.nbins) { HistBin v; v.g = ag[j]; v.h = ah[j]; h0[b] = v; } sg_ += ag[j]; sh_ += ah[j]; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { sg_ += __shfl_xor(sg_, o); sh_ += __shfl_xor(sh_, o); }
+        if (f == 0 && lane == 0) { nk[0].Gq = sg_; nk[0].Hq = sh_; nk[0].searched = 1; atomicAdd(stat_rows, (unsigned long long)pp->n_in); }
+        if (!is_used) { if (lane == 0) ck[f].gain = -INFINITY; return; }
+        scan_child(ag, ah, fm, sg_, sh_, pp->n_in, c, &ck[f]);
+        return;
+    }
+    const int p = pp->exp[pi];
+    const SNode P = nk[p];
+    const int l = P.left, r = P.right;
+    const bool bl = pp->built_is_left[pi] != 0;
+    const int hs_l = nk[l].hslot, hs_r = nk[r].hslot;
+    const HistBin* hp = pk + (long long)P.hslot * c.totbins + fm.hoff;
+    HistBin* hl = pk + (long long)hs_l * c.totbins + fm.hoff;
+    HistBin* hr = pk + (long long)hs_r * c.totbins + fm.hoff;
+    long long bg[4], bh[4];   // the sibling
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = lane * 4 + j;
+        if (b < fm.nbins) {
+            const HistBin par = hp[b];
+            bg[j] = par.g - ag[j]; bh[j] = par.h - ah[j];
+            HistBin built, sib; built.g = ag[j]; built.h = ah[j]; sib.g = bg[j]; sib.h = bh[j];
+            if (bl) { hl[b] = built; hr[b] = sib; } else { hr[b] = built; hl[b] = sib; }
+        } else { bg[j] = 0; bh[j] = 0; }
+    }
+    const int nl = count[(long long)k * 256 + l], nr = count[(long long)k * 256 + r];
+    // SerialTreeLearner::BeforeFindBestSplit: both children too small -> neither is searched
+    const bool go = !(nr < c.min_data_in_leaf * 2 && nl < c.min_data_in_leaf * 2);
+    if (f == 0 && lane == 0) {
+        nk[l].count = nl; nk[r].count = nr; nk[l].searched = go ? 1 : 0; nk[r].searched = go ? 1 : 0;
+        atomicAdd(stat_rows, (unsigned long long)(bl ? nl : nr));
+    }
+    if (!go) return;
+    if (!is_used) { if (lane == 0) { ck[(long long)l * c.F + f].gain = -INFINITY; ck[(long long)r * c.F + f].gain = -INFINITY; } return; }
+    const long long lGq = P.best.left_gq, lHq = P.best.left_hq;
+    if (bl) {
+        scan_child(ag, ah, fm, lGq, lHq, (long long)nl, c, &ck[(long long)l * c.F + f]);
+        scan_child(bg, bh, fm, P.Gq - lGq, P.Hq - lHq, (long long)nr, c, &ck[(long long)r * c.F + f]);
+    } else {
+        scan_child(bg, bh, fm, lGq, lHq, (long long)nl, c, &ck[(long long)l * c.F + f]);
+        scan_child(ag, ah, fm, P.Gq - lGq, P.Hq - lHq, (long long)nr, c, &ck[(long long)r * c.F + f]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_level_plan: one wave per class tree, before pass `level` (which routes depth level-1 -> level).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_level_plan(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, SNode* __restrict__ nodes,
+                                                   const Cand* __restrict__ cand, const FeatMeta* __restrict__ fmeta,
+                                                   const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc) {
+    __shared__ double pm[256];
+    const int k = blockIdx.x, lane = lane_id();
+    LvPlan* pp = &plan[k];
+    if (pp->done) return;
+    SNode* nk = nodes + (long long)k * 256;
+    const Cand* ck = cand + (long long)k * 256 * c.F;
+    const int first = pp->lvl_first, end = pp->lvl_end, nlev = end - first;   // nodes of depth level-1 (<= 64)
+    // 1. best split of every node of the level (SplitInfo::operator>: gain, then smaller feature)
+    for (int n = first; n < end; ++n) {
+        if (!nk[n].searched) { if (lane == 0) { nk[n].best.gain = -INFINITY; nk[n].best_feature = -1; } continue; }
+        const Cand* cf = ck + (long long)n * c.F;
+        double bg = -INFINITY; int bf = -1;
+        for (int f = lane; f < c.F; f += 64) { const double g = cf[f].gain; if (g > -INFINITY && leaf_better(g, f, 0, bg, bf, 0)) { bg = g; bf = f; } }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const double g2 = __shfl_xor(bg, o); const int f2 = __shfl_xor(bf, o); if (leaf_better(g2, f2, 0, bg, bf, 0)) { bg = g2; bf = f2; } }
+        if (lane == 0) {
+            if (bf >= 0) { nk[n].best = cf[bf]; nk[n].best_feature = bf; } else { nk[n].best.gain = -INFINITY; nk[n].best_feature = -1; }
+        }
+    }
+    __syncthreads();
+    // 2. path-min gains
+    for (int n = lane; n < first; n += 64) pm[n] = nk[n].pmin;
+    __syncthreads();
+    if (lane < nlev) {
+        const int n = first + lane;
+        const double g = nk[n].best.gain;
+        const int par = nk[n].parent;
+        double v = g;
+        if (par >= 0) { const double pv = pm[par]; v = (pv < g) ? pv : g; }
+        if (!(g > -INFINITY)) v = -INFINITY;
+        pm[n] = v; nk[n].pmin = v;
+    }
+    __syncthreads();
+    // 3. expansion test: X is dead once num_leaves-1 known nodes are split before it
+    bool expand = false;
+    if (lane < nlev) {
+        const double v = pm[first + lane];
+        if (v > 0.0) {
+            int rank = 0;
+            for (int y = 0; y < end; ++y) rank += (pm[y] > v) ? 1 : 0;
+            expand = rank < c.num_leaves - 1;
+        }
+    }
+    const unsigned long long em = __ballot(expand);
+    const int n_exp = __popcll(em);
+    for (int i = lane; i < 256; i += 64) { pp->route0[i] = 0; pp->route1[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    if (n_exp == 0) { if (lane == 0) { pp->done = 1; pp->n_exp = 0; pp->n_built = 0; } return; }
+    const int child_first = pp->n_nodes;
+    const bool with_hist = level < c.max_depth;   // children of depth max_depth are never searched
+    const int hs0 = pp->n_hslots;
+    if (expand) {
+        const int ei = __popcll(em & ((1ull << lane) - 1ull));
+        const int n = first + lane;
+        const SNode P = nk[n];
+        const int l = child_first + 2 * ei, r = l + 1;
+        const int f = P.best_feature;
+        // hessian-estimated smaller child is the one whose histogram is built
+        const bool built_left = P.best.left_hq * 2 <= P.Hq;
+        nk[n].left = l; nk[n].right = r;
+        SNode L; memset(&L, 0, sizeof(L));
+        L.depth = P.depth + 1; L.parent = n; L.left = -1; L.right = -1; L.best_feature = -1; L.searched = 0; L.best.gain = -INFINITY; L.pmin = -INFINITY;
+        SNode R = L;
+        L.is_left = 1; L.Gq = P.best.left_gq; L.Hq = P.best.left_hq; L.hslot = with_hist ? hs0 + 2 * ei : -1;
+        R.is_left = 0; R.Gq = P.Gq - P.best.left_gq; R.Hq = P.Hq - P.best.left_hq; R.hslot = with_hist ? hs0 + 2 * ei + 1 : -1;
+        nk[l] = L; nk[r] = R;
+        pp->exp[ei] = (uint8_t)n; pp->built_is_left[ei] = built_left ? 1 : 0;
+        const int nanbin = fmeta[f].has_nan ? fmeta[f].V : 255;
+        pp->route0[n] = (uint32_t)f | ((uint32_t)(P.best.theta + 1) & 0xFFu) << 8 | (uint32_t)nanbin << 16 | 1u << 24 | (uint32_t)(P.best.dleft ? 1 : 0) << 25;
+        const uint32_t ls = with_hist && built_left ? (uint32_t)ei : 0xFFu, rs = with_hist && !built_left ? (uint32_t)ei : 0xFFu;
+        pp->route1[n] = (uint32_t)l | (uint32_t)r << 8 | ls << 16 | rs << 24;
+    }
+    // 4. LDS layout of the pass
+    const int n_built = with_hist ? n_exp : 0;
+    int npg = 1, n_groups = 1;
+    if (n_built > 0) {
+        npg = n_built;
+        for (int chn = 0; chn < c.nchunk; ++chn) {
+            const ChunkMeta cm = cmeta[chn]; const FeatMeta* fm = fmeta + cm.first_feat;
+            const long long avail = LV_LDS_BYTES - lv_fixed_bytes(cm, n_exp, fm);
+            long long fit = avail / lv_node_bytes(fm, cm, 0);
+            if (fit < 1) fit = 1;
+            if (fit < npg) npg = (int)fit;
+        }
+        n_groups = (n_built + npg - 1) / npg;
+    }
+    if (lane < c.nchunk) {
+        const ChunkMeta cm = cmeta[lane]; const FeatMeta* fm = fmeta + cm.first_feat;
+        const long long avail = LV_LDS_BYTES - lv_fixed_bytes(cm, n_exp, fm);
+        int s = 5;
+        while (s > 0 && (long long)npg * lv_node_bytes(fm, cm, s) > avail) --s;
+        LvLayout L;
+        int off = 0;
+        for (int j = 0; j < 16; ++j) {
+            if (j < cm.nfeat) { int cs = lv_cap_shift(fm[j].nbins); L.sh[j] = s < cs ? s : cs; L.fbase[j] = off; off += fm[j].nbins << L.sh[j]; }
+            else { L.sh[j] = 0; L.fbase[j] = 0; }
+        }
+        L.spn = off;
+        layout[(long long)k * c.nchunk + lane] = L;
+    }
+    if (lane == 0) {
+        pp->n_exp = n_exp; pp->n_built = n_built; pp->npg = npg; pp->n_groups = n_groups;
+        pp->child_first = child_first; pp->n_nodes = child_first + 2 * n_exp;
+        pp->lvl_first = child_first; pp->lvl_end = child_first + 2 * n_exp;
+        if (with_hist) pp->n_hslots = hs0 + 2 * n_exp;
+        pp->buf_in = pp->buf; pp->buf = 1 - pp->buf;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_level_replay: LightGBM's best-first growth replayed over the speculative nodes; emits the
+// tree (Tree::Split numbering), applies Shrinkage / AddBias, and the node -> score-delta table.
+// One wave per class tree.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, const SNode* __restrict__ nodes, const int32_t* __restrict__ count,
+                                                     TreeOut out, const double* __restrict__ init, double* __restrict__ node_delta /* [K][256] */,
+                                                     int32_t* __restrict__ any_split, int32_t* __restrict__ err_flag, int it, TrainConst c) {
+    __shared__ int leaf_node[LV_MAX_LEAVES], leaf_parent[LV_MAX_LEAVES], leaf_isleft[LV_MAX_LEAVES];
+    __shared__ int node_leaf[256];
+    __shared__ double upd[LV_MAX_LEAVES];
+    const int k = blockIdx.x, lane = lane_id();
+    LvPlan* pp = &plan[k];
+    const SNode* nk = nodes + (long long)k * 256;
+    const long long tbase = (long long)it * c.K + k;
+    const long long nb = tbase * (c.num_leaves - 1);
+    double* lv = out.leaf_value + tbase * c.num_leaves;
+    int32_t* lc = out.leaf_count + tbase * c.num_leaves;
+    const int n_nodes = pp->n_nodes;
+    for (int i = lane; i < 256; i += 64) node_leaf[i] = -1;
+    if (lane == 0) { leaf_node[0] = 0; leaf_parent[0] = -1; leaf_isleft[0] = 0; node_leaf[0] = 0; lc[0] = (int)pp->n_in; }
+    __syncthreads();
+    int L = 1;
+    const int max_leaves = c.num_leaves < LV_MAX_LEAVES ? c.num_leaves : LV_MAX_LEAVES;
+    while (L < max_leaves) {
+        double bg = -INFINITY; int bf = -1, bl = 0x7FFFFFFF;
+        for (int l = lane; l < L; l += 64) {
+            const SNode& s = nk[leaf_node[l]];
+            const double g = s.searched ? s.best.gain : -INFINITY; const int f = s.searched ? s.best_feature : -1;
+            if (bl == 0x7FFFFFFF || leaf_better(g, f, l, bg, bf, bl)) { bg = g; bf = f; bl = l; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double g2 = __shfl_xor(bg, o); const int f2 = __shfl_xor(bf, o), l2 = __shfl_xor(bl, o);
+            if (l2 != 0x7FFFFFFF && (bl == 0x7FFFFFFF || leaf_better(g2, f2, l2, bg, bf, bl))) { bg = g2; bf = f2; bl = l2; }
+        }
+        if (!(bg > 0.0)) break;
+        const int sn = leaf_node[bl];
+        const SNode S = nk[sn];
+        if (S.left < 0) { if (lane == 0) { pp->error = 1; atomicOr(err_flag, 1); } break; }   // the expansion bound was violated (must never happen)
+        const int node = L - 1, right_leaf = L;
+        if (lane == 0) {
+            out.feat[nb + node] = bf; out.theta[nb + node] = S.best.theta; out.dleft[nb + node] = S.best.dleft; out.gain[nb + node] = S.best.gain;
+            out.left[nb + node] = ~bl; out.right[nb + node] = ~right_leaf;
+            const int pn = leaf_parent[bl];
+            if (pn >= 0) { if (leaf_isleft[bl]) out.left[nb + pn] = node; else out.right[nb + pn] = node; }
+            lv[bl] = S.best.left_out; lv[right_leaf] = S.best.right_out;
+            lc[bl] = count[(long long)k * 256 + S.left]; lc[right_leaf] = count[(long long)k * 256 + S.right];
+            leaf_node[bl] = S.left; leaf_node[right_leaf] = S.right;
+            leaf_parent[bl] = node; leaf_isleft[bl] = 1; leaf_parent[right_leaf] = node; leaf_isleft[right_leaf] = 0;
+            node_leaf[S.left] = bl; node_leaf[S.right] = right_leaf;
+        }
+        ++L;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (lane == 0) out.L[tbase] = L;
+    double* nd = node_delta + (long long)k * 256;
+    if (L <= 1) {
+        if (lane == 0) lv[0] = (it == 0) ? init[k] : 0.0;
+        for (int i = lane; i < 256; i += 64) nd[i] = 0.0;
+        return;
+    }
+    if (lane == 0) atomicOr(any_split + it, 1);
+    for (int l = lane; l < L; l += 64) {
+        double v = lv[l] * c.learning_rate;    // Tree::Shrinkage
+        upd[l] = v;
+        if (it == 0 && fabs(init[k]) > k_eps()) v += init[k];   // Tree::AddBias (model only; scores already hold init)
+        lv[l] = v;
+    }
+    __syncthreads();
+    // rows that sit below a final leaf (speculative descendants) inherit that leaf
+    for (int n = lane; n < 256; n += 64) {
+        double d = 0.0;
+        if (n < n_nodes) {
+            int a = n;
+            while (a >= 0 && node_leaf[a] < 0) a = nk[a].parent;
+            // a split node's own entry is overwritten by its children only when it was split in the final tree;
+            // node_leaf of a split node still names the leaf index its LEFT child inherited, so walk DOWN is never needed:
+            // rows only ever sit in the deepest expanded node, whose nearest assigned ancestor-or-self is a final leaf.
+            if (a >= 0) d = upd[node_leaf[a]];
+        }
+        nd[n] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_level_score: ScoreUpdater::AddScore through the final node ids (fully coalesced).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_score(const uint8_t* __restrict__ node_a, const uint8_t* __restrict__ node_b, const LvPlan* __restrict__ plan,
+                                                     const TreeOut out, const double* __restrict__ node_delta, double* __restrict__ score, int it, LevelConst c, int K) {
+    __shared__ double nd[256];
+    const int k = blockIdx.y;
+    if (out.L[(long long)it * K + k] <= 1) return;
+    nd[threadIdx.x] = node_delta[(long long)k * 256 + threadIdx.x];
+    __syncthreads();
+    const long long N = c.N;
+    const uint8_t* node = (plan[k].buf ? node_b : node_a) + (long long)k * c.NS;
+    double* sk = score + (long long)k * N;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < N; i += (long long)gridDim.x * 1024) {
+        if (i + 3 < N) {
+            const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
+            if (n4 != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int n = (n4 >> (8 * j)) & 0xFF; if (n != LV_INACTIVE) sk[i + j] += nd[n]; }
+            }
+        } else {
+            for (long long r = i; r < N; ++r) { const int n = node[r]; if (n != LV_INACTIVE) sk[r] += nd[n]; }
+        }
+    }
+}
+
+}  // namespace rg
