@@ -389,21 +389,24 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     // level grower state
     LevelConst lc; memset(&lc, 0, sizeof(lc));
     DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
-    DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_err; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
+    DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_err, d_leafnode; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
     std::vector<int> lv_groups(LV_MAX_DEPTH + 1, 1);
     if (level_mode) {
         const long long ntiles = (N + LV_TILE - 1) / LV_TILE;
         // workgroups per (class tree, chunk): one 1024-thread workgroup per CU; pick the count that fills whole
         // rounds of 256 CUs best, with <= 2^22 rows per workgroup (32-bit carry words) and >= 1 tile each
+        lc.lds_bytes = LV_LDS_BYTES;
+        if (const char* e = getenv("RGBM_LV_LDS")) { int v = atoi(e); if (v >= 16384 && v <= LV_LDS_BYTES) lc.lds_bytes = v; }
+        const long long cu_slots = 256ll * std::max(1, std::min(2, LV_LDS_BYTES / lc.lds_bytes));   // resident workgroups
         const long long per = (long long)K * nchunk;
         long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
         long long gx = gmin; double best_eff = -1.0;
         for (long long g = gmin; g < gmin + 512 && g <= std::max(gmin, ntiles); ++g) {
-            const long long tot = g * per, rounds = (tot + 255) / 256;
-            const double eff = (double)tot / (double)(rounds * 256);
+            const long long tot = g * per, rounds = (tot + cu_slots - 1) / cu_slots;
+            const double eff = (double)tot / (double)(rounds * cu_slots);
             if (eff > best_eff + 1e-9) { best_eff = eff; gx = g; }
-            if (tot >= 256 && eff >= 0.999) break;
+            if (tot >= cu_slots && eff >= 0.999) break;
         }
         gx = std::min<long long>(gx, std::max<long long>(gmin, ntiles));
         lc.gx = (int)gx; lc.max_built = 1 << std::max(0, p.max_depth - 2); lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
@@ -412,13 +415,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         d_node_a.alloc((size_t)K * lc.NS); d_node_b.alloc((size_t)K * lc.NS);
         d_plan.alloc(K); d_layout.alloc((size_t)K * nchunk); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
         d_part.alloc((size_t)K * gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
-        d_count.alloc((size_t)K * 256); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
+        d_count.alloc((size_t)K * 256); d_leafnode.alloc((size_t)K * LV_MAX_LEAVES); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
         for (int level = 1; level < p.max_depth; ++level) {   // worst-case histogram groups of pass `level`
             const int n_exp = 1 << (level - 1);
             long long npg = n_exp;
             for (int ch = 0; ch < nchunk; ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
-                long long fit = (LV_LDS_BYTES - lv_fixed_bytes(cmeta[ch], n_exp, fm)) / lv_node_bytes(fm, cmeta[ch], 0);
+                long long fit = (lc.lds_bytes - lv_fixed_bytes(cmeta[ch], n_exp, fm)) / lv_node_bytes(fm, cmeta[ch], 0);
                 if (fit < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
                 npg = std::min(npg, fit);
             }
@@ -501,9 +504,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         hipEvent_t a = nullptr, b = nullptr;
         const bool timed = stats && with_hist;
         if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
-        if (root) hipLaunchKernelGGL(k_level_pass<true>, dim3(lc.gx, K, gz), dim3(LV_THREADS), LV_LDS_BYTES, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
+        if (root) hipLaunchKernelGGL(k_level_pass<true>, dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
                                      (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
-        else hipLaunchKernelGGL(k_level_pass<false>, dim3(lc.gx, K, gz), dim3(LV_THREADS), LV_LDS_BYTES, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
+        else hipLaunchKernelGGL(k_level_pass<false>, dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
                                 use_bagging ? d_inbag.p : (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
         if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
@@ -529,16 +532,18 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             launch_pass(true, 1, nchunk);
             hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, d_part.p, d_lpool.p, d_plan.p, d_snodes.p, d_count.p, d_fmeta.p,
                                usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, lc);
-            for (int level = 1; level <= p.max_depth; ++level) {
+            for (int level = 1; level < p.max_depth; ++level) {
                 hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
-                const bool with_hist = level < p.max_depth;
-                launch_pass(false, with_hist ? 1 : 0, with_hist ? nchunk * lv_groups[level] : 1);
-                if (with_hist)
-                    hipLaunchKernelGGL(k_level_split<false>, dim3((F + 3) / 4, 1 << (level - 1), K), dim3(256), 0, s, d_part.p, d_lpool.p, d_plan.p, d_snodes.p,
-                                       d_count.p, d_fmeta.p, usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, lc);
+                launch_pass(false, 1, nchunk * lv_groups[level]);
+                hipLaunchKernelGGL(k_level_split<false>, dim3((F + 3) / 4, 1 << (level - 1), K), dim3(256), 0, s, d_part.p, d_lpool.p, d_plan.p, d_snodes.p,
+                                   d_count.p, d_fmeta.p, usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, lc);
             }
-            hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, to, d_init.p, d_ndelta.p, d_any.p, d_err.p, it, tc);
-            hipLaunchKernelGGL(k_level_score, dim3(score_gx, K), dim3(256), 0, s, d_node_a.p, d_node_b.p, d_plan.p, to, d_ndelta.p, d_score.p, it, lc, K);
+            // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
+            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
+            hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, it, tc);
+            hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
+                               d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, it, lc);
+            hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, d_count.p, d_leafnode.p, to, it, tc);
             continue;
         }
         hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);

@@ -69,7 +69,7 @@ struct LvLayout {   // per (class tree, chunk): packed-slot layout of the coming
 };
 
 struct LevelConst {
-    int32_t gx, max_built, nchunk, K, F, totbins, num_leaves, max_depth, min_data_in_leaf, pad;
+    int32_t gx, max_built, nchunk, K, F, totbins, num_leaves, max_depth, min_data_in_leaf, lds_bytes;
     long long N, NS;   // rows; row stride of the node-id arrays (multiple of 16)
 };
 
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
         const ChunkMeta cm = cmeta[lane];
         const FeatMeta* fm = fmeta + cm.first_feat;
         LvLayout L;
-        const long long avail = LV_LDS_BYTES - lv_fixed_bytes(cm, 0, fm);
+        const long long avail = c.lds_bytes - lv_fixed_bytes(cm, 0, fm);
         int s = 5;
         while (s > 0 && lv_node_bytes(fm, cm, s) > avail) --s;
         int off = 0;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64) void k_level_plan(LvPlan* __restrict__ plan, Lv
         npg = n_built;
         for (int chn = 0; chn < c.nchunk; ++chn) {
             const ChunkMeta cm = cmeta[chn]; const FeatMeta* fm = fmeta + cm.first_feat;
-            const long long avail = LV_LDS_BYTES - lv_fixed_bytes(cm, n_exp, fm);
+            const long long avail = lc.lds_bytes - lv_fixed_bytes(cm, n_exp, fm);
             long long fit = avail / lv_node_bytes(fm, cm, 0);
             if (fit < 1) fit = 1;
             if (fit < npg) npg = (int)fit;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void k_level_plan(LvPlan* __restrict__ plan, Lv
     }
     if (lane < c.nchunk) {
         const ChunkMeta cm = cmeta[lane]; const FeatMeta* fm = fmeta + cm.first_feat;
-        const long long avail = LV_LDS_BYTES - lv_fixed_bytes(cm, n_exp, fm);
+        const long long avail = lc.lds_bytes - lv_fixed_bytes(cm, n_exp, fm);
         int s = 5;
         while (s > 0 && (long long)npg * lv_node_bytes(fm, cm, s) > avail) --s;
         LvLayout L;
@@ -550,6 +550,7 @@ __global__ __launch_bounds__(64) void k_level_plan(LvPlan* __restrict__ plan, Lv
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, const SNode* __restrict__ nodes, const int32_t* __restrict__ count,
                                                      TreeOut out, const double* __restrict__ init, double* __restrict__ node_delta /* [K][256] */,
+                                                     int32_t* __restrict__ leaf_node_out /* [K][LV_MAX_LEAVES] */,
                                                      int32_t* __restrict__ any_split, int32_t* __restrict__ err_flag, int it, TrainConst c) {
     __shared__ int leaf_node[LV_MAX_LEAVES], leaf_parent[LV_MAX_LEAVES], leaf_isleft[LV_MAX_LEAVES];
     __shared__ int node_leaf[256];
@@ -560,10 +561,9 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
     const long long tbase = (long long)it * c.K + k;
     const long long nb = tbase * (c.num_leaves - 1);
     double* lv = out.leaf_value + tbase * c.num_leaves;
-    int32_t* lc = out.leaf_count + tbase * c.num_leaves;
     const int n_nodes = pp->n_nodes;
     for (int i = lane; i < 256; i += 64) node_leaf[i] = -1;
-    if (lane == 0) { leaf_node[0] = 0; leaf_parent[0] = -1; leaf_isleft[0] = 0; node_leaf[0] = 0; lc[0] = (int)pp->n_in; }
+    if (lane == 0) { leaf_node[0] = 0; leaf_parent[0] = -1; leaf_isleft[0] = 0; node_leaf[0] = 0; }
     __syncthreads();
     int L = 1;
     const int max_leaves = c.num_leaves < LV_MAX_LEAVES ? c.num_leaves : LV_MAX_LEAVES;
@@ -590,7 +590,6 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
             const int pn = leaf_parent[bl];
             if (pn >= 0) { if (leaf_isleft[bl]) out.left[nb + pn] = node; else out.right[nb + pn] = node; }
             lv[bl] = S.best.left_out; lv[right_leaf] = S.best.right_out;
-            lc[bl] = count[(long long)k * 256 + S.left]; lc[right_leaf] = count[(long long)k * 256 + S.right];
             leaf_node[bl] = S.left; leaf_node[right_leaf] = S.right;
             leaf_parent[bl] = node; leaf_isleft[bl] = 1; leaf_parent[right_leaf] = node; leaf_isleft[right_leaf] = 0;
             node_leaf[S.left] = bl; node_leaf[S.right] = right_leaf;
@@ -600,6 +599,7 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
     }
     __syncthreads();
     if (lane == 0) out.L[tbase] = L;
+    for (int l = lane; l < L; l += 64) leaf_node_out[(long long)k * LV_MAX_LEAVES + l] = leaf_node[l];   // leaf counts follow after the final pass
     double* nd = node_delta + (long long)k * 256;
     if (L <= 1) {
         if (lane == 0) lv[0] = (it == 0) ? init[k] : 0.0;
@@ -630,29 +630,70 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_level_score: ScoreUpdater::AddScore through the final node ids (fully coalesced).
+// k_level_final: the last routing step (depth max_depth-1 -> max_depth, no histogram), the exact
+// row counts of the deepest children and ScoreUpdater::AddScore in ONE streaming pass: every
+// training row ends in its final speculative node, whose score delta the replay has tabulated.
+// grid (gx, K), block 256, 4 rows per thread.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_level_score(const uint8_t* __restrict__ node_a, const uint8_t* __restrict__ node_b, const LvPlan* __restrict__ plan,
-                                                     const TreeOut out, const double* __restrict__ node_delta, double* __restrict__ score, int it, LevelConst c, int K) {
+__global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ rec, const uint8_t* __restrict__ node_a, const uint8_t* __restrict__ node_b,
+                                                     const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, const TreeOut out,
+                                                     const double* __restrict__ node_delta, double* __restrict__ score, int32_t* __restrict__ count,
+                                                     int it, LevelConst c) {
     __shared__ double nd[256];
+    __shared__ uint32_t route0[256], route1[256];
+    __shared__ int32_t cnt[2 * LV_MAX_EXP * LV_CNT_REP];
     const int k = blockIdx.y;
-    if (out.L[(long long)it * K + k] <= 1) return;
-    nd[threadIdx.x] = node_delta[(long long)k * 256 + threadIdx.x];
+    if (out.L[(long long)it * c.K + k] <= 1) return;   // no split: no score change, nothing to count
+    const LvPlan* pp = &plan[k];
+    const bool route = !pp->done;                      // plan(max_depth) expanded at least one node
+    const int n_exp = route ? pp->n_exp : 0, child_first = pp->child_first;
+    const int tid = threadIdx.x, lane = tid & 63;
+    nd[tid] = node_delta[(long long)k * 256 + tid];
+    route0[tid] = route ? pp->route0[tid] : 0u; route1[tid] = pp->route1[tid];
+    for (int i = tid; i < 2 * n_exp * LV_CNT_REP; i += 256) cnt[i] = 0;
     __syncthreads();
     const long long N = c.N;
-    const uint8_t* node = (plan[k].buf ? node_b : node_a) + (long long)k * c.NS;
+    const uint8_t* node = ((route ? pp->buf_in : pp->buf) ? node_b : node_a) + (long long)k * c.NS;
+    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
     double* sk = score + (long long)k * N;
-    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < N; i += (long long)gridDim.x * 1024) {
-        if (i + 3 < N) {
-            const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
-            if (n4 != 0xFFFFFFFFu) {
+    for (long long i = ((long long)blockIdx.x * 256 + tid) * 4; i < N; i += (long long)gridDim.x * 1024) {
+        const uint32_t n4 = (i + 3 < N) ? *reinterpret_cast<const uint32_t*>(node + i)
+                                        : ((uint32_t)node[i] | (i + 1 < N ? (uint32_t)node[i + 1] << 8 : 0xFF00u) | (i + 2 < N ? (uint32_t)node[i + 2] << 16 : 0xFF0000u) | 0xFF000000u);
+        if (n4 == 0xFFFFFFFFu) continue;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const int n = (n4 >> (8 * j)) & 0xFF; if (n != LV_INACTIVE) sk[i + j] += nd[n]; }
+        for (int j = 0; j < 4; ++j) {
+            int n = (int)((n4 >> (8 * j)) & 0xFFu);
+            if (n == LV_INACTIVE) continue;
+            const long long row = i + j;
+            const uint32_t w0 = route0[n];
+            if (w0 & (1u << 24)) {
+                const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
+                const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
+                const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
+                const uint32_t w1 = route1[n];
+                n = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
+                if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
             }
-        } else {
-            for (long long r = i; r < N; ++r) { const int n = node[r]; if (n != LV_INACTIVE) sk[r] += nd[n]; }
+            sk[row] += nd[n];
         }
     }
+    __syncthreads();
+    for (int ci = tid; ci < 2 * n_exp; ci += 256) {
+        int tot = 0;
+        for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
+        if (tot) atomicAdd(&count[(long long)k * 256 + child_first + ci], tot);
+    }
+}
+
+// leaf counts of the finished tree (Tree::leaf_count_), once every child count is final
+__global__ __launch_bounds__(LV_MAX_LEAVES) void k_level_leafcount(const LvPlan* __restrict__ plan, const int32_t* __restrict__ count,
+                                                                   const int32_t* __restrict__ leaf_node, TreeOut out, int it, TrainConst c) {
+    const int k = blockIdx.x, l = threadIdx.x;
+    const long long tbase = (long long)it * c.K + k;
+    const int L = out.L[tbase];
+    if (l >= L) return;
+    const int n = leaf_node[(long long)k * LV_MAX_LEAVES + l];
+    out.leaf_count[tbase * c.num_leaves + l] = (n == 0) ? (int)plan[k].n_in : count[(long long)k * 256 + n];
 }
 
 }  // namespace rg
