@@ -427,8 +427,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             }
             lv_groups[level] = (int)((n_exp + npg - 1) / npg);
         }
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
@@ -504,10 +505,12 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         hipEvent_t a = nullptr, b = nullptr;
         const bool timed = stats && with_hist;
         if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
-        if (root) hipLaunchKernelGGL(k_level_pass<true>, dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
+        if (root) hipLaunchKernelGGL((k_level_pass<true, false>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
                                      (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
-        else hipLaunchKernelGGL(k_level_pass<false>, dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
-                                use_bagging ? d_inbag.p : (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
+        else if (use_bagging) hipLaunchKernelGGL((k_level_pass<false, true>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
+                                                 (const uint8_t*)d_inbag.p, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
+        else hipLaunchKernelGGL((k_level_pass<false, false>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
+                                (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
         if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
 

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
 // Algorithmic bytes per accumulated row: F bin bytes + 8 B (g,h); the pass also streams the node
 // ids (1 B in, 1 B out) and the records of rows it only routes.
 // ------------------------------------------------------------------------------------------------
-template <bool ROOT>
+template <bool ROOT, bool BAG>
 __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
                                                            uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
@@ -172,10 +172,9 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     const int tid = threadIdx.x, lane = tid & 63;
 
     // ---- LDS carve-up
-    uint32_t* route0 = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* route1 = route0 + 256;
-    volatile int32_t* drain_flag = reinterpret_cast<volatile int32_t*>(route1 + 256);   // [4] (16 B)
-    int32_t* cnt = reinterpret_cast<int32_t*>(route1 + 256) + 4;
+    uint2* route = reinterpret_cast<uint2*>(smem);                                      // [256] (w0, w1) of LvPlan::route0/1
+    volatile int32_t* drain_flag = reinterpret_cast<volatile int32_t*>(route + 256);    // [4] (16 B)
+    int32_t* cnt = reinterpret_cast<int32_t*>(route + 256) + 4;
     const int ncnt = 2 * n_exp * LV_CNT_REP;
     int32_t* wide_g = cnt + ncnt;
     uint32_t* wide_h = reinterpret_cast<uint32_t*>(wide_g + (size_t)ng * wb);
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     off = (off + 15) & ~(size_t)15;
     unsigned long long* fast = reinterpret_cast<unsigned long long*>(smem + off);
 
-    if (!ROOT) for (int i = tid; i < 256; i += LV_THREADS) { route0[i] = pp->route0[i]; route1[i] = pp->route1[i]; }
+    if (!ROOT) for (int i = tid; i < 256; i += LV_THREADS) route[i] = make_uint2(pp->route0[i], pp->route1[i]);
     if (tid < 4) drain_flag[tid] = 0;
     for (int i = tid; i < ncnt; i += LV_THREADS) cnt[i] = 0;
     for (int i = tid; i < ng * wb; i += LV_THREADS) { wide_g[i] = 0; wide_h[i] = 0u; }
@@ -196,9 +195,12 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
         for (int b = tid; b < nb; b += LV_THREADS) { w_slot[wo + b] = (uint32_t)(fb + (b << sh)) | ((uint32_t)sh << 24); w_hoff[wo + b] = (uint32_t)(fm[j].hoff + b); }
         for (int s = tid; s < (nb << sh); s += LV_THREADS) s2w[fb + s] = (uint16_t)((wo + (s >> sh)) | (sh > 0 ? 0x8000 : 0));
     }
-    int fbase[16], fshift[16];
+    // per-feature lane constants: byte offset of this lane's replica of bin 0 (relative to the node's slots), and
+    // the shift that turns a bin into a byte offset
+    int cj[16], fsh3[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { fbase[j] = lay.fbase[j]; fshift[j] = lay.sh[j]; }
+    for (int j = 0; j < 16; ++j) { fsh3[j] = lay.sh[j] + 3; cj[j] = (lay.fbase[j] + (lane & ((1 << lay.sh[j]) - 1))) * 8; }
+    const int nfeat = cm.nfeat;
     __syncthreads();
 
     const long long N = c.N;
@@ -250,73 +252,88 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
         return true;
     };
 
-    // Software pipeline: the loads of tile t+gridDim.x are in flight while tile t's LDS atomics run
-    // (one workgroup per CU, so nothing else would hide the HBM latency).
+    // one histogram update of a (row, built node) pair held by this lane: 15-16 packed LDS atomics, 3 instructions each
+    auto accumulate = [&](bool on, int li, const uint4& r, const int2& g) __attribute__((always_inline)) {
+        const unsigned long long packed = ((unsigned long long)(long long)g.x << 32) + (unsigned long long)(unsigned int)g.y;
+        const bool need = on && packed != 0ull && !(dbg & 2);
+        const unsigned ag = (unsigned)(g.x < 0 ? -g.x : g.x), ah = (unsigned)g.y;
+        const bool over = need && (acc_g + ag > LB_G || acc_h + ah > LB_H);
+        if (__any(over)) { if (lane == 0) drain_flag[0] = 1; rendezvous(); }
+        else if (drain_flag[0]) rendezvous();
+        if (need) {
+            acc_g += ag; acc_h += ah;
+            unsigned char* fb = reinterpret_cast<unsigned char*>(fast) + (unsigned)li * (unsigned)(spn * 8);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#define LV_ATOM(j) atomicAdd(reinterpret_cast<unsigned long long*>(fb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << fsh3[j])), packed)
+            if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
+                LV_ATOM(0); LV_ATOM(1); LV_ATOM(2); LV_ATOM(3); LV_ATOM(4); LV_ATOM(5); LV_ATOM(6); LV_ATOM(7);
+                LV_ATOM(8); LV_ATOM(9); LV_ATOM(10); LV_ATOM(11); LV_ATOM(12); LV_ATOM(13); LV_ATOM(14);
+                if (nfeat == 16) LV_ATOM(15);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 14; ++j) if (j < nfeat) LV_ATOM(j);
+            }
+#undef LV_ATOM
+        }
+    };
+
+    // Software pipeline: the loads of the next tile are in flight while this tile's LDS atomics run (one workgroup
+    // per CU, so nothing else would hide the HBM latency).  Addresses are a uniform tile base + a 32-bit lane offset.
     constexpr int RPT = LV_TILE / LV_THREADS;
     int cur_n[RPT], nxt_n[RPT], cur_ib[RPT], nxt_ib[RPT]; uint4 cur_r[RPT], nxt_r[RPT]; int2 cur_g[RPT], nxt_g[RPT];
-    auto fetch = [&](long long t, int (&fn)[RPT], uint4 (&fr)[RPT], int2 (&fg)[RPT], int (&fib)[RPT]) {
+    // straight-line loads (clamped offsets, no branches) so that the in-order vmcnt bookkeeping stays exact
+    auto fetch = [&](long long t, int (&fn)[RPT], uint4 (&fr)[RPT], int2 (&fg)[RPT], int (&fib)[RPT]) __attribute__((always_inline)) {
+        const bool tv = t < ntiles;                                   // uniform
+        const long long pb = tv ? t * LV_TILE : 0;
+        const long long left_rows = N - pb;
+        const unsigned lim = (unsigned)(left_rows < LV_TILE ? left_rows : LV_TILE) - 1u;   // last valid offset in the tile
+        const uint8_t* nb_ = node_in + pb; const uint4* rb_ = recc + pb; const int2* gb_ = ghk + pb;
+        const uint8_t* ib_ = BAG ? inbag + pb : nullptr;
 #pragma unroll
         for (int s = 0; s < RPT; ++s) {
-            const long long row = t * LV_TILE + (long long)s * LV_THREADS + tid;
-            fn[s] = LV_INACTIVE; fib[s] = 1; fr[s] = make_uint4(0, 0, 0, 0); fg[s] = make_int2(0, 0);
-            if (t < ntiles && row < N) {
-                fn[s] = node_in[row]; fr[s] = recc[row]; fg[s] = ghk[row];
-                if (!ROOT && inbag) fib[s] = inbag[row];
-            }
+            const unsigned o = (unsigned)(s * LV_THREADS + tid);
+            const unsigned oc = o < lim ? o : lim;
+            const int nv = nb_[oc];
+            fr[s] = rb_[oc]; fg[s] = gb_[oc];
+            fib[s] = BAG ? (int)ib_[oc] : 1;
+            fn[s] = (tv && o <= lim) ? nv : LV_INACTIVE;
         }
     };
     fetch(blockIdx.x, cur_n, cur_r, cur_g, cur_ib);
     for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const long long p0 = t * LV_TILE;
         fetch(t + gridDim.x, nxt_n, nxt_r, nxt_g, nxt_ib);
+        uint8_t* ob_ = node_out + p0;
 #pragma unroll
         for (int s = 0; s < RPT; ++s) {
-            const long long row = p0 + (long long)s * LV_THREADS + tid;
-            const int n = (row < N) ? cur_n[s] : LV_INACTIVE;
-            const uint4 r = cur_r[s];
-            const int2 g = cur_g[s];
+            const unsigned o = (unsigned)(s * LV_THREADS + tid);
+            const int n = cur_n[s];
+            if (ROOT) { accumulate(n != LV_INACTIVE, 0, cur_r[s], cur_g[s]); continue; }
             int li = -1;
+            const bool inrange = p0 + o < N;
+            int child = n;
             if (n != LV_INACTIVE) {
-                int bs;
-                if (ROOT) bs = 0;
-                else {
-                    int child = n; bs = 0xFF;
-                    const uint32_t w0 = route0[n];
-                    if (w0 & (1u << 24)) {
-                        const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
-                        const int bin = ((f >> 4) == ch) ? (int)rec_byte(r, f & 15) : (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
-                        const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
-                        const uint32_t w1 = route1[n];
-                        child = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
-                        bs = left ? (int)((w1 >> 16) & 0xFFu) : (int)(w1 >> 24);
-                        if (writer && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                    }
-                    if (writer && !(dbg & 4)) node_out[row] = (uint8_t)child;
-                }
-                if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
-            } else if (writer && row < N) node_out[row] = (uint8_t)LV_INACTIVE;
-            const unsigned long long packed = ((unsigned long long)(long long)g.x << 32) + (unsigned long long)(unsigned int)g.y;
-            const bool need = li >= 0 && packed != 0ull && !(dbg & 2);
-            const unsigned ag = (unsigned)(g.x < 0 ? -g.x : g.x), ah = (unsigned)g.y;
-            if (ng > 0) {
-                // poll / raise the drain flag (wave-uniform decisions)
-                const bool over = need && (acc_g + ag > LB_G || acc_h + ah > LB_H);
-                if (__any(over)) { if (lane == 0) drain_flag[0] = 1; rendezvous(); }
-                else if (drain_flag[0]) rendezvous();
-            }
-            if (need) {
-                acc_g += ag; acc_h += ah;
-                unsigned long long* fb = fast + (size_t)li * spn;
-                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (j < cm.nfeat) {
-                        const uint32_t bin = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                        const int slot = fbase[j] + (int)(bin << fshift[j]) + (lane & ((1 << fshift[j]) - 1));
-                        atomicAdd(&fb[slot], packed);
-                    }
+                const uint2 e = route[n];
+                if (e.x & (1u << 24)) {
+                    const unsigned f = e.x & 0xFFu;
+                    unsigned bin;
+                    if ((f >> 4) == (unsigned)ch) {
+                        // byte (f & 15) of the 16-byte record: pick the 8-byte half (2 v_cndmask), then one v_perm_b32
+                        const bool hi = (f & 8u) != 0u;
+                        const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
+                        const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
+                        bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
+                    } else bin = rec8[((long long)(f >> 4) * N + p0 + o) * 16 + (f & 15u)];
+                    const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
+                    const unsigned sel = left ? e.y : (e.y >> 8);      // child in bits 0..7, built slot in bits 16..23
+                    child = (int)(sel & 0xFFu);
+                    const int bs = (int)((sel >> 16) & 0xFFu);
+                    if (writer && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                    if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
                 }
             }
+            if (writer && inrange && !(dbg & 4)) ob_[o] = (uint8_t)child;
+            if (ng > 0) accumulate(li >= 0, li, cur_r[s], cur_g[s]);
         }
 #pragma unroll
         for (int s = 0; s < RPT; ++s) { cur_n[s] = nxt_n[s]; cur_r[s] = nxt_r[s]; cur_g[s] = nxt_g[s]; cur_ib[s] = nxt_ib[s]; }
