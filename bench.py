@@ -154,7 +154,7 @@ def main():
                        "error_cells": n_cells, "parallelism": "target-sharded x%d" % world},
             "model_train_sec": train_s, "repair_sec": infer_s, "elapsed_sec": elapsed,
             "repair_accuracy_vs_clean": fixed / max(n_cells, 1),
-            "roofline": {"bound": "hbm", "kernel": "rg::k_hist", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "rg::k_level_pass (level grower) | rg::k_hist (leaf-wise grower)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches": int(launches_all), "avg_launch_us": hist_ms_all * 1e3 / max(launches_all, 1),
                          "alg_bytes_per_launch": hist_bytes_all / max(launches_all, 1),
