@@ -149,6 +149,52 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
     }
 }
 
+// Multiclass gradients with the row's K scores parked in LDS (each thread owns one column of the [K][R] tile, so
+// no barrier is needed): every score is read from HBM once, all K loads of a thread are in flight together, and
+// exp(s_k - max) is evaluated once per class.  Same arithmetic, in the same order, as k_grad<1>.
+template <int R>
+__global__ __launch_bounds__(R) void k_grad_mc(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+                                               const double* __restrict__ class_w, const double* __restrict__ sample_w,
+                                               const uint8_t* __restrict__ row_in_bag, int2* __restrict__ gh,
+                                               uint8_t* __restrict__ node0, long long NS, TrainConst c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* tile = reinterpret_cast<double*>(smem) + threadIdx.x;   // element k at tile[k * R]
+    const long long N = c.N;
+    const int K = c.K;
+    const long long i = (long long)blockIdx.x * R + threadIdx.x;
+    if (i >= N) return;
+    const double* sp = score + i;
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sp[(long long)(k + u) * N];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tile[(k + u) * R] = v[u];
+    }
+    for (; k < K; ++k) tile[k * R] = sp[(long long)k * N];
+    const int y = ycol[i];
+    if (node0) {
+        const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
+        for (int kk = 0; kk < K; ++kk) node0[(long long)kk * NS + i] = v;
+    }
+    if (y < 0) return;
+    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) gh[(long long)kk * N + i] = make_int2(0, 0); return; }
+    double wi = class_w ? class_w[y] : 1.0;
+    if (sample_w) wi = wi * sample_w[i];
+    wi = (double)(float)wi;
+    double wmax = tile[0];
+    for (int kk = 1; kk < K; ++kk) { const double s = tile[kk * R]; if (s > wmax) wmax = s; }
+    double wsum = 0.0;
+    for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
+    for (int kk = 0; kk < K; ++kk) {
+        const double pk = tile[kk * R] / wsum;
+        const double g = ((y == kk) ? (pk - 1.0) : pk) * wi;
+        const double h = c.factor * pk * (1.0 - pk) * wi;
+        gh[(long long)kk * N + i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: hist_build -- THE roofline kernel.
 //   grid (gx, K, nchunk), block 256.  Each lane owns one row per step: one dwordx4 load brings its

@@ -673,15 +673,37 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     const uint8_t* node = ((route ? pp->buf_in : pp->buf) ? node_b : node_a) + (long long)k * c.NS;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
     double* sk = score + (long long)k * N;
+    // 4 rows per thread; node ids and scores are loaded together (independent loads), then routed and written back
+    const bool aligned16 = (((unsigned long long)sk) & 15ull) == 0ull;   // uniform
     for (long long i = ((long long)blockIdx.x * 256 + tid) * 4; i < N; i += (long long)gridDim.x * 1024) {
-        const uint32_t n4 = (i + 3 < N) ? *reinterpret_cast<const uint32_t*>(node + i)
-                                        : ((uint32_t)node[i] | (i + 1 < N ? (uint32_t)node[i + 1] << 8 : 0xFF00u) | (i + 2 < N ? (uint32_t)node[i + 2] << 16 : 0xFF0000u) | 0xFF000000u);
-        if (n4 == 0xFFFFFFFFu) continue;
+        if (i + 3 < N && aligned16) {
+            const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
+            double2 s01 = *reinterpret_cast<const double2*>(sk + i), s23 = *reinterpret_cast<const double2*>(sk + i + 2);
+            if (n4 == 0xFFFFFFFFu) continue;
+            double sv[4] = {s01.x, s01.y, s23.x, s23.y};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int n = (int)((n4 >> (8 * j)) & 0xFFu);
+            for (int j = 0; j < 4; ++j) {
+                int n = (int)((n4 >> (8 * j)) & 0xFFu);
+                if (n == LV_INACTIVE) continue;
+                const long long row = i + j;
+                const uint32_t w0 = route0[n];
+                if (w0 & (1u << 24)) {
+                    const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
+                    const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
+                    const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
+                    const uint32_t w1 = route1[n];
+                    n = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
+                    if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                }
+                sv[j] += nd[n];
+            }
+            s01.x = sv[0]; s01.y = sv[1]; s23.x = sv[2]; s23.y = sv[3];
+            *reinterpret_cast<double2*>(sk + i) = s01; *reinterpret_cast<double2*>(sk + i + 2) = s23;
+            continue;
+        }
+        for (long long row = i; row < N && row < i + 4; ++row) {
+            int n = node[row];
             if (n == LV_INACTIVE) continue;
-            const long long row = i + j;
             const uint32_t w0 = route0[n];
             if (w0 & (1u << 24)) {
                 const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);

@@ -1,0 +1,128 @@
+"""-m gpu: the two HIP tree growers (level-synchronous streaming grower, leaf-wise index-list grower)
+against the CPU oracle and against each other, bit-exact.
+
+The level grower (csrc/rgbm_level.h) is used for 1 <= max_depth <= 7 and F <= 255, everything else
+takes the leaf-wise grower (csrc/rgbm_kernels.h).  RGBM_GROWER=leafwise forces the latter, which is
+how the same configuration is run through both here.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.synth import make_table, balanced_weights
+
+pytestmark = pytest.mark.gpu
+
+
+class _grower:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = os.environ.get("RGBM_GROWER")
+        if self.name == "leafwise":
+            os.environ["RGBM_GROWER"] = "leafwise"
+        else:
+            os.environ.pop("RGBM_GROWER", None)
+
+    def __exit__(self, *a):
+        if self.prev is None:
+            os.environ.pop("RGBM_GROWER", None)
+        else:
+            os.environ["RGBM_GROWER"] = self.prev
+
+
+def _three_way(X, n_codes, y, K, obj, cw=None, yv=None, **kw):
+    from oracle import oracle as O
+    from repair import _native as N
+    params = dict(objective=obj, num_class=max(K, 2), **kw)
+    mo = O.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
+    with _grower("level"):
+        ml = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
+    with _grower("leafwise"):
+        mw = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
+    bo = mo.save()
+    assert ml.save() == bo, "level grower differs from the oracle"
+    assert mw.save() == bo, "leaf-wise grower differs from the oracle"
+    po = mo.predict(X)
+    assert np.array_equal(po, ml.predict(X))
+    return mo
+
+
+def _xy(n, cols, tgt, seed, null_ratio=0.01):
+    dirty, clean, cards = make_table(n, cols, seed=seed, null_ratio=null_ratio)
+    feats = [c for c in range(cols) if c != tgt]
+    rows = dirty[tgt] >= 0
+    return np.ascontiguousarray(dirty[feats][:, rows]), cards[feats], dirty[tgt][rows], int(cards[tgt])
+
+
+@pytest.mark.parametrize("depth,leaves", [(1, 31), (2, 31), (3, 5), (5, 31), (7, 2), (7, 100), (6, 64)])
+def test_depth_and_leaf_budgets(depth, leaves):
+    X, nc, y, K = _xy(20011, 8, 5, seed=31)
+    _three_way(X, nc, y, K, 1, cw=balanced_weights(y, K), n_estimators=6, learning_rate=0.3, max_depth=depth, num_leaves=leaves)
+
+
+@pytest.mark.parametrize("n", [1, 7, 63, 2047, 2049, 4100])
+def test_row_counts_around_tile_edges(n):
+    X, nc, y, K = _xy(max(n * 2, 40), 6, 3, seed=37)
+    X = np.ascontiguousarray(X[:, :n]); y = y[:n]
+    _three_way(X, nc, y, K, 1, cw=balanced_weights(y, K) if len(np.unique(y)) > 1 else None, n_estimators=4, learning_rate=0.3, min_data_in_leaf=2)
+
+
+def test_binary_and_regression_three_way():
+    X, nc, y, K = _xy(30000, 8, 0, seed=41)   # column 0 is binary
+    assert K == 2
+    _three_way(X, nc, y, K, 0, cw=balanced_weights(y, K), n_estimators=12, learning_rate=0.2)
+    rng = np.random.default_rng(43)
+    dirty, clean, cards = make_table(9000, 6, seed=43)
+    vals = np.sort(rng.normal(size=30))
+    _three_way(np.ascontiguousarray(dirty[:5]), cards[:5], (clean[5] % 30).astype(np.int32), 30, 2, yv=vals, n_estimators=10, learning_rate=0.1, lambda_l2=1.0)
+
+
+def test_many_bins_force_histogram_groups():
+    """16 features x ~250 bins: one node's histogram is ~64 KB of LDS, so deep levels run several groups per pass."""
+    rng = np.random.default_rng(47)
+    n = 60000
+    z = rng.integers(0, 250, n)
+    X = np.stack([((z * (j + 3) + rng.integers(0, 40, n)) % 250).astype(np.int32) for j in range(16)])
+    X[3][rng.random(n) < 0.03] = -1
+    y = ((z // 25 + (X[0] > 120)) % 6).astype(np.int32)
+    _three_way(np.ascontiguousarray(X), [250] * 16, y, 6, 1, cw=balanced_weights(y, 6), n_estimators=4, learning_rate=0.3, min_data_in_leaf=5)
+
+
+def test_two_chunks_with_many_bins():
+    rng = np.random.default_rng(53)
+    n = 25000
+    z = rng.integers(0, 120, n)
+    X = np.stack([((z * (j + 1) + rng.integers(0, 9, n)) % (20 + 11 * j)).astype(np.int32) for j in range(23)])
+    y = ((z // 10 + X[20] % 3) % 5).astype(np.int32)
+    _three_way(np.ascontiguousarray(X), [20 + 11 * j for j in range(23)], y, 5, 1, cw=balanced_weights(y, 5), n_estimators=5, learning_rate=0.3)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(bagging_fraction=0.6, bagging_freq=2),
+    dict(feature_fraction=0.4, lambda_l1=0.3, min_gain_to_split=0.02),
+    dict(min_data_in_leaf=400, min_sum_hessian_in_leaf=5.0),
+])
+def test_sampling_constraints_three_way(kw):
+    X, nc, y, K = _xy(15000, 9, 6, seed=59, null_ratio=0.03)
+    _three_way(X, nc, y, K, 1, cw=balanced_weights(y, K), n_estimators=8, learning_rate=0.2, **kw)
+
+
+def test_many_classes():
+    """K = 64 class trees grown in lock step (the expensive shape of the synthetic workload)."""
+    X, nc, y, K = _xy(40000, 16, 10, seed=61)
+    assert K == 64
+    _three_way(X, nc, y, K, 1, cw=balanced_weights(y, K), n_estimators=3, learning_rate=0.3)
+
+
+def test_unseen_and_constant_columns():
+    rng = np.random.default_rng(67)
+    n = 5000
+    a = rng.integers(0, 4, n).astype(np.int32)
+    b = np.zeros(n, np.int32)                      # constant -> trivial feature
+    c = np.full(n, -1, np.int32)                   # all NULL
+    d = rng.integers(0, 9, n).astype(np.int32)
+    y = ((a + d) % 3).astype(np.int32)
+    _three_way(np.ascontiguousarray(np.stack([a, b, c, d])), [4, 1, 5, 9], y, 3, 1, cw=balanced_weights(y, 3), n_estimators=6, learning_rate=0.3)
