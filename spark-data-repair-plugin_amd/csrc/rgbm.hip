@@ -427,9 +427,12 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             }
             lv_groups[level] = (int)((n_exp + npg - 1) / npg);
         }
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
@@ -505,12 +508,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         hipEvent_t a = nullptr, b = nullptr;
         const bool timed = stats && with_hist;
         if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
-        if (root) hipLaunchKernelGGL((k_level_pass<true, false>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
-                                     (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
-        else if (use_bagging) hipLaunchKernelGGL((k_level_pass<false, true>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
-                                                 (const uint8_t*)d_inbag.p, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
-        else hipLaunchKernelGGL((k_level_pass<false, false>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p,
-                                (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc);
+#define RGBM_LAUNCH_PASS(R, B, M, INBAG)                                                                                                        \
+        hipLaunchKernelGGL((k_level_pass<R, B, M>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p, \
+                           (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc)
+        const bool multi = nchunk > 1;
+        if (root) { if (multi) RGBM_LAUNCH_PASS(true, false, true, nullptr); else RGBM_LAUNCH_PASS(true, false, false, nullptr); }
+        else if (use_bagging) { if (multi) RGBM_LAUNCH_PASS(false, true, true, d_inbag.p); else RGBM_LAUNCH_PASS(false, true, false, d_inbag.p); }
+        else { if (multi) RGBM_LAUNCH_PASS(false, false, true, nullptr); else RGBM_LAUNCH_PASS(false, false, false, nullptr); }
+#undef RGBM_LAUNCH_PASS
         if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
 

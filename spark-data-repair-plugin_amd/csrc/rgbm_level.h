@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
 // Algorithmic bytes per accumulated row: F bin bytes + 8 B (g,h); the pass also streams the node
 // ids (1 B in, 1 B out) and the records of rows it only routes.
 // ------------------------------------------------------------------------------------------------
-template <bool ROOT, bool BAG>
+template <bool ROOT, bool BAG, bool MULTI /* more than one 16-feature chunk */>
 __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
                                                            uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
 
     // ---- LDS carve-up
     uint2* route = reinterpret_cast<uint2*>(smem);                                      // [256] (w0, w1) of LvPlan::route0/1
-    volatile int32_t* drain_flag = reinterpret_cast<volatile int32_t*>(route + 256);    // [4] (16 B)
+    int32_t* drain_flag = reinterpret_cast<int32_t*>(route + 256);                      // [4] (16 B), relaxed atomic accesses
     int32_t* cnt = reinterpret_cast<int32_t*>(route + 256) + 4;
     const int ncnt = 2 * n_exp * LV_CNT_REP;
     int32_t* wide_g = cnt + ncnt;
@@ -187,6 +187,8 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
 
     if (!ROOT) for (int i = tid; i < 256; i += LV_THREADS) route[i] = make_uint2(pp->route0[i], pp->route1[i]);
     if (tid < 4) drain_flag[tid] = 0;
+#define LV_FLAG_LOAD() __hip_atomic_load(drain_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LV_FLAG_STORE(v) __hip_atomic_store(drain_flag, (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
     for (int i = tid; i < ncnt; i += LV_THREADS) cnt[i] = 0;
     for (int i = tid; i < ng * wb; i += LV_THREADS) { wide_g[i] = 0; wide_h[i] = 0u; }
     for (int i = tid; i < ng * spn; i += LV_THREADS) fast[i] = 0ull;
@@ -243,10 +245,10 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     // every wave that reaches a rendezvous executes exactly: barrier, [flag set: drain, barrier, clear, barrier]
     auto rendezvous = [&]() -> bool {
         __syncthreads();
-        if (!drain_flag[0]) return false;
+        if (!LV_FLAG_LOAD()) return false;
         drain();
         __syncthreads();
-        if (tid == 0) drain_flag[0] = 0;
+        if (tid == 0) LV_FLAG_STORE(0);
         __syncthreads();
         acc_g = 0; acc_h = 0;
         return true;
@@ -258,8 +260,8 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
         const bool need = on && packed != 0ull && !(dbg & 2);
         const unsigned ag = (unsigned)(g.x < 0 ? -g.x : g.x), ah = (unsigned)g.y;
         const bool over = need && (acc_g + ag > LB_G || acc_h + ah > LB_H);
-        if (__any(over)) { if (lane == 0) drain_flag[0] = 1; rendezvous(); }
-        else if (drain_flag[0]) rendezvous();
+        if (__any(over)) { if (lane == 0) LV_FLAG_STORE(1); rendezvous(); }
+        else if (LV_FLAG_LOAD()) rendezvous();
         if (need) {
             acc_g += ag; acc_h += ah;
             unsigned char* fb = reinterpret_cast<unsigned char*>(fast) + (unsigned)li * (unsigned)(spn * 8);
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
                 if (e.x & (1u << 24)) {
                     const unsigned f = e.x & 0xFFu;
                     unsigned bin;
-                    if ((f >> 4) == (unsigned)ch) {
+                    if (!MULTI || (f >> 4) == (unsigned)ch) {
                         // byte (f & 15) of the 16-byte record: pick the 8-byte half (2 v_cndmask), then one v_perm_b32
                         const bool hi = (f & 8u) != 0u;
                         const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
@@ -362,6 +364,9 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
         }
     }
 }
+
+#undef LV_FLAG_LOAD
+#undef LV_FLAG_STORE
 
 // ------------------------------------------------------------------------------------------------
 // k_level_split: sum the workgroup partials of the built child, derive the sibling by subtraction,
