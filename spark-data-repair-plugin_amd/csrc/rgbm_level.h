@@ -43,6 +43,13 @@ constexpr int LV_LDS_BYTES = 160 * 1024;
 constexpr int LV_CARRY_SHIFT = 11;
 constexpr int LV_MAX_DEPTH = 7;
 constexpr int LV_MAX_LEAVES = 128;
+#ifndef LV_RING
+#define LV_RING 0       // 1: level passes compact the rows that feed a histogram into full waves (per-wave LDS ring).
+                        // Measured on MI355X (K=64, 10M rows): halves the LDS atomic instructions but the pass time is unchanged
+                        // (2.9 ms either way: VALU issue + s_waitcnt bound, not LDS bound), so the simpler path is the default.
+#endif
+constexpr int LV_LIST = 256;                                   // ring entries per wave
+constexpr int LV_LIST_BYTES = LV_RING ? (LV_THREADS / 64) * LV_LIST * 4 : 0;
 
 struct SNode {   // speculative node of one class tree
     long long Gq, Hq;
@@ -96,7 +103,7 @@ __host__ __device__ inline long long lv_node_bytes(const FeatMeta* fm, const Chu
 
 __host__ __device__ inline long long lv_fixed_bytes(const ChunkMeta& cm, int n_exp, const FeatMeta* fm) {
     // route tables + child counters + (wide->slot, wide->hoff) tables + slot->wide map at the largest layout + alignment slack
-    return 2048 + 16 + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + (long long)lv_slots(fm, cm.nfeat, 5) * 2 + 64;
+    return 2048 + 16 + LV_LIST_BYTES + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + (long long)lv_slots(fm, cm.nfeat, 5) * 2 + 64;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     // ---- LDS carve-up
     uint2* route = reinterpret_cast<uint2*>(smem);                                      // [256] (w0, w1) of LvPlan::route0/1
     int32_t* drain_flag = reinterpret_cast<int32_t*>(route + 256);                      // [4] (16 B), relaxed atomic accesses
-    int32_t* cnt = reinterpret_cast<int32_t*>(route + 256) + 4;
+    uint32_t* lst = reinterpret_cast<uint32_t*>(route + 256) + 4 + (tid >> 6) * LV_LIST;   // this wave's ring (LV_RING)
+    int32_t* cnt = reinterpret_cast<int32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4;
     const int ncnt = 2 * n_exp * LV_CNT_REP;
     int32_t* wide_g = cnt + ncnt;
     uint32_t* wide_h = reinterpret_cast<uint32_t*>(wide_g + (size_t)ng * wb);
@@ -296,49 +304,131 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
             const unsigned o = (unsigned)(s * LV_THREADS + tid);
             const unsigned oc = o < lim ? o : lim;
             const int nv = nb_[oc];
-            fr[s] = rb_[oc]; fg[s] = gb_[oc];
+            fr[s] = rb_[oc];
+            if (ROOT || !LV_RING) fg[s] = gb_[oc]; else fg[s] = make_int2(0, 0);
             fib[s] = BAG ? (int)ib_[oc] : 1;
             fn[s] = (tv && o <= lim) ? nv : LV_INACTIVE;
         }
     };
-    fetch(blockIdx.x, cur_n, cur_r, cur_g, cur_ib);
-    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const long long p0 = t * LV_TILE;
-        fetch(t + gridDim.x, nxt_n, nxt_r, nxt_g, nxt_ib);
-        uint8_t* ob_ = node_out + p0;
+    if (ROOT || !LV_RING) {
+        fetch(blockIdx.x, cur_n, cur_r, cur_g, cur_ib);
+        for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const long long p0 = t * LV_TILE;
+            fetch(t + gridDim.x, nxt_n, nxt_r, nxt_g, nxt_ib);
+            uint8_t* ob_ = node_out + p0;
+    #pragma unroll
+            for (int s = 0; s < RPT; ++s) {
+                const unsigned o = (unsigned)(s * LV_THREADS + tid);
+                const int n = cur_n[s];
+                if (ROOT) { accumulate(n != LV_INACTIVE, 0, cur_r[s], cur_g[s]); continue; }
+                int li = -1;
+                const bool inrange = p0 + o < N;
+                int child = n;
+                if (n != LV_INACTIVE) {
+                    const uint2 e = route[n];
+                    if (e.x & (1u << 24)) {
+                        const unsigned f = e.x & 0xFFu;
+                        unsigned bin;
+                        if (!MULTI || (f >> 4) == (unsigned)ch) {
+                            // byte (f & 15) of the 16-byte record: pick the 8-byte half (2 v_cndmask), then one v_perm_b32
+                            const bool hi = (f & 8u) != 0u;
+                            const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
+                            const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
+                            bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
+                        } else bin = rec8[((long long)(f >> 4) * N + p0 + o) * 16 + (f & 15u)];
+                        const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
+                        const unsigned sel = left ? e.y : (e.y >> 8);      // child in bits 0..7, built slot in bits 16..23
+                        child = (int)(sel & 0xFFu);
+                        const int bs = (int)((sel >> 16) & 0xFFu);
+                        if (writer && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                        if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
+                    }
+                }
+                if (writer && inrange && !(dbg & 4)) ob_[o] = (uint8_t)child;
+                if (ng > 0) accumulate(li >= 0, li, cur_r[s], cur_g[s]);
+            }
+    #pragma unroll
+            for (int s = 0; s < RPT; ++s) { cur_n[s] = nxt_n[s]; cur_r[s] = nxt_r[s]; cur_g[s] = nxt_g[s]; cur_ib[s] = nxt_ib[s]; }
+        }
+    } else {
+        // ---- level pass with compaction.  Phase 1 (every row): route, count, store the new node id; rows that feed a
+        // histogram of this block's group are appended to this wave's LDS ring (4 B: tile index | row offset | slot).
+        // Phase 2: full waves of 64 listed rows reload (rec, gh) -- L2 hits, the records were streamed a moment ago --
+        // and run the packed atomics.  Order inside one tile step: [batch loads] [far prefetch] [routing] [atomics]:
+        // vmcnt retires in order, so waiting for the batch never waits for the prefetch issued after it.
+        const long long gstep = gridDim.x;
+        int lcount = 0, lhead = 0;            // wave-uniform ring state
+        uint32_t ti = 0;                      // index of the current tile among this block's tiles
+        fetch(blockIdx.x, cur_n, cur_r, cur_g, cur_ib);
+        for (long long t = blockIdx.x; t < ntiles; t += gstep, ++ti) {
+            const long long p0 = t * LV_TILE;
+            bool b_on[2]; uint4 b_r[2]; int2 b_g[2]; int b_li[2]; int b_n[2];
 #pragma unroll
-        for (int s = 0; s < RPT; ++s) {
-            const unsigned o = (unsigned)(s * LV_THREADS + tid);
-            const int n = cur_n[s];
-            if (ROOT) { accumulate(n != LV_INACTIVE, 0, cur_r[s], cur_g[s]); continue; }
-            int li = -1;
-            const bool inrange = p0 + o < N;
-            int child = n;
-            if (n != LV_INACTIVE) {
-                const uint2 e = route[n];
-                if (e.x & (1u << 24)) {
-                    const unsigned f = e.x & 0xFFu;
-                    unsigned bin;
-                    if (!MULTI || (f >> 4) == (unsigned)ch) {
-                        // byte (f & 15) of the 16-byte record: pick the 8-byte half (2 v_cndmask), then one v_perm_b32
-                        const bool hi = (f & 8u) != 0u;
-                        const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
-                        const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
-                        bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
-                    } else bin = rec8[((long long)(f >> 4) * N + p0 + o) * 16 + (f & 15u)];
-                    const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
-                    const unsigned sel = left ? e.y : (e.y >> 8);      // child in bits 0..7, built slot in bits 16..23
-                    child = (int)(sel & 0xFFu);
-                    const int bs = (int)((sel >> 16) & 0xFFu);
-                    if (writer && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                    if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
+            for (int b = 0; b < 2; ++b) {
+                const int nb = ng > 0 ? (lcount < 64 ? lcount : 64) : 0;
+                b_n[b] = nb; b_on[b] = lane < nb;
+                const uint32_t e = lst[(lhead + (b_on[b] ? lane : 0)) & (LV_LIST - 1)];
+                const long long row = b_on[b] ? ((long long)blockIdx.x + (long long)(e >> 16) * gstep) * LV_TILE + ((e >> 5) & 0x7FFu) : p0;
+                b_li[b] = (int)(e & 31u);
+                b_r[b] = recc[row]; b_g[b] = ghk[row];
+                lhead += nb; lcount -= nb;
+            }
+            fetch(t + gstep, nxt_n, nxt_r, nxt_g, nxt_ib);
+            uint8_t* ob_ = node_out + p0;
+#pragma unroll
+            for (int s = 0; s < RPT; ++s) {
+                const unsigned o = (unsigned)(s * LV_THREADS + tid);
+                const int n = cur_n[s];
+                int li = -1;
+                const bool inrange = p0 + o < N;
+                int child = n;
+                if (n != LV_INACTIVE) {
+                    const uint2 e = route[n];
+                    if (e.x & (1u << 24)) {
+                        const unsigned f = e.x & 0xFFu;
+                        unsigned bin;
+                        if (!MULTI || (f >> 4) == (unsigned)ch) {
+                            const bool hi = (f & 8u) != 0u;
+                            const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
+                            const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
+                            bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
+                        } else bin = rec8[((long long)(f >> 4) * N + p0 + o) * 16 + (f & 15u)];
+                        const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
+                        const unsigned sel = left ? e.y : (e.y >> 8);
+                        child = (int)(sel & 0xFFu);
+                        const int bs = (int)((sel >> 16) & 0xFFu);
+                        if (writer && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                        if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
+                    }
+                }
+                if (writer && inrange && !(dbg & 4)) ob_[o] = (uint8_t)child;
+                if (ng > 0) {
+                    const unsigned long long m = __ballot(li >= 0);
+                    if (li >= 0) lst[(lhead + lcount + __popcll(m & ((1ull << lane) - 1ull))) & (LV_LIST - 1)] = (ti << 16) | (o << 5) | (uint32_t)li;
+                    lcount += __popcll(m);
                 }
             }
-            if (writer && inrange && !(dbg & 4)) ob_[o] = (uint8_t)child;
-            if (ng > 0) accumulate(li >= 0, li, cur_r[s], cur_g[s]);
-        }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // ring entries are read by other lanes of this wave
+            if (ng > 0) {
+                if (b_n[0] == 0) { if (LV_FLAG_LOAD()) rendezvous(); }
+                else {
+                    accumulate(b_on[0], b_li[0], b_r[0], b_g[0]);
+                    if (b_n[1] > 0) accumulate(b_on[1], b_li[1], b_r[1], b_g[1]);
+                }
+            }
 #pragma unroll
-        for (int s = 0; s < RPT; ++s) { cur_n[s] = nxt_n[s]; cur_r[s] = nxt_r[s]; cur_g[s] = nxt_g[s]; cur_ib[s] = nxt_ib[s]; }
+            for (int s = 0; s < RPT; ++s) { cur_n[s] = nxt_n[s]; cur_r[s] = nxt_r[s]; cur_ib[s] = nxt_ib[s]; }
+        }
+        // leftovers in the ring
+        while (ng > 0 && lcount > 0) {
+            const int nb = lcount < 64 ? lcount : 64;
+            const bool on = lane < nb;
+            const uint32_t e = lst[(lhead + (on ? lane : 0)) & (LV_LIST - 1)];
+            const long long row = on ? ((long long)blockIdx.x + (long long)(e >> 16) * gstep) * LV_TILE + ((e >> 5) & 0x7FFu) : 0;
+            const uint4 br = recc[row]; const int2 bg = ghk[row];
+            lhead += nb; lcount -= nb;
+            accumulate(on, (int)(e & 31u), br, bg);
+        }
     }
     // epilogue rendezvous: leave only when every wave has finished its rows and no drain is pending
     if (ng > 0) { while (rendezvous()) {} } else __syncthreads();
