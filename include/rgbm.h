@@ -56,7 +56,7 @@ typedef struct {
     int32_t bagging_freq;     /* subsample_freq, train.py:151 */
     int32_t seed;             /* random_state=42, train.py:113 */
     int32_t device_id;        /* HIP device ordinal */
-    int32_t reserved;
+    int32_t reserved;         /* flags: RGBM_FLAG_ROW_SHARDED */
     double learning_rate;           /* model.lgb.learning_rate, train.py:41-42 */
     double lambda_l1;               /* reg_alpha, train.py:47-49 */
     double lambda_l2;               /* reg_lambda, train.py:155 */
@@ -137,6 +137,25 @@ int rgbm_table_repair_chain(rgbm_table* t, const rgbm_model* const* models, int3
                             int64_t row_begin, int64_t n_rows, int32_t* out_label, double* out_prob);
 /* Copy one column of the resident table back to the host. */
 int rgbm_table_read_column(const rgbm_table* t, int32_t col, int32_t* out /* [n] */);
+
+/* ---- row-sharded multi-GPU training ------------------------------------------------------------
+ * The reference parallelises training per target attribute (python/repair/model.py:817-926); a single
+ * multiclass target cannot be split that way.  Here every rank (one process per GPU) uploads a ROW SHARD
+ * of the table with rgbm_table_create and calls rgbm_table_train for the same targets in the same
+ * order; inside, the code counts, the per-level histograms and the child row counts are summed with
+ * integer all-reduces (RCCL over xGMI, enqueued on the training stream).  All sums are exact integers,
+ * so every rank ends with the same model, bit-identical to single-GPU training on the whole table.
+ * The communicator belongs to the calling thread.  Level grower only, no bagging / per-row weights. */
+#define RGBM_COMM_ID_BYTES 128
+#define RGBM_FLAG_ROW_SHARDED 1 /* rgbm_params.reserved: this call is one rank of a row-sharded training */
+int rgbm_comm_unique_id(void* id_out /* [RGBM_COMM_ID_BYTES], call on one rank, hand to all */);
+int rgbm_comm_init(const void* id, int32_t rank, int32_t nranks, int32_t device_id);
+int rgbm_comm_finalize(void);
+int rgbm_comm_info(int32_t* info /* [3] = {0 none | 1 RCCL | 2 thread group, rank, nranks} */);
+/* Test transport: the ranks are host threads of one process sharing one device. */
+int rgbm_local_group_create(int32_t nranks, int32_t device_id, void** group_out);
+void rgbm_local_group_free(void* group);
+int rgbm_comm_init_local(void* group, int32_t rank);
 
 /* ---- model handle: pickling (python/repair/model.py:910,921,1069) -------------------------- */
 int rgbm_model_save(const rgbm_model* m, void* buf, size_t* len); /* buf==NULL: length query */

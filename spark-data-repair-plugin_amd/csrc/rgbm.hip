@@ -11,7 +11,9 @@
 // returns RGBM_ERR_NO_DEVICE (the CPU oracle under oracle/ is test infrastructure and is never
 // linked or loaded from here).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <algorithm>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +65,77 @@ struct DevBuf {
     void download(T* h, size_t count, hipStream_t s) const { if (count) HIPCHK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
     void zero(hipStream_t s) { if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Row-sharded multi-GPU training (DESIGN.md "Multi-GPU"): every rank holds a row shard of the table and grows the
+// SAME trees; the only exchanges are integer all-reduces of (a) the code counts used for binning, (b) the built
+// children's histograms after each level pass and (c) the exact child row counts.  Sums are exact integers, so the
+// model is bit-identical to single-GPU training for any number of ranks and any row split.
+// Two transports: RCCL (one process per GPU, all-reduce enqueued on the training stream: no host round trip) and an
+// in-process thread group (one rank per host thread on one device) that exists so the sharding logic can be
+// verified on a single GPU.
+// ---------------------------------------------------------------------------------------------
+struct LocalGroup {
+    int nranks = 0, device = 0;
+    std::mutex mu; std::condition_variable cv;
+    int arrived = 0; long long generation = 0;
+    std::vector<void*> ptr;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const long long gen = generation;
+        if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
+struct Comm {
+    int kind = 0;   // 0 none, 1 RCCL, 2 local thread group
+    int rank = 0, nranks = 1;
+    ncclComm_t nccl = nullptr;
+    LocalGroup* lg = nullptr;
+    void* tmp = nullptr; size_t tmp_bytes = 0;
+};
+thread_local Comm g_comm;
+
+enum { AR_I64 = 0, AR_U32 = 1, AR_I32 = 2 };
+
+struct PtrList { const void* p[16]; };
+template <typename T>
+__global__ void k_sum_ranks(PtrList src, int n, T* __restrict__ out, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    T acc = 0;
+    for (int r = 0; r < n; ++r) acc += reinterpret_cast<const T*>(src.p[r])[i];
+    out[i] = acc;
+}
+
+// in-place sum all-reduce of `count` elements on stream s
+void all_reduce(void* buf, size_t count, int type, hipStream_t s) {
+    Comm& c = g_comm;
+    if (c.kind == 0 || count == 0) return;
+    const size_t esz = type == AR_I64 ? 8 : 4;
+    if (c.kind == 1) {
+        const ncclDataType_t dt = type == AR_I64 ? ncclInt64 : (type == AR_U32 ? ncclUint32 : ncclInt32);
+        ncclResult_t r = ncclAllReduce(buf, buf, count, dt, ncclSum, c.nccl, s);
+        if (r != ncclSuccess) throw std::runtime_error(std::string("ncclAllReduce failed: ") + ncclGetErrorString(r));
+        return;
+    }
+    LocalGroup* g = c.lg;
+    if (c.tmp_bytes < count * esz) { if (c.tmp) (void)hipFree(c.tmp); HIPCHK(hipMalloc(&c.tmp, count * esz)); c.tmp_bytes = count * esz; }
+    HIPCHK(hipStreamSynchronize(s));
+    { std::lock_guard<std::mutex> lk(g->mu); g->ptr[c.rank] = buf; }
+    g->barrier();
+    PtrList pl; for (int r = 0; r < g->nranks; ++r) pl.p[r] = g->ptr[r];
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    if (type == AR_I64) hipLaunchKernelGGL(k_sum_ranks<long long>, dim3(blocks), dim3(256), 0, s, pl, g->nranks, (long long*)c.tmp, count);
+    else if (type == AR_U32) hipLaunchKernelGGL(k_sum_ranks<unsigned int>, dim3(blocks), dim3(256), 0, s, pl, g->nranks, (unsigned int*)c.tmp, count);
+    else hipLaunchKernelGGL(k_sum_ranks<int>, dim3(blocks), dim3(256), 0, s, pl, g->nranks, (int*)c.tmp, count);
+    HIPCHK(hipStreamSynchronize(s));
+    g->barrier();                                   // everyone has read every buffer
+    HIPCHK(hipMemcpyAsync(buf, c.tmp, count * esz, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    g->barrier();
+}
 
 struct Feat { int32_t n_codes = 0, V = 0, has_nan = 0; std::vector<int32_t> ub; };
 struct Tree {
@@ -260,6 +333,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         int gx = (int)std::min<int64_t>((N + 255) / 256, 1024);
         hipLaunchKernelGGL(k_count_codes, dim3(gx, F + 1), dim3(256), 0, s, tab.codes.p, (long long)N, d_ycol, d_cols.p, d_ncod.p, d_cnt_off.p, d_cnt.p);
     }
+    // row-sharded: this table is one rank's row shard (rgbm_params.reserved bit 0 = RGBM_FLAG_ROW_SHARDED)
+    if ((p.reserved & RGBM_FLAG_ROW_SHARDED) && g_comm.kind == 0) throw std::invalid_argument("row-sharded training requested but this thread has no communicator (rgbm_comm_init)");
+    const bool dp = (p.reserved & RGBM_FLAG_ROW_SHARDED) != 0;
+    if (dp) all_reduce(d_cnt.p, (size_t)cnt_off[F + 1], AR_U32, s);
     std::vector<unsigned int> cnt(cnt_off[F + 1]);
     d_cnt.download(cnt.data(), cnt.size(), s);
     HIPCHK(hipStreamSynchronize(s));
@@ -369,6 +446,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     const char* genv = getenv("RGBM_GROWER");
     const bool level_mode = p.max_depth >= 1 && p.max_depth <= LV_MAX_DEPTH && F <= 255 && !(genv && strcmp(genv, "leafwise") == 0);
     const bool use_bagging = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
+    if (dp && (!level_mode || use_bagging || sample_weight_host))
+        throw std::invalid_argument("row-sharded training supports the level grower (1 <= max_depth <= 7) without bagging / per-row weights");
     DevBuf<int32_t> d_base; DevBuf<unsigned int> d_counter(1); d_counter.zero(s);
     if (!level_mode || use_bagging) {
         d_base.alloc(n_train);
@@ -389,7 +468,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     // level grower state
     LevelConst lc; memset(&lc, 0, sizeof(lc));
     DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
-    DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_err, d_leafnode; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
+    DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
     std::vector<int> lv_groups(LV_MAX_DEPTH + 1, 1);
     if (level_mode) {
@@ -415,7 +494,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         d_node_a.alloc((size_t)K * lc.NS); d_node_b.alloc((size_t)K * lc.NS);
         d_plan.alloc(K); d_layout.alloc((size_t)K * nchunk); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
         d_part.alloc((size_t)K * gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
-        d_count.alloc((size_t)K * 256); d_leafnode.alloc((size_t)K * LV_MAX_LEAVES); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
+        d_count.alloc((size_t)K * 256); if (dp) { d_count_g.alloc((size_t)K * 256); d_part_red.alloc((size_t)K * lc.max_built * tc.totbins + (size_t)K * 128 /* K*256 int64 counts */); }
+        d_leafnode.alloc((size_t)K * LV_MAX_LEAVES); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
         for (int level = 1; level < p.max_depth; ++level) {   // worst-case histogram groups of pass `level`
             const int n_exp = 1 << (level - 1);
             long long npg = n_exp;
@@ -539,21 +619,37 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         if (level_mode) {
             d_count.zero(s);
             hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_fmeta.p, d_cmeta.p, n_in_ptr, (long long)n_train, lc);
+            int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
+            // row-sharded: partials of this rank -> compact buffer -> integer all-reduce; the split kernel then sees ONE partial
+            auto exchange = [&](bool root, int nb) -> std::pair<const HistBin*, LevelConst> {
+                if (!dp) return {d_part.p, lc};
+                hipLaunchKernelGGL(k_level_reduce, dim3((tc.totbins + 255) / 256, nb, K), dim3(256), 0, s, d_part.p, d_part_red.p, d_plan.p, d_count.p, root ? 1 : 0, nb, lc);
+                const size_t nh = (size_t)K * nb * tc.totbins * 2;          // int64 words of histograms, then K*256 child counts
+                all_reduce(d_part_red.p, nh + (size_t)K * 256, AR_I64, s);
+                hipLaunchKernelGGL(k_counts_unpack, dim3(K), dim3(256), 0, s, reinterpret_cast<const long long*>(d_part_red.p) + nh, d_count_g.p);
+                LevelConst r = lc; r.gx = 1; r.max_built = nb;
+                return {d_part_red.p, r};
+            };
             launch_pass(true, 1, nchunk);
-            hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, d_part.p, d_lpool.p, d_plan.p, d_snodes.p, d_count.p, d_fmeta.p,
-                               usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, lc);
+            {
+                auto ex = exchange(true, 1);
+                hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p, cntg, d_fmeta.p,
+                                   usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, ex.second);
+            }
             for (int level = 1; level < p.max_depth; ++level) {
                 hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
                 launch_pass(false, 1, nchunk * lv_groups[level]);
-                hipLaunchKernelGGL(k_level_split<false>, dim3((F + 3) / 4, 1 << (level - 1), K), dim3(256), 0, s, d_part.p, d_lpool.p, d_plan.p, d_snodes.p,
-                                   d_count.p, d_fmeta.p, usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, lc);
+                auto ex = exchange(false, 1 << (level - 1));
+                hipLaunchKernelGGL(k_level_split<false>, dim3((F + 3) / 4, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
+                                   cntg, d_fmeta.p, usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, ex.second);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
             hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
-            hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, it, tc);
+            hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, it, tc);
             hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, it, lc);
-            hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, d_count.p, d_leafnode.p, to, it, tc);
+            if (dp) { HIPCHK(hipMemcpyAsync(d_count_g.p, d_count.p, (size_t)K * 256 * 4, hipMemcpyDeviceToDevice, s)); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
+            hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, it, tc);
             continue;
         }
         hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);
@@ -613,8 +709,11 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const bool root_done = n_train >= (int64_t)p.min_data_in_leaf * 2;
             for (int it = 0; it < NE; ++it) for (int k = 0; k < K; ++k) { if (root_done && !use_bagging) root_rows += n_train; stats->trees += 1; }
             if (use_bagging) root_rows = 0;   // bag sizes vary; not tracked separately
-            stats->hist_rows = (int64_t)h_statrows; stats->root_rows = root_rows;
-            stats->hist_bytes = (int64_t)h_statrows * ((int64_t)F + 8);
+            // row-sharded: the device counter sums GLOBAL child counts on every rank; report this rank's share
+            const int64_t rows_acc = dp ? (int64_t)(h_statrows / (unsigned long long)g_comm.nranks) : (int64_t)h_statrows;
+            if (dp) root_rows /= g_comm.nranks;
+            stats->hist_rows = rows_acc; stats->root_rows = root_rows;
+            stats->hist_bytes = rows_acc * ((int64_t)F + 8);
             (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
             return guard.release();
         }
@@ -946,6 +1045,69 @@ RGBM_EXPORT int rgbm_model_load(const void* buf, size_t len, rgbm_model** out) {
             return RGBM_OK;
         } catch (const std::length_error&) { return fail(RGBM_ERR_FORMAT, "rgbm_model_load: truncated buffer"); }
     });
+}
+
+// ---- row-sharded multi-GPU training: communicator of the CALLING THREAD --------------------------------------
+RGBM_EXPORT int rgbm_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(RGBM_ERR_ARG, "rgbm_comm_unique_id: bad argument");
+    return guarded([&]() {
+        static_assert(sizeof(ncclUniqueId) <= RGBM_COMM_ID_BYTES, "ncclUniqueId larger than RGBM_COMM_ID_BYTES");
+        ncclUniqueId id; memset(&id, 0, sizeof(id));
+        ncclResult_t r = ncclGetUniqueId(&id);
+        if (r != ncclSuccess) throw std::runtime_error(std::string("ncclGetUniqueId failed: ") + ncclGetErrorString(r));
+        memset(id_out, 0, RGBM_COMM_ID_BYTES); memcpy(id_out, &id, sizeof(id));
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_comm_init(const void* id, int32_t rank, int32_t nranks, int32_t device_id) {
+    if (!id || rank < 0 || nranks < 1 || rank >= nranks) return fail(RGBM_ERR_ARG, "rgbm_comm_init: bad argument");
+    return guarded([&]() {
+        if (g_comm.kind != 0) throw std::invalid_argument("rgbm_comm_init: this thread already has a communicator");
+        use_device(device_id);
+        ncclUniqueId uid; memcpy(&uid, id, sizeof(uid));
+        ncclComm_t c = nullptr;
+        ncclResult_t r = ncclCommInitRank(&c, nranks, uid, rank);
+        if (r != ncclSuccess) throw std::runtime_error(std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
+        g_comm.kind = 1; g_comm.rank = rank; g_comm.nranks = nranks; g_comm.nccl = c;
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_local_group_create(int32_t nranks, int32_t device_id, void** group_out) {
+    if (!group_out || nranks < 1 || nranks > 16) return fail(RGBM_ERR_ARG, "rgbm_local_group_create: bad argument (1..16 ranks)");
+    return guarded([&]() {
+        use_device(device_id);
+        LocalGroup* g = new LocalGroup(); g->nranks = nranks; g->device = device_id; g->ptr.assign(nranks, nullptr);
+        *group_out = g;
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT void rgbm_local_group_free(void* group) { delete static_cast<LocalGroup*>(group); }
+
+RGBM_EXPORT int rgbm_comm_init_local(void* group, int32_t rank) {
+    LocalGroup* g = static_cast<LocalGroup*>(group);
+    if (!g || rank < 0 || rank >= g->nranks) return fail(RGBM_ERR_ARG, "rgbm_comm_init_local: bad argument");
+    return guarded([&]() {
+        if (g_comm.kind != 0) throw std::invalid_argument("rgbm_comm_init_local: this thread already has a communicator");
+        use_device(g->device);
+        g_comm.kind = 2; g_comm.rank = rank; g_comm.nranks = g->nranks; g_comm.lg = g;
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_comm_finalize(void) {
+    if (g_comm.kind == 1 && g_comm.nccl) (void)ncclCommDestroy(g_comm.nccl);
+    if (g_comm.tmp) (void)hipFree(g_comm.tmp);
+    g_comm = Comm();
+    return RGBM_OK;
+}
+
+RGBM_EXPORT int rgbm_comm_info(int32_t* info) {
+    if (!info) return fail(RGBM_ERR_ARG, "rgbm_comm_info: bad argument");
+    info[0] = g_comm.kind; info[1] = g_comm.rank; info[2] = g_comm.nranks;
+    return RGBM_OK;
 }
 
 RGBM_EXPORT void rgbm_model_free(rgbm_model* m) { delete m; }

@@ -459,6 +459,35 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
 #undef LV_FLAG_STORE
 
 // ------------------------------------------------------------------------------------------------
+// k_level_reduce (row-sharded multi-GPU training only): sum the gx workgroup partials of every built child into
+// one compact [K][nb][totbins] buffer, which is then all-reduced (exact integer sums) across the ranks.
+// grid (ceil(totbins/256), nb, K), block 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_reduce(const HistBin* __restrict__ part, HistBin* __restrict__ red, const LvPlan* __restrict__ plan,
+                                                      const int32_t* __restrict__ count, int is_root, int nb, LevelConst c) {
+    const int k = blockIdx.z, bslot = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    // the local child counts ride in the same all-reduce, as int64 words behind the histograms
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        reinterpret_cast<long long*>(red + (long long)c.K * nb * c.totbins)[(long long)k * 256 + threadIdx.x] = (long long)count[(long long)k * 256 + threadIdx.x];
+    if (b >= c.totbins) return;
+    const LvPlan* pp = &plan[k];
+    HistBin acc; acc.g = 0; acc.h = 0;
+    const int n_built = pp->done ? 0 : (is_root ? 1 : pp->n_built);
+    if (bslot < n_built) {
+        for (int x = 0; x < c.gx; ++x) {
+            const HistBin v = part[(((long long)k * c.gx + x) * c.max_built + bslot) * c.totbins + b];
+            acc.g += v.g; acc.h += v.h;
+        }
+    }
+    red[((long long)k * nb + bslot) * c.totbins + b] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_counts_unpack(const long long* __restrict__ cnt64, int32_t* __restrict__ count_g) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    count_g[i] = (int32_t)cnt64[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_level_split: sum the workgroup partials of the built child, derive the sibling by subtraction,
 // scan both (FindBestThreshold).  grid (ceil(F/4), ROOT ? 1 : max parents, K), block 256.
 // ------------------------------------------------------------------------------------------------

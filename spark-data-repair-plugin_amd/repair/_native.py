@@ -44,8 +44,14 @@ PARAM_DEFAULTS = dict(objective=1, num_class=2, n_estimators=300, num_leaves=31,
                       min_sum_hessian_in_leaf=1e-3, bagging_fraction=1.0, feature_fraction=1.0)
 
 
+FLAG_ROW_SHARDED = 1
+
+
 def make_params(**kw):
     d = dict(PARAM_DEFAULTS)
+    kw = dict(kw)
+    if kw.pop("row_sharded", False):
+        d["reserved"] = d.get("reserved", 0) | FLAG_ROW_SHARDED
     for k, v in kw.items():
         if k not in d:
             raise TypeError("unknown parameter %r" % k)
@@ -68,8 +74,11 @@ def lib():
         l.rgbm_last_error.restype = C.c_char_p
         for name in ("rgbm_device_count", "rgbm_version", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
                      "rgbm_table_create", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
-                     "rgbm_model_save", "rgbm_model_load", "rgbm_model_info", "rgbm_model_importance"):
+                     "rgbm_model_save", "rgbm_model_load", "rgbm_model_info", "rgbm_model_importance",
+                     "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
+                     "rgbm_local_group_create", "rgbm_comm_init_local"):
             getattr(l, name).restype = C.c_int
+        l.rgbm_local_group_free.restype = None
         l.rgbm_table_free.restype = None
         l.rgbm_model_free.restype = None
         _lib = l
@@ -80,7 +89,52 @@ EXPORTED_SYMBOLS = [
     "rgbm_device_count", "rgbm_last_error", "rgbm_version", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
     "rgbm_table_create", "rgbm_table_free", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
     "rgbm_model_save", "rgbm_model_load", "rgbm_model_free", "rgbm_model_info", "rgbm_model_importance",
+    "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
+    "rgbm_local_group_create", "rgbm_local_group_free", "rgbm_comm_init_local",
 ]
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 opaque bytes (an ncclUniqueId) created on one rank; every rank passes them to ``comm_init``."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(lib().rgbm_comm_unique_id(buf), "rgbm_comm_unique_id")
+    return bytes(buf)
+
+
+def comm_init(uid, rank, nranks, device_id=0):
+    """RCCL communicator of the calling thread for row-sharded training (include/rgbm.h)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+    _check(lib().rgbm_comm_init(buf, C.c_int32(rank), C.c_int32(nranks), C.c_int32(device_id)), "rgbm_comm_init")
+
+
+def comm_finalize():
+    _check(lib().rgbm_comm_finalize(), "rgbm_comm_finalize")
+
+
+def comm_info():
+    a = np.zeros(3, np.int32)
+    _check(lib().rgbm_comm_info(_p(a, C.c_int32)), "rgbm_comm_info")
+    return dict(kind=int(a[0]), rank=int(a[1]), nranks=int(a[2]))
+
+
+class LocalGroup:
+    """Test transport: ``nranks`` host threads of this process act as the ranks of a row-sharded job on one device."""
+
+    def __init__(self, nranks, device_id=0):
+        self.h = C.c_void_p()
+        _check(lib().rgbm_local_group_create(C.c_int32(nranks), C.c_int32(device_id), C.byref(self.h)), "rgbm_local_group_create")
+        self.nranks = nranks
+
+    def join(self, rank):
+        """Call from the thread that plays ``rank``; pair with ``comm_finalize()`` in the same thread."""
+        _check(lib().rgbm_comm_init_local(self.h, C.c_int32(rank)), "rgbm_comm_init_local")
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None:
+            _lib.rgbm_local_group_free(h)
 
 
 def _check(rc, what):

@@ -38,6 +38,10 @@ class HipEngine:
     def train(self, table, target, feats, class_weight, params, y_value=None, want_stats=False):
         return table.train(target, feats, y_value=y_value, class_weight=class_weight, want_stats=want_stats, **params)
 
+    def train_row_sharded(self, shard_table, target, feats, class_weight, params, y_value=None, want_stats=False):
+        """Collective: every rank calls this for the same target with its own row shard (needs dist.init_row_comm)."""
+        return shard_table.train(target, feats, y_value=y_value, class_weight=class_weight, want_stats=want_stats, row_sharded=True, **params)
+
     def load_model(self, blob):
         return _native.Model.load(blob)
 
@@ -52,11 +56,14 @@ def model_params(n_classes, base):
     return p
 
 
-def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, base_params, want_stats=False):
+def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, base_params, want_stats=False, row_table=None,
+            force_row_sharding=False):
     """Train + repair, sharded over the ranks of the current torch.distributed group (if any).
 
     train_table / dirty_table : engine tables (all rows with error cells NULLed / the dirty rows)
-    label_counts[t]           : per-code row counts of target t over its non-NULL rows
+    label_counts[t]           : per-code row counts of target t over its non-NULL rows (GLOBAL counts)
+    row_table                 : this rank's row shard of the training table; when given (and more than one rank),
+                                the expensive targets are trained row-sharded over ALL ranks (dist.split_targets)
     Returns dict(labels [T][D], probs [T][D], models {target: bytes}, times, stats).
     """
     rank, ws = dist.world()
@@ -65,22 +72,30 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     for t in targets:
         k = int(n_codes[t])
         costs.append((t, (1 if k <= 2 else k) * float(np.sum(label_counts[t]))))
-    mine = dist.assign_targets(costs, ws)[rank]
+    big, small = dist.split_targets(costs, ws, row_table is not None, force=force_row_sharding)
+    mine = dist.assign_targets(small, ws)[rank]
     t0 = time.perf_counter()
-    blobs, stats = {}, []
-    for t in mine:
+    blobs, stats, shared = {}, [], {}
+
+    def one(t, table, fn):
         feats = [c for c in range(n_cols) if c != t]
         cw = balanced_class_weight(label_counts[t])
-        res = engine.train(train_table, t, feats, cw, model_params(int(n_codes[t]), base_params), want_stats=want_stats)
+        res = fn(table, t, feats, cw, model_params(int(n_codes[t]), base_params), want_stats=want_stats)
         if want_stats:
             res, st = res
             st["target"] = t
             stats.append(st)
-        blobs[t] = res.save()
+        return res.save()
+
+    for t, _ in big:                      # collective: same order on every rank, identical model everywhere
+        shared[t] = one(t, row_table, engine.train_row_sharded)
+    for t in mine:
+        blobs[t] = one(t, train_table, engine.train)
     t_train = time.perf_counter() - t0
     # C1: all-gather of the serialised models (Spark broadcast, model.py:1069)
     t0 = time.perf_counter()
     all_blobs = dist.exchange_blobs(blobs)
+    all_blobs.update(shared)
     models = [engine.load_model(all_blobs[t]) for t in targets]
     t_xchg = time.perf_counter() - t0
     # data-parallel chained inference on this rank's row shard
@@ -95,5 +110,5 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     labels = dist.gather_rows(lab, D)
     probs = dist.gather_rows(prob, D) if prob is not None else None
     t_gather = time.perf_counter() - t0
-    return dict(labels=labels, probs=probs, models=all_blobs, stats=stats, my_targets=mine,
+    return dict(labels=labels, probs=probs, models=all_blobs, stats=stats, my_targets=mine, row_sharded_targets=[t for t, _ in big],
                 times=dict(train=t_train, exchange=t_xchg, infer=t_infer, gather=t_gather))

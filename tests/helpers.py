@@ -78,6 +78,24 @@ class OracleEngine:
                     int(table.n_codes[target]), y_value=y_value, class_weight=class_weight, **p)
         return (m, {"hist_ms": 0.0, "hist_bytes": 0, "hist_launches": 0, "root_ms": 0.0, "root_rows": 0}) if want_stats else m
 
+    def train_row_sharded(self, shard_table, target, feats, class_weight, params, y_value=None, want_stats=False):
+        """CPU stand-in for the collective: all-gather the row shards (so every rank must take part, in the same
+        order) and train on their concatenation -- the product's row-sharded HIP training gives exactly the
+        single-device model (tests/test_gpu_rowshard.py), which is what this returns."""
+        import torch
+        import torch.distributed as dist
+        ws = dist.get_world_size()
+        n = torch.tensor([shard_table.n], dtype=torch.int64)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(ws)]
+        dist.all_gather(sizes, n)
+        mx = int(max(int(x.item()) for x in sizes))
+        pad = np.full((shard_table.c, mx), -1, np.int32)
+        pad[:, :shard_table.n] = shard_table.codes
+        outs = [torch.zeros((shard_table.c, mx), dtype=torch.int32) for _ in range(ws)]
+        dist.all_gather(outs, torch.from_numpy(pad))
+        full = np.concatenate([outs[r].numpy()[:, :int(sizes[r].item())] for r in range(ws)], axis=1)
+        return self.train(OracleEngine._Table(full, shard_table.n_codes), target, feats, class_weight, params, y_value=y_value, want_stats=want_stats)
+
     def load_model(self, blob):
         from oracle import oracle as O
         return O.OracleModel.load(blob)

@@ -17,7 +17,8 @@ PARAMS = dict(num_leaves=15, max_depth=7, max_bin=255, min_data_in_leaf=20, min_
               bagging_fraction=1.0, feature_fraction=1.0, n_estimators=6)
 
 
-def _job():
+def _job(hybrid=False):
+    from repair import dist as rdist
     from repair.engine import run_job
     from tests.helpers import OracleEngine
     dirty, clean, cards = make_table(6000, 6, seed=21, null_ratio=0.03)
@@ -25,18 +26,24 @@ def _job():
     counts = {t: np.bincount(dirty[t][dirty[t] >= 0], minlength=int(cards[t])) for t in targets}
     mask = (dirty[targets] < 0).any(axis=0)
     eng = OracleEngine()
-    res = run_job(eng, eng.upload(dirty, cards), eng.upload(np.ascontiguousarray(dirty[:, mask]), cards), cards, targets, counts, PARAMS)
+    row_table = None
+    if hybrid:
+        rank, ws = rdist.world()
+        b, c = rdist.shard_rows(dirty.shape[1], ws, rank)
+        row_table = eng.upload(np.ascontiguousarray(dirty[:, b:b + c]), cards)
+    res = run_job(eng, eng.upload(dirty, cards), eng.upload(np.ascontiguousarray(dirty[:, mask]), cards), cards, targets, counts, PARAMS,
+                  row_table=row_table)
     return res
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, hybrid=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spark-data-repair-plugin_amd"))
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _job()
-        q.put((rank, res["labels"], res["probs"], sorted(res["models"].items()), res["my_targets"]))
+        res = _job(hybrid)
+        q.put((rank, res["labels"], res["probs"], sorted(res["models"].items()), res["my_targets"] + res["row_sharded_targets"]))
     finally:
         dist.destroy_process_group()
 
@@ -69,3 +76,33 @@ def test_two_rank_gloo_job_equals_single_process():
         assert np.array_equal(labels, single["labels"])
         assert np.array_equal(probs, single["probs"])
         assert models == sorted(single["models"].items())
+
+
+def test_split_targets_rule():
+    from repair import dist
+    costs = [(0, 1), (1, 3), (2, 4), (3, 6), (4, 8), (5, 12), (6, 16), (7, 24), (8, 32), (9, 48), (10, 64)]
+    big, small = dist.split_targets(costs, 8, True)            # fair share 218/8, threshold half of it
+    assert [t for t, _ in big] == [6, 7, 8, 9, 10] and [t for t, _ in small] == [0, 1, 2, 3, 4, 5]
+    assert dist.split_targets(costs, 8, False) == ([], costs) and dist.split_targets(costs, 1, True) == ([], costs)
+
+
+def test_two_rank_gloo_hybrid_job_equals_single_process():
+    """Expensive targets row-sharded over both ranks (collective), cheap ones target-sharded."""
+    import torch.multiprocessing as mp
+    single = _job()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, labels, probs, models, trained in outs:
+        assert np.array_equal(labels, single["labels"])
+        assert np.array_equal(probs, single["probs"])
+        assert models == sorted(single["models"].items())
+    # at least one target went through the collective path on both ranks
+    assert set(outs[0][4]) & set(outs[1][4])

@@ -1,0 +1,111 @@
+"""-m gpu: row-sharded (data-parallel) training == single-device training, bit for bit.
+
+Every rank holds a row shard and the ranks exchange integer all-reduces only (code counts, per-level
+histograms, child counts), so the model must not depend on the number of ranks or on the split.
+A real multi-GPU run needs one process per GPU (RCCL); the box the tests run on has ONE GPU, so the
+sharding logic is exercised with the in-process thread-group transport (one rank per host thread on
+the same device) and the RCCL transport with a world of one.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from tests.synth import make_table, balanced_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _train_sharded(dirty, cards, bounds, target, feats, cw, kw):
+    from repair import _native as N
+    nr = len(bounds) - 1
+    group = N.LocalGroup(nr)
+    out, err = [None] * nr, [None] * nr
+
+    def work(r):
+        try:
+            group.join(r)
+            try:
+                tab = N.Table(np.ascontiguousarray(dirty[:, bounds[r]:bounds[r + 1]]), cards)
+                out[r] = tab.train(target, feats, class_weight=cw, row_sharded=True, **kw).save()
+            finally:
+                N.comm_finalize()
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(nr)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=600)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("target,bounds", [(4, [0, 9000, 20000]), (5, [0, 3000, 3500, 14000, 20000]), (0, [0, 1, 20000])])
+def test_thread_group_shards_give_the_single_device_model(target, bounds):
+    from repair import _native as N
+    dirty, clean, cards = make_table(20000, 8, seed=71, null_ratio=0.02)
+    feats = [c for c in range(8) if c != target]
+    K = int(cards[target])
+    cw = balanced_weights(dirty[target], K)
+    kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=8, learning_rate=0.2)
+    single = N.Table(dirty, cards).train(target, feats, class_weight=cw, **kw).save()
+    shards = _train_sharded(dirty, cards, bounds, target, feats, cw, kw)
+    for r, b in enumerate(shards):
+        assert b == single, "rank %d of %d differs from the single-device model" % (r, len(shards))
+
+
+def test_two_chunks_and_many_bins_sharded():
+    from repair import _native as N
+    rng = np.random.default_rng(73)
+    n = 24000
+    z = rng.integers(0, 120, n)
+    X = np.stack([((z * (j + 1) + rng.integers(0, 9, n)) % (20 + 11 * j)).astype(np.int32) for j in range(19)])
+    y = ((z // 10 + X[3] % 3) % 5).astype(np.int32)
+    tab = np.ascontiguousarray(np.vstack([X, y[None, :]]))
+    cards = np.asarray([20 + 11 * j for j in range(19)] + [5], np.int32)
+    cw = balanced_weights(y, 5)
+    kw = dict(objective=1, num_class=5, n_estimators=4, learning_rate=0.3)
+    feats = list(range(19))
+    single = N.Table(tab, cards).train(19, feats, class_weight=cw, **kw).save()
+    for b in _train_sharded(tab, cards, [0, 7000, 15000, 24000], 19, feats, cw, kw):
+        assert b == single
+
+
+def test_rccl_world_of_one():
+    from repair import _native as N
+    dirty, clean, cards = make_table(12000, 6, seed=79)
+    t = 3
+    feats = [c for c in range(6) if c != t]
+    K = int(cards[t])
+    cw = balanced_weights(dirty[t], K)
+    kw = dict(objective=1, num_class=K, n_estimators=5, learning_rate=0.2)
+    single = N.Table(dirty, cards).train(t, feats, class_weight=cw, **kw).save()
+    N.comm_init(N.comm_unique_id(), 0, 1, 0)
+    try:
+        assert N.comm_info() == dict(kind=1, rank=0, nranks=1)
+        sharded = N.Table(dirty, cards).train(t, feats, class_weight=cw, row_sharded=True, **kw).save()
+        local = N.Table(dirty, cards).train(t, feats, class_weight=cw, **kw).save()   # same thread, flag off: plain local training
+        assert local == single
+    finally:
+        N.comm_finalize()
+    assert sharded == single
+    assert N.comm_info()["kind"] == 0
+
+
+def test_row_sharded_rejects_bagging_and_leafwise():
+    from repair import _native as N
+    dirty, clean, cards = make_table(4000, 5, seed=83)
+    group = N.LocalGroup(1)
+    group.join(0)
+    try:
+        tab = N.Table(dirty, cards)
+        with pytest.raises(N.RepairGbmError):
+            tab.train(1, [0, 2, 3, 4], objective=1, num_class=int(cards[1]), n_estimators=2, bagging_fraction=0.5, bagging_freq=1, row_sharded=True)
+        with pytest.raises(N.RepairGbmError):
+            tab.train(1, [0, 2, 3, 4], objective=1, num_class=int(cards[1]), n_estimators=2, max_depth=-1, row_sharded=True)
+    finally:
+        N.comm_finalize()
