@@ -197,7 +197,6 @@ def main():
     sys.stdout.flush(); sys.stderr.flush()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    os._exit(0)
 
 
 if __name__ == "__main__":

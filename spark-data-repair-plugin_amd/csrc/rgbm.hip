@@ -640,7 +640,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
                 launch_pass(false, 1, nchunk * lv_groups[level]);
                 auto ex = exchange(false, 1 << (level - 1));
-                hipLaunchKernelGGL(k_level_split<false>, dim3((F + 3) / 4, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
+                hipLaunchKernelGGL(k_level_split<false>, dim3((F + 1) / 2, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
                                    cntg, d_fmeta.p, usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, ex.second);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass

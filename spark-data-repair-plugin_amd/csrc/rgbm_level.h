@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_counts_unpack(const long long* __restri
 
 // ------------------------------------------------------------------------------------------------
 // k_level_split: sum the workgroup partials of the built child, derive the sibling by subtraction,
-// scan both (FindBestThreshold).  grid (ceil(F/4), ROOT ? 1 : max parents, K), block 256.
+// scan both (FindBestThreshold).  grid (ROOT ? ceil(F/4) : ceil(F/2), ROOT ? 1 : max parents, K), block 256.
 // ------------------------------------------------------------------------------------------------
 template <bool ROOT>
 __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__ part, HistBin* __restrict__ pool, LvPlan* __restrict__ plan,
@@ -498,7 +498,11 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
                                                      Cand* __restrict__ cand /* [K][256][F] */, unsigned long long* __restrict__ stat_rows,
                                                      int n_hnodes, TrainConst c, LevelConst lc) {
     const int k = blockIdx.z, pi = blockIdx.y;
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // ROOT: one wave per feature (4 per block).  Otherwise one wave per (feature, child side): 2 features per block,
+    // so the two FindBestThreshold scans of a parent run side by side instead of back to back.
+    const int wv = threadIdx.x >> 6;
+    const int f = ROOT ? blockIdx.x * 4 + wv : blockIdx.x * 2 + (wv >> 1);
+    const int side = wv & 1;   // 0 = left child, 1 = right child
     const LvPlan* pp = &plan[k];
     if (pp->done) return;
     if (!ROOT && pi >= pp->n_exp) return;
@@ -535,38 +539,31 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
     const SNode P = nk[p];
     const int l = P.left, r = P.right;
     const bool bl = pp->built_is_left[pi] != 0;
-    const int hs_l = nk[l].hslot, hs_r = nk[r].hslot;
+    const int me = side == 0 ? l : r;
+    const bool i_am_built = (side == 0) == bl;
     const HistBin* hp = pk + (long long)P.hslot * c.totbins + fm.hoff;
-    HistBin* hl = pk + (long long)hs_l * c.totbins + fm.hoff;
-    HistBin* hr = pk + (long long)hs_r * c.totbins + fm.hoff;
-    long long bg[4], bh[4];   // the sibling
+    HistBin* hm = pk + (long long)nk[me].hslot * c.totbins + fm.hoff;
+    if (!i_am_built) {   // the sibling: parent - built (exact integers)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = lane * 4 + j;
-        if (b < fm.nbins) {
-            const HistBin par = hp[b];
-            bg[j] = par.g - ag[j]; bh[j] = par.h - ah[j];
-            HistBin built, sib; built.g = ag[j]; built.h = ah[j]; sib.g = bg[j]; sib.h = bh[j];
-            if (bl) { hl[b] = built; hr[b] = sib; } else { hr[b] = built; hl[b] = sib; }
-        } else { bg[j] = 0; bh[j] = 0; }
+        for (int j = 0; j < 4; ++j) {
+            const int b = lane * 4 + j;
+            if (b < fm.nbins) { const HistBin par = hp[b]; ag[j] = par.g - ag[j]; ah[j] = par.h - ah[j]; } else { ag[j] = 0; ah[j] = 0; }
+        }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int b = lane * 4 + j; if (b < fm.nbins) { HistBin v; v.g = ag[j]; v.h = ah[j]; hm[b] = v; } }
     const int nl = count[(long long)k * 256 + l], nr = count[(long long)k * 256 + r];
     // SerialTreeLearner::BeforeFindBestSplit: both children too small -> neither is searched
     const bool go = !(nr < c.min_data_in_leaf * 2 && nl < c.min_data_in_leaf * 2);
     if (f == 0 && lane == 0) {
-        nk[l].count = nl; nk[r].count = nr; nk[l].searched = go ? 1 : 0; nk[r].searched = go ? 1 : 0;
-        atomicAdd(stat_rows, (unsigned long long)(bl ? nl : nr));
+        nk[me].count = side == 0 ? nl : nr; nk[me].searched = go ? 1 : 0;
+        if (side == 0) atomicAdd(stat_rows, (unsigned long long)(bl ? nl : nr));
     }
     if (!go) return;
-    if (!is_used) { if (lane == 0) { ck[(long long)l * c.F + f].gain = -INFINITY; ck[(long long)r * c.F + f].gain = -INFINITY; } return; }
+    if (!is_used) { if (lane == 0) ck[(long long)me * c.F + f].gain = -INFINITY; return; }
     const long long lGq = P.best.left_gq, lHq = P.best.left_hq;
-    if (bl) {
-        scan_child(ag, ah, fm, lGq, lHq, (long long)nl, c, &ck[(long long)l * c.F + f]);
-        scan_child(bg, bh, fm, P.Gq - lGq, P.Hq - lHq, (long long)nr, c, &ck[(long long)r * c.F + f]);
-    } else {
-        scan_child(bg, bh, fm, lGq, lHq, (long long)nl, c, &ck[(long long)l * c.F + f]);
-        scan_child(ag, ah, fm, P.Gq - lGq, P.Hq - lHq, (long long)nr, c, &ck[(long long)r * c.F + f]);
-    }
+    if (side == 0) scan_child(ag, ah, fm, lGq, lHq, (long long)nl, c, &ck[(long long)l * c.F + f]);
+    else scan_child(ag, ah, fm, P.Gq - lGq, P.Hq - lHq, (long long)nr, c, &ck[(long long)r * c.F + f]);
 }
 
 // ------------------------------------------------------------------------------------------------
