@@ -37,40 +37,43 @@ BASE_PARAMS = dict(num_leaves=31, max_depth=7, max_bin=255, min_data_in_leaf=20,
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(rows, cols, steps_full, budget_s=20.0):
-    """Oracle (kind "port", 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(rows, cols, steps_full, budget_s=25.0):
+    """Oracle (kind "port": the plain-C restatement of the LightGBM path) on a bounded sample of the same workload.
+    One target attribute per host thread (the oracle releases the GIL), like the reference's per-target parallel
+    mode; the chained repair is single-threaded like one Spark task."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     from repair.engine import balanced_class_weight
-    n = min(rows, 60_000)
+    n = min(rows, 250_000)
     iters = 10
     dirty, clean, cards = make_table(n, cols, seed=42)
-    t_train = t_infer = 0.0
-    models, feats_l, done = [], [], []
-    t_begin = time.perf_counter()
-    for t in range(cols):
+    cores = max(1, min(cols, os.cpu_count() or 1))
+
+    def fit(t):
         feats = [c for c in range(cols) if c != t]
         r = dirty[t] >= 0
         K = int(cards[t])
         cw = balanced_class_weight(np.bincount(dirty[t][r], minlength=K))
-        t0 = time.perf_counter()
-        m = O.train(np.ascontiguousarray(dirty[feats][:, r]), cards[feats], dirty[t][r], K, class_weight=cw,
-                    objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=iters,
-                    **{k: v for k, v in BASE_PARAMS.items()})
-        t_train += time.perf_counter() - t0
-        models.append(m); feats_l.append(feats); done.append(t)
-        if time.perf_counter() - t_begin > budget_s:
-            break
-    mask = (dirty[done] < 0).any(axis=0) if len(done) else np.zeros(n, bool)
+        return O.train(np.ascontiguousarray(dirty[feats][:, r]), cards[feats], dirty[t][r], K, class_weight=cw,
+                       objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=iters, **{k: v for k, v in BASE_PARAMS.items()})
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        models = list(ex.map(fit, range(cols)))
+    t_train = time.perf_counter() - t0
+    done = list(range(cols))
+    feats_l = [[c for c in range(cols) if c != t] for t in done]
+    mask = (dirty[done] < 0).any(axis=0)
     dr = np.ascontiguousarray(dirty[:, mask])
     cells = int((dr[done] < 0).sum())
     t0 = time.perf_counter()
     O.repair_chain(models, done, feats_l, [list(range(int(cards[t]))) for t in done], dr)
     t_infer = time.perf_counter() - t0
     scale = steps_full / float(iters)
-    value = cells / max((t_train + t_infer) * scale, 1e-9)
-    return dict(value=value, unit="repaired cells/sec", cores=1, kind="port",
-                sample="%d-row subsample x %d cols, targets %s of %d, %d of %d boosting iterations timed "
-                       "(train %.2fs + repair %.2fs), time scaled x%.1f" % (n, cols, done, cols, iters, steps_full, t_train, t_infer, scale))
+    value = cells / max(t_train * scale + t_infer * scale, 1e-9)
+    return dict(value=value, unit="repaired cells/sec", cores=cores, kind="port",
+                sample="%d-row subsample x %d cols, all %d targets (one per host thread, %d threads), %d of %d boosting iterations timed "
+                       "(train %.2fs wall + repair %.2fs), time scaled x%.1f" % (n, cols, cols, cores, iters, steps_full, t_train, t_infer, scale))
 
 
 def main():
