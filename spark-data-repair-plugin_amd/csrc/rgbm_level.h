@@ -321,29 +321,35 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
                 const unsigned o = (unsigned)(s * LV_THREADS + tid);
                 const int n = cur_n[s];
                 if (ROOT) { accumulate(n != LV_INACTIVE, 0, cur_r[s], cur_g[s]); continue; }
-                int li = -1;
                 const bool inrange = p0 + o < N;
-                int child = n;
-                if (n != LV_INACTIVE) {
-                    const uint2 e = route[n];
-                    if (e.x & (1u << 24)) {
-                        const unsigned f = e.x & 0xFFu;
-                        unsigned bin;
-                        if (!MULTI || (f >> 4) == (unsigned)ch) {
-                            // byte (f & 15) of the 16-byte record: pick the 8-byte half (2 v_cndmask), then one v_perm_b32
+                // branch-free routing (for !MULTI): route[255] is never expanded, so inactive rows fall through as
+                // "not expanded"; a lane's work is paid by its whole wave anyway, only the exec-mask juggling goes away
+                const uint2 e = route[n];
+                const bool expd = (e.x & (1u << 24)) != 0u;
+                const unsigned f = e.x & 0xFFu;
+                unsigned bin;
+                if (!MULTI) {
+                    const bool hi = (f & 8u) != 0u;
+                    const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
+                    const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
+                    bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
+                } else {
+                    bin = 0;
+                    if (expd) {
+                        if ((f >> 4) == (unsigned)ch) {
                             const bool hi = (f & 8u) != 0u;
                             const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
                             const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
                             bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
                         } else bin = rec8[((long long)(f >> 4) * N + p0 + o) * 16 + (f & 15u)];
-                        const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
-                        const unsigned sel = left ? e.y : (e.y >> 8);      // child in bits 0..7, built slot in bits 16..23
-                        child = (int)(sel & 0xFFu);
-                        const int bs = (int)((sel >> 16) & 0xFFu);
-                        if (writer && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                        if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
                     }
                 }
+                const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
+                const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, built slot in bits 16..23
+                const int child = expd ? (int)(sel & 0xFFu) : n;
+                const int bs = expd ? (int)((sel >> 16) & 0xFFu) : 0xFF;
+                if (writer && expd && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                const int li = (bs != 0xFF && bs >= g0 && bs - g0 < ng) ? bs - g0 : -1;
                 if (writer && inrange && !(dbg & 4)) ob_[o] = (uint8_t)child;
                 if (ng > 0) accumulate(li >= 0, li, cur_r[s], cur_g[s]);
             }
