@@ -575,18 +575,18 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
 // ------------------------------------------------------------------------------------------------
 // k_level_plan: one wave per class tree, before pass `level` (which routes depth level-1 -> level).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_level_plan(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, SNode* __restrict__ nodes,
-                                                   const Cand* __restrict__ cand, const FeatMeta* __restrict__ fmeta,
-                                                   const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc) {
+__global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, SNode* __restrict__ nodes,
+                                                    const Cand* __restrict__ cand, const FeatMeta* __restrict__ fmeta,
+                                                    const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc) {
     __shared__ double pm[256];
-    const int k = blockIdx.x, lane = lane_id();
+    const int k = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
     LvPlan* pp = &plan[k];
     if (pp->done) return;
     SNode* nk = nodes + (long long)k * 256;
     const Cand* ck = cand + (long long)k * 256 * c.F;
     const int first = pp->lvl_first, end = pp->lvl_end, nlev = end - first;   // nodes of depth level-1 (<= 64)
-    // 1. best split of every node of the level (SplitInfo::operator>: gain, then smaller feature)
-    for (int n = first; n < end; ++n) {
+    // 1. best split of every node of the level (SplitInfo::operator>: gain, then smaller feature); one wave per node, 4 at a time
+    for (int n = first + wave; n < end; n += 4) {
         if (!nk[n].searched) { if (lane == 0) { nk[n].best.gain = -INFINITY; nk[n].best_feature = -1; } continue; }
         const Cand* cf = ck + (long long)n * c.F;
         double bg = -INFINITY; int bf = -1;
@@ -598,6 +598,7 @@ __global__ __launch_bounds__(64) void k_level_plan(LvPlan* __restrict__ plan, Lv
         }
     }
     __syncthreads();
+    if (wave != 0) return;   // the rest is one wave's work (the barriers below only count live waves)
     // 2. path-min gains
     for (int n = lane; n < first; n += 64) pm[n] = nk[n].pmin;
     __syncthreads();
@@ -706,16 +707,33 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
     const long long nb = tbase * (c.num_leaves - 1);
     double* lv = out.leaf_value + tbase * c.num_leaves;
     const int n_nodes = pp->n_nodes;
-    for (int i = lane; i < 256; i += 64) node_leaf[i] = -1;
-    if (lane == 0) { leaf_node[0] = 0; leaf_parent[0] = -1; leaf_isleft[0] = 0; node_leaf[0] = 0; }
+    // the whole selection loop runs out of LDS: one coalesced sweep over the speculative nodes first
+    __shared__ double s_gain[256], s_lout[256], s_rout[256], s_lv[LV_MAX_LEAVES];
+    __shared__ int s_feat[256], s_theta[256];
+    __shared__ short s_left[256], s_right[256], s_parent[256];
+    __shared__ unsigned char s_dleft[256];
+    for (int n = lane; n < 256; n += 64) {
+        node_leaf[n] = -1;
+        if (n < n_nodes) {
+            const SNode& sn = nk[n];
+            const bool se = sn.searched != 0;
+            s_gain[n] = se ? sn.best.gain : -INFINITY; s_feat[n] = se ? sn.best_feature : -1;
+            s_theta[n] = sn.best.theta; s_dleft[n] = (unsigned char)(sn.best.dleft ? 1 : 0);
+            s_lout[n] = sn.best.left_out; s_rout[n] = sn.best.right_out;
+            s_left[n] = (short)sn.left; s_right[n] = (short)sn.right; s_parent[n] = (short)sn.parent;
+        }
+    }
+    if (lane == 0) { leaf_node[0] = 0; leaf_parent[0] = -1; leaf_isleft[0] = 0; }
+    __syncthreads();
+    if (lane == 0) node_leaf[0] = 0;
     __syncthreads();
     int L = 1;
     const int max_leaves = c.num_leaves < LV_MAX_LEAVES ? c.num_leaves : LV_MAX_LEAVES;
     while (L < max_leaves) {
         double bg = -INFINITY; int bf = -1, bl = 0x7FFFFFFF;
         for (int l = lane; l < L; l += 64) {
-            const SNode& s = nk[leaf_node[l]];
-            const double g = s.searched ? s.best.gain : -INFINITY; const int f = s.searched ? s.best_feature : -1;
+            const int sn = leaf_node[l];
+            const double g = s_gain[sn]; const int f = s_feat[sn];
             if (bl == 0x7FFFFFFF || leaf_better(g, f, l, bg, bf, bl)) { bg = g; bf = f; bl = l; }
         }
 #pragma unroll
@@ -725,18 +743,19 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
         }
         if (!(bg > 0.0)) break;
         const int sn = leaf_node[bl];
-        const SNode S = nk[sn];
-        if (S.left < 0) { if (lane == 0) { pp->error = 1; atomicOr(err_flag, 1); } break; }   // the expansion bound was violated (must never happen)
+        const int sl = s_left[sn], sr = s_right[sn];
+        if (sl < 0) { if (lane == 0) { pp->error = 1; atomicOr(err_flag, 1); } break; }   // the expansion bound was violated (must never happen)
         const int node = L - 1, right_leaf = L;
+        __syncthreads();   // every lane has read leaf_node[] before lane 0 rewrites it
         if (lane == 0) {
-            out.feat[nb + node] = bf; out.theta[nb + node] = S.best.theta; out.dleft[nb + node] = S.best.dleft; out.gain[nb + node] = S.best.gain;
+            out.feat[nb + node] = bf; out.theta[nb + node] = s_theta[sn]; out.dleft[nb + node] = (int)s_dleft[sn]; out.gain[nb + node] = s_gain[sn];
             out.left[nb + node] = ~bl; out.right[nb + node] = ~right_leaf;
             const int pn = leaf_parent[bl];
             if (pn >= 0) { if (leaf_isleft[bl]) out.left[nb + pn] = node; else out.right[nb + pn] = node; }
-            lv[bl] = S.best.left_out; lv[right_leaf] = S.best.right_out;
-            leaf_node[bl] = S.left; leaf_node[right_leaf] = S.right;
+            s_lv[bl] = s_lout[sn]; s_lv[right_leaf] = s_rout[sn];
+            leaf_node[bl] = sl; leaf_node[right_leaf] = sr;
             leaf_parent[bl] = node; leaf_isleft[bl] = 1; leaf_parent[right_leaf] = node; leaf_isleft[right_leaf] = 0;
-            node_leaf[S.left] = bl; node_leaf[S.right] = right_leaf;
+            node_leaf[sl] = bl; node_leaf[sr] = right_leaf;
         }
         ++L;
         __syncthreads();
@@ -752,7 +771,7 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
     }
     if (lane == 0) atomicOr(any_split + it, 1);
     for (int l = lane; l < L; l += 64) {
-        double v = lv[l] * c.learning_rate;    // Tree::Shrinkage
+        double v = s_lv[l] * c.learning_rate;    // Tree::Shrinkage
         upd[l] = v;
         if (it == 0 && fabs(init[k]) > k_eps()) v += init[k];   // Tree::AddBias (model only; scores already hold init)
         lv[l] = v;
@@ -763,7 +782,7 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
         double d = 0.0;
         if (n < n_nodes) {
             int a = n;
-            while (a >= 0 && node_leaf[a] < 0) a = nk[a].parent;
+            while (a >= 0 && node_leaf[a] < 0) a = s_parent[a];
             // a split node's own entry is overwritten by its children only when it was split in the final tree;
             // node_leaf of a split node still names the leaf index its LEFT child inherited, so walk DOWN is never needed:
             // rows only ever sit in the deepest expanded node, whose nearest assigned ancestor-or-self is a final leaf.
