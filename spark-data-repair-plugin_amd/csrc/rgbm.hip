@@ -470,6 +470,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
+    bool use_reduce = false;   // sum the per-workgroup partials in a separate kernel (many workgroups per class tree, or row-sharded)
     std::vector<int> lv_groups(LV_MAX_DEPTH + 1, 1);
     if (level_mode) {
         const long long ntiles = (N + LV_TILE - 1) / LV_TILE;
@@ -494,7 +495,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         d_node_a.alloc((size_t)K * lc.NS); d_node_b.alloc((size_t)K * lc.NS);
         d_plan.alloc(K); d_layout.alloc((size_t)K * nchunk); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
         d_part.alloc((size_t)K * gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
-        d_count.alloc((size_t)K * 256); if (dp) { d_count_g.alloc((size_t)K * 256); d_part_red.alloc((size_t)K * lc.max_built * tc.totbins + (size_t)K * 128 /* K*256 int64 counts */); }
+        d_count.alloc((size_t)K * 256); use_reduce = dp || lc.gx > 4;
+        if (dp) d_count_g.alloc((size_t)K * 256);
+        if (use_reduce) { d_part_red.alloc((size_t)K * lc.max_built * tc.totbins + (size_t)K * 128 /* K*256 int64 counts */); }
         d_leafnode.alloc((size_t)K * LV_MAX_LEAVES); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
         for (int level = 1; level < p.max_depth; ++level) {   // worst-case histogram groups of pass `level`
             const int n_exp = 1 << (level - 1);
@@ -622,11 +625,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
             // row-sharded: partials of this rank -> compact buffer -> integer all-reduce; the split kernel then sees ONE partial
             auto exchange = [&](bool root, int nb) -> std::pair<const HistBin*, LevelConst> {
-                if (!dp) return {d_part.p, lc};
-                hipLaunchKernelGGL(k_level_reduce, dim3((tc.totbins + 255) / 256, nb, K), dim3(256), 0, s, d_part.p, d_part_red.p, d_plan.p, d_count.p, root ? 1 : 0, nb, lc);
-                const size_t nh = (size_t)K * nb * tc.totbins * 2;          // int64 words of histograms, then K*256 child counts
-                all_reduce(d_part_red.p, nh + (size_t)K * 256, AR_I64, s);
-                hipLaunchKernelGGL(k_counts_unpack, dim3(K), dim3(256), 0, s, reinterpret_cast<const long long*>(d_part_red.p) + nh, d_count_g.p);
+                if (!use_reduce) return {d_part.p, lc};
+                hipLaunchKernelGGL(k_level_reduce, dim3((tc.totbins + 63) / 64, nb, K), dim3(256), 0, s, d_part.p, d_part_red.p, d_plan.p, d_count.p, root ? 1 : 0, nb, lc);
+                if (dp) {
+                    const size_t nh = (size_t)K * nb * tc.totbins * 2;          // int64 words of histograms, then K*256 child counts
+                    all_reduce(d_part_red.p, nh + (size_t)K * 256, AR_I64, s);
+                    hipLaunchKernelGGL(k_counts_unpack, dim3(K), dim3(256), 0, s, reinterpret_cast<const long long*>(d_part_red.p) + nh, d_count_g.p);
+                }
                 LevelConst r = lc; r.gx = 1; r.max_built = nb;
                 return {d_part_red.p, r};
             };

@@ -465,27 +465,35 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
 #undef LV_FLAG_STORE
 
 // ------------------------------------------------------------------------------------------------
-// k_level_reduce (row-sharded multi-GPU training only): sum the gx workgroup partials of every built child into
-// one compact [K][nb][totbins] buffer, which is then all-reduced (exact integer sums) across the ranks.
-// grid (ceil(totbins/256), nb, K), block 256.
+// k_level_reduce: sum the gx workgroup partials of every built child into one compact [K][nb][totbins] buffer.
+// Used (a) when a class tree has many workgroups (binary / few-class targets: gx up to 256 -- summing them inside
+// the one-wave-per-feature split kernel took longer than the pass itself) and (b) for row-sharded multi-GPU
+// training, where the compact buffer is what gets all-reduced (exact integer sums) across the ranks.
+// grid (ceil(totbins/64), nb, K), block 256 = 64 bins x 4 partial-lanes.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_level_reduce(const HistBin* __restrict__ part, HistBin* __restrict__ red, const LvPlan* __restrict__ plan,
                                                       const int32_t* __restrict__ count, int is_root, int nb, LevelConst c) {
-    const int k = blockIdx.z, bslot = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
-    // the local child counts ride in the same all-reduce, as int64 words behind the histograms
+    __shared__ long long sg[4][64], sh[4][64];
+    const int k = blockIdx.z, bslot = blockIdx.y, bl = threadIdx.x & 63, xl = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + bl;
+    // the local child counts ride in the same buffer (row-sharded: same all-reduce), as int64 words behind the histograms
     if (blockIdx.x == 0 && blockIdx.y == 0)
         reinterpret_cast<long long*>(red + (long long)c.K * nb * c.totbins)[(long long)k * 256 + threadIdx.x] = (long long)count[(long long)k * 256 + threadIdx.x];
-    if (b >= c.totbins) return;
     const LvPlan* pp = &plan[k];
-    HistBin acc; acc.g = 0; acc.h = 0;
     const int n_built = pp->done ? 0 : (is_root ? 1 : pp->n_built);
-    if (bslot < n_built) {
-        for (int x = 0; x < c.gx; ++x) {
-            const HistBin v = part[(((long long)k * c.gx + x) * c.max_built + bslot) * c.totbins + b];
-            acc.g += v.g; acc.h += v.h;
-        }
+    long long ag = 0, ah = 0;
+    if (b < c.totbins && bslot < n_built) {
+        const HistBin* src = part + (((long long)k * c.gx) * c.max_built + bslot) * c.totbins + b;
+        const long long xs = (long long)c.max_built * c.totbins;
+#pragma unroll 8
+        for (int x = xl; x < c.gx; x += 4) { const HistBin v = src[x * xs]; ag += v.g; ah += v.h; }
     }
-    red[((long long)k * nb + bslot) * c.totbins + b] = acc;
+    sg[xl][bl] = ag; sh[xl][bl] = ah;
+    __syncthreads();
+    if (xl == 0 && b < c.totbins) {
+        HistBin acc; acc.g = sg[0][bl] + sg[1][bl] + sg[2][bl] + sg[3][bl]; acc.h = sh[0][bl] + sh[1][bl] + sh[2][bl] + sh[3][bl];
+        red[((long long)k * nb + bslot) * c.totbins + b] = acc;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_counts_unpack(const long long* __restrict__ cnt64, int32_t* __restrict__ count_g) {
