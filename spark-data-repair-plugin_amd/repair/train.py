@@ -8,6 +8,13 @@ hyperopt is not installed in this image (and its TPE draws cannot be reproduced 
 sampler is a seeded random search whose first evaluation is LightGBM's defaults for the searched
 parameters; `RandomState(42)` as in train.py:207.  Everything else keeps the reference's option
 names: model.lgb.*, model.cv.n_splits, model.hp.{timeout,max_evals,no_progress_loss}.
+
+On the device the search is BATCHED: every fit of a CV fold is an independent training call on its own HIP stream
+(librepairgbm creates one per call and ctypes releases the GIL), and at the reference's default sample size
+(<= 10 000 rows, model.py:755-766) one fit is launch/latency bound and uses a sliver of the GPU.  So the folds of
+`model.hp.batch_size` consecutive trials are trained concurrently from a thread pool.  The outcome is identical to the
+sequential search: points are drawn from the same RandomState in the same order and the no-progress / timeout rule is
+applied to the losses in trial order (trials past the stopping point are evaluated in vain and discarded).
 """
 import copy
 import time
@@ -37,11 +44,12 @@ _opt_n_splits = _option("model.cv.n_splits", 3, int, lambda v: v >= 3, "`{}` sho
 _opt_timeout = _option("model.hp.timeout", 0, int, None, None)
 _opt_max_evals = _option("model.hp.max_evals", 100000000, int, lambda v: v > 0, "`{}` should be positive")
 _opt_no_progress_loss = _option("model.hp.no_progress_loss", 50, int, lambda v: v > 0, "`{}` should be positive")
+_opt_batch_size = _option("model.hp.batch_size", 8, int, lambda v: v > 0, "`{}` should be positive")
 
 train_option_keys = [o.key for o in (
     _opt_boosting_type, _opt_class_weight, _opt_learning_rate, _opt_max_depth, _opt_max_bin, _opt_reg_alpha,
     _opt_min_split_gain, _opt_n_estimators, _opt_importance_type, _opt_n_splits, _opt_timeout, _opt_max_evals,
-    _opt_no_progress_loss)]
+    _opt_no_progress_loss, _opt_batch_size)]
 
 # LightGBM defaults of the searched parameters = evaluation #0 of the search
 _DEFAULT_POINT = dict(num_leaves=31, subsample=1.0, subsample_freq=0, colsample_bytree=1.0, min_child_samples=20,
@@ -68,17 +76,23 @@ def fixed_params(opts: Dict[str, str], is_discrete: bool, num_class: int, n_jobs
     return p
 
 
-def _cv_loss(model: Any, X: pd.DataFrame, y: pd.Series, is_discrete: bool, n_splits: int, seed: int) -> float:
-    from sklearn.base import clone
-    from sklearn.metrics import f1_score, mean_squared_error
+def _cv_folds(X: pd.DataFrame, y: pd.Series, is_discrete: bool, n_splits: int, seed: int) -> List[Tuple[np.ndarray, np.ndarray]]:
     from sklearn.model_selection import KFold, StratifiedKFold
     cv = StratifiedKFold(n_splits=n_splits, shuffle=True, random_state=seed) if is_discrete \
         else KFold(n_splits=n_splits, shuffle=True, random_state=seed)
-    scores = []
-    for tr, va in cv.split(X, y):
-        m = clone(model).fit(X.iloc[tr], y.iloc[tr])
-        pred = m.predict(X.iloc[va])
-        scores.append(f1_score(y.iloc[va], pred, average="macro") if is_discrete else -mean_squared_error(y.iloc[va], pred))
+    return list(cv.split(X, y))
+
+
+def _fold_score(model: Any, X: pd.DataFrame, y: pd.Series, is_discrete: bool, tr: np.ndarray, va: np.ndarray) -> float:
+    from sklearn.base import clone
+    from sklearn.metrics import f1_score, mean_squared_error
+    m = clone(model).fit(X.iloc[tr], y.iloc[tr])
+    pred = m.predict(X.iloc[va])
+    return float(f1_score(y.iloc[va], pred, average="macro") if is_discrete else -mean_squared_error(y.iloc[va], pred))
+
+
+def _cv_loss(model: Any, X: pd.DataFrame, y: pd.Series, is_discrete: bool, n_splits: int, seed: int) -> float:
+    scores = [_fold_score(model, X, y, is_discrete, tr, va) for tr, va in _cv_folds(X, y, is_discrete, n_splits, seed)]
     return -float(np.mean(scores))
 
 
@@ -102,27 +116,49 @@ def _build_gbm_model(X: pd.DataFrame, y: pd.Series, is_discrete: bool, num_class
     max_evals = int(g(_opt_max_evals))
     patience = int(g(_opt_no_progress_loss))
     timeout = int(g(_opt_timeout))
+    batch = max(1, int(g(_opt_batch_size)))
     try:
+        from concurrent.futures import ThreadPoolExecutor
         rs = np.random.RandomState(42)
         trials: List[Tuple[float, Dict[str, Any]]] = []
         best_loss, since_best, start = None, 0, time.time()
-        while len(trials) < max_evals:
-            point = dict(_DEFAULT_POINT) if not trials else _sample_point(rs)
-            if max_evals == 1:
-                loss = 0.0   # a single evaluation decides nothing: skip the CV fits
-            else:
-                try:
-                    loss = _cv_loss(_create_model(point), X, y, is_discrete, n_splits, seed=len(trials))
-                except Exception as e:   # e.g. a fold misses a label (train.py:175-179)
-                    _logger.warning("%s: %s" % (e.__class__, e))
-                    loss = 0.0
-            trials.append((loss, point))
-            if best_loss is None or loss < best_loss:
-                best_loss, since_best = loss, 0
-            else:
-                since_best += 1
-            if since_best >= patience or (timeout > 0 and time.time() - start > timeout):
-                break
+        stop = False
+        with ThreadPoolExecutor(max_workers=batch * n_splits) as pool:
+            while len(trials) < max_evals and not stop:
+                # draw the next `batch` points (same RandomState stream as a sequential search) ...
+                nb = min(batch, max_evals - len(trials))
+                points = [dict(_DEFAULT_POINT) if (not trials and i == 0) else _sample_point(rs) for i in range(nb)]
+                futs: List[Any] = []
+                if max_evals > 1:   # a single evaluation decides nothing: skip the CV fits
+                    # ... train every CV fold of every point of the batch concurrently (one HIP stream per fit) ...
+                    for i, point in enumerate(points):
+                        try:
+                            model = _create_model(point)
+                            folds = _cv_folds(X, y, is_discrete, n_splits, seed=len(trials) + i)
+                            futs.append([pool.submit(_fold_score, model, X, y, is_discrete, tr, va) for tr, va in folds])
+                        except Exception as e:   # noqa: BLE001
+                            futs.append(e)
+                # ... and account for the losses in trial order, exactly like the sequential loop
+                for i, point in enumerate(points):
+                    if max_evals == 1:
+                        loss = 0.0
+                    else:
+                        try:
+                            if isinstance(futs[i], Exception):
+                                raise futs[i]
+                            loss = -float(np.mean([f.result() for f in futs[i]]))
+                        except Exception as e:   # e.g. a fold misses a label (train.py:175-179)
+                            _logger.warning("%s: %s" % (e.__class__, e))
+                            loss = 0.0
+                    if stop:
+                        continue   # evaluated in vain: past the stopping point of the sequential search
+                    trials.append((loss, point))
+                    if best_loss is None or loss < best_loss:
+                        best_loss, since_best = loss, 0
+                    else:
+                        since_best += 1
+                    if since_best >= patience or (timeout > 0 and time.time() - start > timeout):
+                        stop = True
         _logger.info("hyperopt: #eval=%d/%d" % (len(trials), max_evals))
         best = min(trials, key=lambda t: t[0])
         model = _create_model(best[1])

@@ -244,3 +244,18 @@ def test_build_model_contract(oracle_backend):
     # any failure inside the build -> (None, 0.0)  (reference train.py:227-229)
     (model, score), _ = build_model(X, pd.Series([None] * 300), True, 3, n_jobs=-1, opts={"model.hp.max_evals": "1"})
     assert model is None and score == 0.0
+
+
+def test_batched_hp_search_equals_sequential(oracle_backend):
+    """model.hp.batch_size only changes HOW MANY CV fits are in flight (threads / HIP streams), never the outcome."""
+    from repair.train import build_model
+    rng = np.random.default_rng(7)
+    X = pd.DataFrame({"a": rng.choice(list("xyz"), 400), "b": rng.choice(list("pqrs"), 400), "c": rng.integers(0, 5, 400)})
+    y = pd.Series(np.where(X.a == "x", "A", np.where(X.b == "p", "B", "C")))
+    base = {"model.hp.max_evals": "7", "model.lgb.n_estimators": "15", "model.lgb.learning_rate": "0.2", "model.hp.no_progress_loss": "3"}
+    outs = []
+    for bs in ("1", "3", "8"):
+        (m, score), _ = build_model(X, y, True, 3, n_jobs=-1, opts=dict(base, **{"model.hp.batch_size": bs}))
+        assert m is not None
+        outs.append((score, m.booster_bytes_, m.get_params()["num_leaves"]))
+    assert outs[0] == outs[1] == outs[2]
