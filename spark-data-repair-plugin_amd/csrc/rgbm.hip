@@ -602,24 +602,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
 
-    // ---- 5. boosting iterations: everything below is enqueue-only
-    for (int it = 0; it < NE; ++it) {
-        const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw = sample_weight_host ? d_sw.p : nullptr;
-        if (use_bagging && it % p.bagging_freq == 0) {
-            const long long nrb = (n_train + 1023) / 1024;
-            d_bagcnt.zero(s);
-            hipLaunchKernelGGL(k_bagging, dim3((unsigned)((nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, (long long)n_train, p.bagging_fraction, d_sorted_rows.p, d_inbag.p);
-            hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((n_train + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, (long long)n_train, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
-        }
-        const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
-        uint8_t* node0 = level_mode ? d_node_a.p : nullptr;
-        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K <= 64) hipLaunchKernelGGL(k_grad_mc<128>, dim3((unsigned)((N + 127) / 128)), dim3(128), (size_t)K * 128 * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K <= 128) hipLaunchKernelGGL(k_grad_mc<64>, dim3((unsigned)((N + 63) / 64)), dim3(64), (size_t)K * 64 * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        const uint8_t* usedp = d_used.p + (size_t)it * K * F;
-        if (level_mode) {
+    DevBuf<int32_t> d_it(1); d_it.zero(s);   // device-side iteration counter (k_next_iteration)
+    // one boosting iteration of the level grower after the gradients: an iteration-invariant launch sequence
+    auto enqueue_level_growth = [&]() {
             d_count.zero(s);
             hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_fmeta.p, d_cmeta.p, n_in_ptr, (long long)n_train, lc);
             int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
@@ -639,22 +624,67 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             {
                 auto ex = exchange(true, 1);
                 hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p, cntg, d_fmeta.p,
-                                   usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, ex.second);
+                                   d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             for (int level = 1; level < p.max_depth; ++level) {
                 hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
                 launch_pass(false, 1, nchunk * lv_groups[level]);
                 auto ex = exchange(false, 1 << (level - 1));
                 hipLaunchKernelGGL(k_level_split<false>, dim3((F + 1) / 2, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
-                                   cntg, d_fmeta.p, usedp, d_lcand.p, d_statrows.p, n_hnodes, tc, ex.second);
+                                   cntg, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
             hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
-            hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, it, tc);
+            hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
             hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
-                               d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, it, lc);
+                               d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
             if (dp) { HIPCHK(hipMemcpyAsync(d_count_g.p, d_count.p, (size_t)K * 256 * 4, hipMemcpyDeviceToDevice, s)); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
-            hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, it, tc);
+            hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, d_it.p, tc);
+    };
+
+    auto enqueue_grad = [&]() {
+        const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw = sample_weight_host ? d_sw.p : nullptr;
+        const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
+        uint8_t* node0 = level_mode ? d_node_a.p : nullptr;
+        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1 && K <= 64) hipLaunchKernelGGL(k_grad_mc<128>, dim3((unsigned)((N + 127) / 128)), dim3(128), (size_t)K * 128 * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1 && K <= 128) hipLaunchKernelGGL(k_grad_mc<64>, dim3((unsigned)((N + 63) / 64)), dim3(64), (size_t)K * 64 * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+    };
+
+    // ---- 5. boosting iterations: everything below is enqueue-only.
+    // Without bagging / row sharding / per-launch timing one iteration of the level grower is the same launch sequence
+    // every time (the iteration counter lives on the device), so it CAN be captured once into a hipGraph and replayed
+    // (RGBM_GRAPH=1).  It is off by default: measured on MI355X / ROCm 7.2 a 10 000-row fit is bound by the GPU-side
+    // latency of its ~27 small dependent kernels per iteration, not by the host launches (134.7 ms either way), and
+    // graphs replayed from several host threads at once (the batched hp search) gave 2 wrong models in 72.
+    const char* genv_graph = getenv("RGBM_GRAPH");
+    const bool graph_mode = level_mode && !use_bagging && !dp && !stats && genv_graph && genv_graph[0] == '1';
+    if (graph_mode) {
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        enqueue_grad();
+        enqueue_level_growth();
+        hipLaunchKernelGGL(k_next_iteration, dim3(1), dim3(1), 0, s, d_it.p);
+        HIPCHK(hipStreamEndCapture(s, &graph));
+        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int it = 0; it < NE; ++it) HIPCHK(hipGraphLaunch(exec, s));
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+    }
+    for (int it = graph_mode ? NE : 0; it < NE; ++it) {
+        if (use_bagging && it % p.bagging_freq == 0) {
+            const long long nrb = (n_train + 1023) / 1024;
+            d_bagcnt.zero(s);
+            hipLaunchKernelGGL(k_bagging, dim3((unsigned)((nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, (long long)n_train, p.bagging_fraction, d_sorted_rows.p, d_inbag.p);
+            hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((n_train + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, (long long)n_train, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
+        }
+        enqueue_grad();
+        const uint8_t* usedp = d_used.p + (size_t)it * K * F;
+        if (level_mode) {
+            enqueue_level_growth();
+            hipLaunchKernelGGL(k_next_iteration, dim3(1), dim3(1), 0, s, d_it.p);
             continue;
         }
         hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);

@@ -508,9 +508,11 @@ __global__ __launch_bounds__(256) void k_counts_unpack(const long long* __restri
 template <bool ROOT>
 __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__ part, HistBin* __restrict__ pool, LvPlan* __restrict__ plan,
                                                      SNode* __restrict__ nodes, const int32_t* __restrict__ count,
-                                                     const FeatMeta* __restrict__ fmeta, const uint8_t* __restrict__ used /* [K][F] */,
+                                                     const FeatMeta* __restrict__ fmeta, const uint8_t* __restrict__ used_all /* [NE][K][F] */,
                                                      Cand* __restrict__ cand /* [K][256][F] */, unsigned long long* __restrict__ stat_rows,
+                                                     const int32_t* __restrict__ itp /* device-side iteration counter */,
                                                      int n_hnodes, TrainConst c, LevelConst lc) {
+    const uint8_t* used = used_all + (long long)(*itp) * c.K * c.F;
     const int k = blockIdx.z, pi = blockIdx.y;
     // ROOT: one wave per feature (4 per block).  Otherwise one wave per (feature, child side): 2 features per block,
     // so the two FindBestThreshold scans of a parent run side by side instead of back to back.
@@ -704,7 +706,8 @@ __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, L
 __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, const SNode* __restrict__ nodes, const int32_t* __restrict__ count,
                                                      TreeOut out, const double* __restrict__ init, double* __restrict__ node_delta /* [K][256] */,
                                                      int32_t* __restrict__ leaf_node_out /* [K][LV_MAX_LEAVES] */,
-                                                     int32_t* __restrict__ any_split, int32_t* __restrict__ err_flag, int it, TrainConst c) {
+                                                     int32_t* __restrict__ any_split, int32_t* __restrict__ err_flag, const int32_t* __restrict__ itp, TrainConst c) {
+    const int it = *itp;
     __shared__ int leaf_node[LV_MAX_LEAVES], leaf_parent[LV_MAX_LEAVES], leaf_isleft[LV_MAX_LEAVES];
     __shared__ int node_leaf[256];
     __shared__ double upd[LV_MAX_LEAVES];
@@ -809,7 +812,8 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
 __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ rec, const uint8_t* __restrict__ node_a, const uint8_t* __restrict__ node_b,
                                                      const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, const TreeOut out,
                                                      const double* __restrict__ node_delta, double* __restrict__ score, int32_t* __restrict__ count,
-                                                     int it, LevelConst c) {
+                                                     const int32_t* __restrict__ itp, LevelConst c) {
+    const int it = *itp;
     __shared__ double nd[256];
     __shared__ uint32_t route0[256], route1[256];
     __shared__ int32_t cnt[2 * LV_MAX_EXP * LV_CNT_REP];
@@ -880,7 +884,8 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
 
 // leaf counts of the finished tree (Tree::leaf_count_), once every child count is final
 __global__ __launch_bounds__(LV_MAX_LEAVES) void k_level_leafcount(const LvPlan* __restrict__ plan, const int32_t* __restrict__ count,
-                                                                   const int32_t* __restrict__ leaf_node, TreeOut out, int it, TrainConst c) {
+                                                                   const int32_t* __restrict__ leaf_node, TreeOut out, const int32_t* __restrict__ itp, TrainConst c) {
+    const int it = *itp;
     const int k = blockIdx.x, l = threadIdx.x;
     const long long tbase = (long long)it * c.K + k;
     const int L = out.L[tbase];
@@ -888,5 +893,8 @@ __global__ __launch_bounds__(LV_MAX_LEAVES) void k_level_leafcount(const LvPlan*
     const int n = leaf_node[(long long)k * LV_MAX_LEAVES + l];
     out.leaf_count[tbase * c.num_leaves + l] = (n == 0) ? (int)plan[k].n_in : count[(long long)k * 256 + n];
 }
+
+// the iteration counter lives on the device so that one boosting iteration is the same launch sequence every time (hipGraph)
+__global__ void k_next_iteration(int32_t* it) { if (threadIdx.x == 0 && blockIdx.x == 0) it[0] += 1; }
 
 }  // namespace rg
