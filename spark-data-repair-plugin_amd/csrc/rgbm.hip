@@ -586,14 +586,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     };
 
     const int score_gx = (int)std::max<long long>(1, std::min<long long>((N + 1023) / 1024, (2048 + K - 1) / K));
-    const int lv_dbg = getenv("RGBM_LV_DEBUG") ? atoi(getenv("RGBM_LV_DEBUG")) << 8 : 0;
     auto launch_pass = [&](bool root, int with_hist, int gz) {
         hipEvent_t a = nullptr, b = nullptr;
         const bool timed = stats && with_hist;
         if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
 #define RGBM_LAUNCH_PASS(R, B, M, INBAG)                                                                                                        \
         hipLaunchKernelGGL((k_level_pass<R, B, M>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p, \
-                           (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist | lv_dbg, lc)
+                           (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc)
         const bool multi = nchunk > 1;
         if (root) { if (multi) RGBM_LAUNCH_PASS(true, false, true, nullptr); else RGBM_LAUNCH_PASS(true, false, false, nullptr); }
         else if (use_bagging) { if (multi) RGBM_LAUNCH_PASS(false, true, true, d_inbag.p); else RGBM_LAUNCH_PASS(false, true, false, d_inbag.p); }

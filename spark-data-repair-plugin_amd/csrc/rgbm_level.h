@@ -26,8 +26,9 @@
 //
 // LDS per workgroup (1024 threads, one workgroup per CU): route table | child counters |
 // packed 32+32-bit histogram slots [built node][feature][bin][replica] | 32-bit carry words per
-// bin.  Packed slots are drained every 2048 rows: bits >= 2^11 move to the carry words, so
-// neither field can overflow (2048 * (2^20-1) + 2047 < 2^31, 2048 * (2^21-1) + 2047 < 2^32).
+// bin.  Packed slots are drained lazily: every lane budgets the |g| and h it has added since the
+// last drain so that no field can exceed 2047 + sum of the 1024 lane budgets < 2^31 (2^32 for h);
+// a drain moves the bits >= 2^11 to the carry words (see k_level_pass).
 #pragma once
 #include "rgbm_kernels.h"
 
@@ -162,8 +163,6 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     const LvPlan* pp = &plan[k];
     if (pp->done) return;
     const int n_exp = ROOT ? 0 : pp->n_exp;
-    const int dbg = with_hist >> 8;   // timing experiments only (RGBM_LV_DEBUG): 1 = no drain, 2 = no atomics, 4 = no count/store
-    with_hist &= 0xFF;
     const int n_built = with_hist ? pp->n_built : 0;
     const int npg = pp->npg;
     const bool writer = !ROOT && ch == 0 && grp == 0;
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     // one histogram update of a (row, built node) pair held by this lane: 15-16 packed LDS atomics, 3 instructions each
     auto accumulate = [&](bool on, int li, const uint4& r, const int2& g) __attribute__((always_inline)) {
         const unsigned long long packed = ((unsigned long long)(long long)g.x << 32) + (unsigned long long)(unsigned int)g.y;
-        const bool need = on && packed != 0ull && !(dbg & 2);
+        const bool need = on && packed != 0ull;
         const unsigned ag = (unsigned)(g.x < 0 ? -g.x : g.x), ah = (unsigned)g.y;
         const bool over = need && (acc_g + ag > LB_G || acc_h + ah > LB_H);
         if (__any(over)) { if (lane == 0) LV_FLAG_STORE(1); rendezvous(); }
@@ -348,9 +347,9 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
                 const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, built slot in bits 16..23
                 const int child = expd ? (int)(sel & 0xFFu) : n;
                 const int bs = expd ? (int)((sel >> 16) & 0xFFu) : 0xFF;
-                if (writer && expd && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                if (writer && expd && cur_ib[s]) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
                 const int li = (bs != 0xFF && bs >= g0 && bs - g0 < ng) ? bs - g0 : -1;
-                if (writer && inrange && !(dbg & 4)) ob_[o] = (uint8_t)child;
+                if (writer && inrange) ob_[o] = (uint8_t)child;
                 if (ng > 0) accumulate(li >= 0, li, cur_r[s], cur_g[s]);
             }
     #pragma unroll
@@ -403,11 +402,11 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
                         const unsigned sel = left ? e.y : (e.y >> 8);
                         child = (int)(sel & 0xFFu);
                         const int bs = (int)((sel >> 16) & 0xFFu);
-                        if (writer && cur_ib[s] && !(dbg & 4)) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                        if (writer && cur_ib[s]) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
                         if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
                     }
                 }
-                if (writer && inrange && !(dbg & 4)) ob_[o] = (uint8_t)child;
+                if (writer && inrange) ob_[o] = (uint8_t)child;
                 if (ng > 0) {
                     const unsigned long long m = __ballot(li >= 0);
                     if (li >= 0) lst[(lhead + lcount + __popcll(m & ((1ull << lane) - 1ull))) & (LV_LIST - 1)] = (ti << 16) | (o << 5) | (uint32_t)li;
