@@ -192,7 +192,18 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     off = (off + 15) & ~(size_t)15;
     unsigned long long* fast = reinterpret_cast<unsigned long long*>(smem + off);
 
-    if (!ROOT) for (int i = tid; i < 256; i += LV_THREADS) route[i] = make_uint2(pp->route0[i], pp->route1[i]);
+    if (!ROOT) for (int i = tid; i < 256; i += LV_THREADS) {
+        // LDS copy of the route table, specialised for this block: built slots become group-local (0xFF = the child's
+        // histogram is not this block's business) and an unexpanded node routes to itself, so the row loop needs no selects
+        const uint32_t w0 = pp->route0[i]; uint32_t w1 = pp->route1[i];
+        if (w0 & (1u << 24)) {
+            const int ls = (int)((w1 >> 16) & 0xFFu), rs = (int)(w1 >> 24);
+            const uint32_t l2 = (ls != 0xFF && ls >= g0 && ls - g0 < ng) ? (uint32_t)(ls - g0) : 0xFFu;
+            const uint32_t r2 = (rs != 0xFF && rs >= g0 && rs - g0 < ng) ? (uint32_t)(rs - g0) : 0xFFu;
+            w1 = (w1 & 0xFFFFu) | l2 << 16 | r2 << 24;
+        } else w1 = (uint32_t)i | (uint32_t)i << 8 | 0xFFFF0000u;
+        route[i] = make_uint2(w0, w1);
+    }
     if (tid < 4) drain_flag[tid] = 0;
 #define LV_FLAG_LOAD() __hip_atomic_load(drain_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LV_FLAG_STORE(v) __hip_atomic_store(drain_flag, (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -310,26 +321,27 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
         }
     };
     if (ROOT || !LV_RING) {
-        fetch(blockIdx.x, cur_n, cur_r, cur_g, cur_ib);
-        for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // one tile: prefetch the tile after it into the other register set, then process this one (the two sets swap
+        // roles from call to call, so nothing is copied)
+        auto tile_step = [&](long long t, int (&Cn)[RPT], uint4 (&Cr)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT],
+                             int (&Xn)[RPT], uint4 (&Xr)[RPT], int2 (&Xg)[RPT], int (&Xib)[RPT]) __attribute__((always_inline)) {
             const long long p0 = t * LV_TILE;
-            fetch(t + gridDim.x, nxt_n, nxt_r, nxt_g, nxt_ib);
+            fetch(t + gridDim.x, Xn, Xr, Xg, Xib);
             uint8_t* ob_ = node_out + p0;
-    #pragma unroll
+#pragma unroll
             for (int s = 0; s < RPT; ++s) {
                 const unsigned o = (unsigned)(s * LV_THREADS + tid);
-                const int n = cur_n[s];
-                if (ROOT) { accumulate(n != LV_INACTIVE, 0, cur_r[s], cur_g[s]); continue; }
+                const int n = Cn[s];
+                if (ROOT) { accumulate(n != LV_INACTIVE, 0, Cr[s], Cg[s]); continue; }
                 const bool inrange = p0 + o < N;
-                // branch-free routing (for !MULTI): route[255] is never expanded, so inactive rows fall through as
-                // "not expanded"; a lane's work is paid by its whole wave anyway, only the exec-mask juggling goes away
+                // branch-free routing (for !MULTI): unexpanded nodes (and the inactive id 255) route to themselves
                 const uint2 e = route[n];
                 const bool expd = (e.x & (1u << 24)) != 0u;
                 const unsigned f = e.x & 0xFFu;
                 unsigned bin;
                 if (!MULTI) {
                     const bool hi = (f & 8u) != 0u;
-                    const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
+                    const uint32_t rx = Cr[s].x, ry = Cr[s].y, rz = Cr[s].z, rw = Cr[s].w;
                     const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
                     bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
                 } else {
@@ -337,23 +349,26 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
                     if (expd) {
                         if ((f >> 4) == (unsigned)ch) {
                             const bool hi = (f & 8u) != 0u;
-                            const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
+                            const uint32_t rx = Cr[s].x, ry = Cr[s].y, rz = Cr[s].z, rw = Cr[s].w;
                             const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
                             bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
                         } else bin = rec8[((long long)(f >> 4) * N + p0 + o) * 16 + (f & 15u)];
                     }
                 }
                 const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
-                const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, built slot in bits 16..23
-                const int child = expd ? (int)(sel & 0xFFu) : n;
-                const int bs = expd ? (int)((sel >> 16) & 0xFFu) : 0xFF;
-                if (writer && expd && cur_ib[s]) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                const int li = (bs != 0xFF && bs >= g0 && bs - g0 < ng) ? bs - g0 : -1;
+                const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, group-local built slot in bits 16..23
+                const int child = (int)(sel & 0xFFu);
+                const int li = (int)((sel >> 16) & 0xFFu);             // 0xFF: nothing to accumulate here
+                if (writer && expd && Cib[s]) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
                 if (writer && inrange) ob_[o] = (uint8_t)child;
-                if (ng > 0) accumulate(li >= 0, li, cur_r[s], cur_g[s]);
+                if (ng > 0) accumulate(li != 0xFF, li, Cr[s], Cg[s]);
             }
-    #pragma unroll
-            for (int s = 0; s < RPT; ++s) { cur_n[s] = nxt_n[s]; cur_r[s] = nxt_r[s]; cur_g[s] = nxt_g[s]; cur_ib[s] = nxt_ib[s]; }
+        };
+        long long t = blockIdx.x;
+        fetch(t, cur_n, cur_r, cur_g, cur_ib);
+        while (t < ntiles) {
+            tile_step(t, cur_n, cur_r, cur_g, cur_ib, nxt_n, nxt_r, nxt_g, nxt_ib); t += gridDim.x; if (t >= ntiles) break;
+            tile_step(t, nxt_n, nxt_r, nxt_g, nxt_ib, cur_n, cur_r, cur_g, cur_ib); t += gridDim.x;
         }
     } else {
         // ---- level pass with compaction.  Phase 1 (every row): route, count, store the new node id; rows that feed a
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
                         child = (int)(sel & 0xFFu);
                         const int bs = (int)((sel >> 16) & 0xFFu);
                         if (writer && cur_ib[s]) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                        if (bs != 0xFF && bs >= g0 && bs - g0 < ng) li = bs - g0;
+                        if (bs != 0xFF) li = bs;   // group-local already (LDS copy of the route table)
                     }
                 }
                 if (writer && inrange) ob_[o] = (uint8_t)child;
