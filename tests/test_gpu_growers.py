@@ -126,3 +126,29 @@ def test_unseen_and_constant_columns():
     d = rng.integers(0, 9, n).astype(np.int32)
     y = ((a + d) % 3).astype(np.int32)
     _three_way(np.ascontiguousarray(np.stack([a, b, c, d])), [4, 1, 5, 9], y, 3, 1, cw=balanced_weights(y, 3), n_estimators=6, learning_rate=0.3)
+
+
+def test_random_configurations_stress():
+    """Irregular gains (noise features, tiny leaves, heavy leaf-budget pruning): the speculative expansion bound and the
+    best-first replay must reproduce the oracle's leaf-wise tree for every draw."""
+    from oracle import oracle as O
+    from repair import _native as N
+    rng = np.random.default_rng(20260922)
+    for trial in range(40):
+        n = int(rng.integers(300, 9000))
+        F = int(rng.integers(2, 12))
+        cards = rng.integers(2, 40, F)
+        X = np.stack([rng.integers(0, c, n) for c in cards]).astype(np.int32)
+        if rng.random() < 0.5:
+            X[rng.integers(0, F)][rng.random(n) < 0.1] = -1
+        K = int(rng.choice([2, 3, 5, 9]))
+        signal = (X[0] % K + (X[min(1, F - 1)] > cards[min(1, F - 1)] // 2)) % K
+        y = np.where(rng.random(n) < rng.uniform(0.2, 0.9), rng.integers(0, K, n), signal).astype(np.int32)
+        kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=int(rng.integers(2, 7)), learning_rate=float(rng.uniform(0.05, 0.5)),
+                  num_leaves=int(rng.integers(2, 41)), max_depth=int(rng.integers(1, 8)), min_data_in_leaf=int(rng.integers(1, 60)),
+                  min_sum_hessian_in_leaf=float(10 ** rng.uniform(-3, 0.5)), lambda_l2=float(rng.choice([0.0, 0.5, 3.0])),
+                  min_gain_to_split=float(rng.choice([0.0, 0.0, 0.05])), feature_fraction=float(rng.choice([1.0, 1.0, 0.6])))
+        cw = balanced_weights(y, K)
+        mo = O.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
+        mg = N.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
+        assert mo.save() == mg.save(), "trial %d differs: n=%d F=%d K=%d %r" % (trial, n, F, K, kw)
