@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <condition_variable>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -322,6 +323,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     hipEvent_t ev_begin, ev_end; HIPCHK(hipEventCreate(&ev_begin)); HIPCHK(hipEventCreate(&ev_end));
     HIPCHK(hipEventRecord(ev_begin, s));
 
+    const bool timing = getenv("RGBM_TIMING") != nullptr;   // host wall-clock of the phases, to stderr
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
     // ---- 1. code frequencies of the training rows (features + the target itself)
     std::vector<int32_t> cols(feat_cols, feat_cols + F); cols.push_back(target_col);
     std::vector<int32_t> ncod(F + 1); std::vector<long long> cnt_off(F + 2, 0);
@@ -434,6 +438,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     tc.N = N; tc.n_train = n_train;
     const int NL = p.num_leaves, NE = p.n_estimators;
 
+    const double t_bins = now();
     // ---- 4. device state
     DevBuf<FeatMeta> d_fmeta(F); DevBuf<ChunkMeta> d_cmeta(nchunk); DevBuf<long long> d_lut_off(F + 1); DevBuf<uint8_t> d_lut(lut.size()), d_miss(F);
     d_fmeta.upload(fmeta.data(), F, s); d_cmeta.upload(cmeta.data(), nchunk, s); d_lut_off.upload(lut_off.data(), F + 1, s);
@@ -504,7 +509,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             long long npg = n_exp;
             for (int ch = 0; ch < nchunk; ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
-                long long fit = (lc.lds_bytes - lv_fixed_bytes(cmeta[ch], n_exp, fm)) / lv_node_bytes(fm, cmeta[ch], 0);
+                long long fit = (lc.lds_bytes - lv_fixed_bytes(cmeta[ch], n_exp, fm) - (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 2) / lv_node_bytes(fm, cmeta[ch], 0);
                 if (fit < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
                 npg = std::min(npg, fit);
             }
@@ -652,6 +657,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
     };
 
+    if (timing) HIPCHK(hipStreamSynchronize(s));
+    const double t_setup = now();
     // ---- 5. boosting iterations: everything below is enqueue-only.
     // Without bagging / row sharding / per-launch timing one iteration of the level grower is the same launch sequence
     // every time (the iteration counter lives on the device), so it CAN be captured once into a hipGraph and replayed
@@ -702,6 +709,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     }
     HIPCHK(hipGetLastError());
 
+    const double t_enq = now();
     // ---- 6. trees back to the host
     std::vector<int32_t> hL(NT), hfeat(NT * (NL - 1)), htheta(NT * (NL - 1)), hdleft(NT * (NL - 1)), hleft(NT * (NL - 1)), hright(NT * (NL - 1)), hcnt(NT * NL), hany(NE);
     std::vector<double> hgain(NT * (NL - 1)), hval(NT * NL);
@@ -713,6 +721,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (level_mode) { d_err.download(&h_err, 1, s); d_statrows.download(&h_statrows, 1, s); }
     HIPCHK(hipEventRecord(ev_end, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (timing) fprintf(stderr, "[rgbm] target %d K=%d: count+bins %.1f ms, alloc+pack %.1f ms, enqueue %.1f ms, drain+download %.1f ms\n", target_col, K, t_bins - t_start, t_setup - t_bins, t_enq - t_setup, now() - t_enq);
     if (h_err) throw std::runtime_error("level grower: a node outside the speculative expansion was selected (expansion bound violated)");
 
     int n_iter = NE;

@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
 // ------------------------------------------------------------------------------------------------
 // packed-slot layout for `ng` built nodes of one chunk inside `avail` bytes of LDS
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline int lv_cap_shift(int nbins) { int s = 0; while (s < 5 && (nbins << (s + 1)) <= 256) ++s; return s; }
+__host__ __device__ inline int lv_cap_shift(int nbins) { int s = 0; while (s < 5 && (nbins << (s + 1)) <= 2048) ++s; return s; }
 
 __host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int s) {
     int t = 0;
@@ -102,9 +102,15 @@ __host__ __device__ inline long long lv_node_bytes(const FeatMeta* fm, const Chu
     return (long long)lv_slots(fm, cm.nfeat, s) * 8 + (long long)cm.wide_bins * 8;
 }
 
+// everything that depends on the replication cap s for `nodes` built nodes: packed slots + carry words per node, plus the slot->wide map
+__host__ __device__ inline long long lv_layout_bytes(const FeatMeta* fm, const ChunkMeta& cm, int s, long long nodes) {
+    return nodes * lv_node_bytes(fm, cm, s) + (long long)lv_slots(fm, cm.nfeat, s) * 2;
+}
+
 __host__ __device__ inline long long lv_fixed_bytes(const ChunkMeta& cm, int n_exp, const FeatMeta* fm) {
-    // route tables + child counters + (wide->slot, wide->hoff) tables + slot->wide map at the largest layout + alignment slack
-    return 2048 + 16 + LV_LIST_BYTES + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + (long long)lv_slots(fm, cm.nfeat, 5) * 2 + 64;
+    // route tables + child counters + (wide->slot, wide->hoff) tables + alignment slack (the slot->wide map is charged to the layout: lv_layout_bytes)
+    (void)fm;
+    return 2048 + 16 + LV_LIST_BYTES + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + 64;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
         LvLayout L;
         const long long avail = c.lds_bytes - lv_fixed_bytes(cm, 0, fm);
         int s = 5;
-        while (s > 0 && lv_node_bytes(fm, cm, s) > avail) --s;
+        while (s > 0 && lv_layout_bytes(fm, cm, s, 1) > avail) --s;
         int off = 0;
         for (int j = 0; j < 16; ++j) {
             if (j < cm.nfeat) { int cs = lv_cap_shift(fm[j].nbins); L.sh[j] = s < cs ? s : cs; L.fbase[j] = off; off += fm[j].nbins << L.sh[j]; }
@@ -238,7 +244,11 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     // lanes, so it cannot overflow while every lane stays within LB_G / LB_H.  A lane that would exceed its
     // budget raises the drain flag; waves poll the flag once per row step and rendezvous at a barrier, drain
     // cooperatively and continue.  Drains are rare for small gradients (multiclass), at worst every 2 rows/lane.
-    constexpr unsigned LB_G = ((1u << 31) - 2048u) / LV_THREADS, LB_H = (unsigned)((((1ull << 32) - 2048ull)) / LV_THREADS);
+    // A slot of feature f only receives lanes with the same (lane mod rep_f): 1024 / rep_f lanes, so the budget grows with the
+    // smallest replication factor of this block's layout (x16..32 at the root and the shallow levels).
+    int rep_min = 32;
+    for (int j = 0; j < cm.nfeat; ++j) { const int r = 1 << lay.sh[j]; if (r < rep_min) rep_min = r; }
+    const unsigned LB_G = (((1u << 31) - 2048u) / LV_THREADS) * (unsigned)rep_min, LB_H = (unsigned)((((1ull << 32) - 2048ull)) / LV_THREADS) * (unsigned)rep_min;
     unsigned acc_g = 0, acc_h = 0;
     auto drain = [&]() {
         // move the bits above 2^11 of both fields into the per-bin carry words
@@ -683,7 +693,7 @@ __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, L
         for (int chn = 0; chn < c.nchunk; ++chn) {
             const ChunkMeta cm = cmeta[chn]; const FeatMeta* fm = fmeta + cm.first_feat;
             const long long avail = lc.lds_bytes - lv_fixed_bytes(cm, n_exp, fm);
-            long long fit = avail / lv_node_bytes(fm, cm, 0);
+            long long fit = (avail - (long long)lv_slots(fm, cm.nfeat, 0) * 2) / lv_node_bytes(fm, cm, 0);
             if (fit < 1) fit = 1;
             if (fit < npg) npg = (int)fit;
         }
@@ -693,7 +703,7 @@ __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, L
         const ChunkMeta cm = cmeta[lane]; const FeatMeta* fm = fmeta + cm.first_feat;
         const long long avail = lc.lds_bytes - lv_fixed_bytes(cm, n_exp, fm);
         int s = 5;
-        while (s > 0 && (long long)npg * lv_node_bytes(fm, cm, s) > avail) --s;
+        while (s > 0 && lv_layout_bytes(fm, cm, s, npg) > avail) --s;
         LvLayout L;
         int off = 0;
         for (int j = 0; j < 16; ++j) {
