@@ -651,8 +651,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
         uint8_t* node0 = level_mode ? d_node_a.p : nullptr;
         if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K <= 64) hipLaunchKernelGGL(k_grad_mc<128>, dim3((unsigned)((N + 127) / 128)), dim3(128), (size_t)K * 128 * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K <= 128) hipLaunchKernelGGL(k_grad_mc<64>, dim3((unsigned)((N + 63) / 64)), dim3(64), (size_t)K * 64 * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1 && K <= 120) hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
         else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
         else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
     };

@@ -149,49 +149,52 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
     }
 }
 
-// Multiclass gradients with the row's K scores parked in LDS (each thread owns one column of the [K][R] tile, so
-// no barrier is needed): every score is read from HBM once, all K loads of a thread are in flight together, and
-// exp(s_k - max) is evaluated once per class.  Same arithmetic, in the same order, as k_grad<1>.
-template <int R>
-__global__ __launch_bounds__(R) void k_grad_mc(const double* __restrict__ score, const int32_t* __restrict__ ycol,
-                                               const double* __restrict__ class_w, const double* __restrict__ sample_w,
-                                               const uint8_t* __restrict__ row_in_bag, int2* __restrict__ gh,
-                                               uint8_t* __restrict__ node0, long long NS, TrainConst c) {
+// Multiclass gradients, FP64-VALU bound (one exp, one division and two quantisations per row and class).
+// A workgroup of 256 threads owns 64 rows; wave c owns the classes k = c, c+4, c+8, ...  The K x 64 tile of scores sits
+// in LDS (every score is read from HBM once, fully coalesced), the maximum is combined across the four waves
+// (order-independent), exp(s_k - max) overwrites the tile, ONE wave adds the K terms of every row in class order (the
+// summation order of the numerics spec), and every wave finishes its own classes.  Same arithmetic, in the same order,
+// as k_grad<1>; 4x the waves per LDS byte of a thread-per-row layout, which is what an FP64-bound kernel needs.
+__global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+                                                 const double* __restrict__ class_w, const double* __restrict__ sample_w,
+                                                 const uint8_t* __restrict__ row_in_bag, int2* __restrict__ gh,
+                                                 uint8_t* __restrict__ node0, long long NS, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* tile = reinterpret_cast<double*>(smem) + threadIdx.x;   // element k at tile[k * R]
+    double* tile = reinterpret_cast<double*>(smem);          // [K][64]
+    double* pmax = tile + (size_t)c.K * 64;                  // [4][64]
+    double* psum = pmax + 256;                               // [64]
     const long long N = c.N;
-    const int K = c.K;
-    const long long i = (long long)blockIdx.x * R + threadIdx.x;
-    if (i >= N) return;
-    const double* sp = score + i;
-    int k = 0;
-    for (; k + 8 <= K; k += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = sp[(long long)(k + u) * N];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) tile[(k + u) * R] = v[u];
-    }
-    for (; k < K; ++k) tile[k * R] = sp[(long long)k * N];
-    const int y = ycol[i];
-    if (node0) {
+    const int K = c.K, r = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + r;
+    const bool valid = i < N;
+    const long long ic = valid ? i : N - 1;
+    double m = -INFINITY;
+    for (int k = wv; k < K; k += 4) { const double v = score[(long long)k * N + ic]; tile[k * 64 + r] = v; if (v > m) m = v; }
+    pmax[wv * 64 + r] = m;
+    const int y = ycol[ic];
+    if (node0 && valid) {   // every training row restarts in node 0 (the root); all other rows never take part
         const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
-        for (int kk = 0; kk < K; ++kk) node0[(long long)kk * NS + i] = v;
+        for (int k = wv; k < K; k += 4) node0[(long long)k * NS + i] = v;
     }
-    if (y < 0) return;
-    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) gh[(long long)kk * N + i] = make_int2(0, 0); return; }
+    const bool out_of_bag = row_in_bag && !row_in_bag[ic];
+    __syncthreads();
+    double wmax = pmax[r];
+    { const double b1 = pmax[64 + r], b2 = pmax[128 + r], b3 = pmax[192 + r]; if (b1 > wmax) wmax = b1; if (b2 > wmax) wmax = b2; if (b3 > wmax) wmax = b3; }
+    for (int k = wv; k < K; k += 4) tile[k * 64 + r] = rg_exp(tile[k * 64 + r] - wmax);
+    __syncthreads();
+    if (wv == 0) { double wsum = 0.0; for (int k = 0; k < K; ++k) wsum += tile[k * 64 + r]; psum[r] = wsum; }
+    __syncthreads();
+    if (!valid || y < 0) return;    // not a training row: its gh stays 0 for ever
+    if (out_of_bag) { for (int k = wv; k < K; k += 4) gh[(long long)k * N + i] = make_int2(0, 0); return; }
     double wi = class_w ? class_w[y] : 1.0;
     if (sample_w) wi = wi * sample_w[i];
-    wi = (double)(float)wi;
-    double wmax = tile[0];
-    for (int kk = 1; kk < K; ++kk) { const double s = tile[kk * R]; if (s > wmax) wmax = s; }
-    double wsum = 0.0;
-    for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
-    for (int kk = 0; kk < K; ++kk) {
-        const double pk = tile[kk * R] / wsum;
-        const double g = ((y == kk) ? (pk - 1.0) : pk) * wi;
+    wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
+    const double wsum = psum[r];
+    for (int k = wv; k < K; k += 4) {
+        const double pk = tile[k * 64 + r] / wsum;
+        const double g = ((y == k) ? (pk - 1.0) : pk) * wi;
         const double h = c.factor * pk * (1.0 - pk) * wi;
-        gh[(long long)kk * N + i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+        gh[(long long)k * N + i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
     }
 }
 
