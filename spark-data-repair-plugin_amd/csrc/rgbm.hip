@@ -476,6 +476,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
     bool use_reduce = false;   // sum the per-workgroup partials in a separate kernel (many workgroups per class tree, or row-sharded)
+    // Experiment (RGBM_LAZY_SCORE=1, off): defer AddScore into the next iteration's gradient kernel so that the scores are touched
+    // once per iteration.  Measured on MI355X (K=64, 10M rows): k_level_final 2.48 -> 0.70 ms, but the per-(row, class) gather of
+    // the node delta inside the FP64-bound gradient kernel costs more than it saves (2.8 -> 6.8 ms).
+    const bool lazy_score = level_mode && obj == 1 && K <= 112 && getenv("RGBM_LAZY_SCORE") != nullptr;
     std::vector<int> lv_groups(LV_MAX_DEPTH + 1, 1);
     if (level_mode) {
         const long long ntiles = (N + LV_TILE - 1) / LV_TILE;
@@ -640,8 +644,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
             hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
-            hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
-                               d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
+            if (lazy_score) hipLaunchKernelGGL(k_level_final<false>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
+                                               d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
+            else hipLaunchKernelGGL(k_level_final<true>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
+                                    d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
             if (dp) { HIPCHK(hipMemcpyAsync(d_count_g.p, d_count.p, (size_t)K * 256 * 4, hipMemcpyDeviceToDevice, s)); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
             hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, d_it.p, tc);
     };
@@ -651,7 +657,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
         uint8_t* node0 = level_mode ? d_node_a.p : nullptr;
         if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K <= 120) hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1 && K <= 112) {
+            PendingTree pend; memset(&pend, 0, sizeof(pend));
+            if (lazy_score) {
+                pend.node_a = d_node_a.p; pend.node_b = d_node_b.p; pend.buf = &d_plan.p[0].buf; pend.buf_stride = (long long)(sizeof(LvPlan) / sizeof(int32_t));
+                pend.node_delta = d_ndelta.p; pend.tree_L = t_L.p; pend.itp = d_it.p;
+            }
+            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8 + (size_t)K * 64, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, pend, tc);
+        }
         else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
         else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
     };

@@ -155,10 +155,22 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
 // (order-independent), exp(s_k - max) overwrites the tile, ONE wave adds the K terms of every row in class order (the
 // summation order of the numerics spec), and every wave finishes its own classes.  Same arithmetic, in the same order,
 // as k_grad<1>; 4x the waves per LDS byte of a thread-per-row layout, which is what an FP64-bound kernel needs.
-__global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+// Lazy AddScore (level grower): the score update of the PREVIOUS tree is applied here, from the final node id of every
+// row (k_level_final<false> stored it) and the node -> delta table of the replay -- the scores are read and written once
+// per iteration instead of twice.  `pend` is null on the leaf-wise path.
+struct PendingTree {
+    const uint8_t* node_a; const uint8_t* node_b;   // final node ids of the previous iteration live in a or b (per class)
+    const int32_t* buf;                              // [K] which of the two, stride `buf_stride` ints (LvPlan::buf)
+    long long buf_stride;
+    const double* node_delta;                        // [K][256]
+    const int32_t* tree_L;                           // [NE][K] leaves of every tree
+    const int32_t* itp;                              // device-side iteration counter
+};
+
+__global__ __launch_bounds__(256) void k_grad_mc(double* __restrict__ score, const int32_t* __restrict__ ycol,
                                                  const double* __restrict__ class_w, const double* __restrict__ sample_w,
                                                  const uint8_t* __restrict__ row_in_bag, int2* __restrict__ gh,
-                                                 uint8_t* __restrict__ node0, long long NS, TrainConst c) {
+                                                 uint8_t* __restrict__ node0, long long NS, PendingTree pend, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem);          // [K][64]
     double* pmax = tile + (size_t)c.K * 64;                  // [4][64]
@@ -169,9 +181,31 @@ __global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ scor
     const bool valid = i < N;
     const long long ic = valid ? i : N - 1;
     double m = -INFINITY;
-    for (int k = wv; k < K; k += 4) { const double v = score[(long long)k * N + ic]; tile[k * 64 + r] = v; if (v > m) m = v; }
-    pmax[wv * 64 + r] = m;
     const int y = ycol[ic];
+    const int it = pend.itp ? pend.itp[0] : 0;
+    if (it > 0) {
+        // pending AddScore of the previous tree: three unrolled sweeps so that the loads of a sweep are all in flight together
+        // (node ids -> LDS, then the delta gathers, then the scores)
+        uint8_t* ntile = reinterpret_cast<uint8_t*>(psum + 64);     // [K][64] node ids of this row block
+        const int32_t* Lp = pend.tree_L + (long long)(it - 1) * K;
+#pragma unroll 4
+        for (int k = wv; k < K; k += 4) {
+            const uint8_t* nd = (pend.buf[(long long)k * pend.buf_stride] ? pend.node_b : pend.node_a) + (long long)k * NS;
+            ntile[k * 64 + r] = (Lp[k] > 1) ? nd[ic] : (uint8_t)255;
+        }
+#pragma unroll 4
+        for (int k = wv; k < K; k += 4) {
+            const int n = ntile[k * 64 + r];
+            const double d = (n != 255) ? pend.node_delta[k * 256 + n] : 0.0;
+            const double v = score[(long long)k * N + ic] + d;
+            if (n != 255 && valid) score[(long long)k * N + i] = v;
+            tile[k * 64 + r] = v; if (v > m) m = v;
+        }
+    } else {
+#pragma unroll 4
+        for (int k = wv; k < K; k += 4) { const double v = score[(long long)k * N + ic]; tile[k * 64 + r] = v; if (v > m) m = v; }
+    }
+    pmax[wv * 64 + r] = m;
     if (node0 && valid) {   // every training row restarts in node 0 (the root); all other rows never take part
         const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
         for (int k = wv; k < K; k += 4) node0[(long long)k * NS + i] = v;

@@ -833,7 +833,8 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
 // training row ends in its final speculative node, whose score delta the replay has tabulated.
 // grid (gx, K), block 256, 4 rows per thread.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ rec, const uint8_t* __restrict__ node_a, const uint8_t* __restrict__ node_b,
+template <bool SCORE /* false: store the final node ids instead; the next k_grad_mc applies the deltas (lazy AddScore) */>
+__global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ rec, uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
                                                      const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, const TreeOut out,
                                                      const double* __restrict__ node_delta, double* __restrict__ score, int32_t* __restrict__ count,
                                                      const int32_t* __restrict__ itp, LevelConst c) {
@@ -845,6 +846,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     if (out.L[(long long)it * c.K + k] <= 1) return;   // no split: no score change, nothing to count
     const LvPlan* pp = &plan[k];
     const bool route = !pp->done;                      // plan(max_depth) expanded at least one node
+    if (!SCORE && !route) return;                      // the ids in pp->buf are final already
     const int n_exp = route ? pp->n_exp : 0, child_first = pp->child_first;
     const int tid = threadIdx.x, lane = tid & 63;
     nd[tid] = node_delta[(long long)k * 256 + tid];
@@ -853,6 +855,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     __syncthreads();
     const long long N = c.N;
     const uint8_t* node = ((route ? pp->buf_in : pp->buf) ? node_b : node_a) + (long long)k * c.NS;
+    uint8_t* node_out = (pp->buf ? node_b : node_a) + (long long)k * c.NS;   // !SCORE: receives the routed ids
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
     double* sk = score + (long long)k * N;
     // 4 rows per thread; node ids and scores are loaded together (independent loads), then routed and written back
@@ -860,13 +863,15 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     for (long long i = ((long long)blockIdx.x * 256 + tid) * 4; i < N; i += (long long)gridDim.x * 1024) {
         if (i + 3 < N && aligned16) {
             const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
-            double2 s01 = *reinterpret_cast<const double2*>(sk + i), s23 = *reinterpret_cast<const double2*>(sk + i + 2);
-            if (n4 == 0xFFFFFFFFu) continue;
+            double2 s01 = make_double2(0, 0), s23 = make_double2(0, 0);
+            if (SCORE) { s01 = *reinterpret_cast<const double2*>(sk + i); s23 = *reinterpret_cast<const double2*>(sk + i + 2); }
+            if (n4 == 0xFFFFFFFFu) { if (!SCORE) *reinterpret_cast<uint32_t*>(node_out + i) = n4; continue; }
             double sv[4] = {s01.x, s01.y, s23.x, s23.y};
+            uint32_t o4 = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int n = (int)((n4 >> (8 * j)) & 0xFFu);
-                if (n == LV_INACTIVE) continue;
+                if (n == LV_INACTIVE) { o4 |= 0xFFu << (8 * j); continue; }
                 const long long row = i + j;
                 const uint32_t w0 = route0[n];
                 if (w0 & (1u << 24)) {
@@ -877,15 +882,17 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
                     n = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
                     if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
                 }
-                sv[j] += nd[n];
+                if (SCORE) sv[j] += nd[n]; else o4 |= (uint32_t)n << (8 * j);
             }
-            s01.x = sv[0]; s01.y = sv[1]; s23.x = sv[2]; s23.y = sv[3];
-            *reinterpret_cast<double2*>(sk + i) = s01; *reinterpret_cast<double2*>(sk + i + 2) = s23;
+            if (SCORE) {
+                s01.x = sv[0]; s01.y = sv[1]; s23.x = sv[2]; s23.y = sv[3];
+                *reinterpret_cast<double2*>(sk + i) = s01; *reinterpret_cast<double2*>(sk + i + 2) = s23;
+            } else *reinterpret_cast<uint32_t*>(node_out + i) = o4;
             continue;
         }
         for (long long row = i; row < N && row < i + 4; ++row) {
             int n = node[row];
-            if (n == LV_INACTIVE) continue;
+            if (n == LV_INACTIVE) { if (!SCORE) node_out[row] = (uint8_t)LV_INACTIVE; continue; }
             const uint32_t w0 = route0[n];
             if (w0 & (1u << 24)) {
                 const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
@@ -895,7 +902,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
                 n = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
                 if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
             }
-            sk[row] += nd[n];
+            if (SCORE) sk[row] += nd[n]; else node_out[row] = (uint8_t)n;
         }
     }
     __syncthreads();
