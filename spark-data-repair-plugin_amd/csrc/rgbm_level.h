@@ -288,8 +288,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
         const bool need = on && packed != 0ull;
         const unsigned ag = (unsigned)(g.x < 0 ? -g.x : g.x), ah = (unsigned)g.y;
         const bool over = need && (acc_g + ag > LB_G || acc_h + ah > LB_H);
-        if (__any(over)) { if (lane == 0) LV_FLAG_STORE(1); rendezvous(); }
-        else if (LV_FLAG_LOAD()) rendezvous();
+        if (__any(over)) { if (lane == 0) LV_FLAG_STORE(1); rendezvous(); }   // (the flag itself is polled once per tile, see tile_step)
         if (need) {
             acc_g += ag; acc_h += ah;
             unsigned char* fb = reinterpret_cast<unsigned char*>(fast) + (unsigned)li * (unsigned)(spn * 8);
@@ -336,6 +335,9 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
         auto tile_step = [&](long long t, int (&Cn)[RPT], uint4 (&Cr)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT],
                              int (&Xn)[RPT], uint4 (&Xr)[RPT], int2 (&Xg)[RPT], int (&Xib)[RPT]) __attribute__((always_inline)) {
             const long long p0 = t * LV_TILE;
+            // one poll of the drain flag per tile, before this tile's atomics are queued: an LDS read returns behind every
+            // LDS atomic issued before it, so polling inside the row steps would serialise the atomics of consecutive steps
+            if (ng > 0 && LV_FLAG_LOAD()) rendezvous();
             fetch(t + gridDim.x, Xn, Xr, Xg, Xib);
             uint8_t* ob_ = node_out + p0;
 #pragma unroll
