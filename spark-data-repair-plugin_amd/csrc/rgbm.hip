@@ -657,6 +657,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
         uint8_t* node0 = level_mode ? d_node_a.p : nullptr;
         if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1 && K < 16 && !lazy_score)
+            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
         else if (obj == 1 && K <= 112) {
             PendingTree pend; memset(&pend, 0, sizeof(pend));
             if (lazy_score) {

@@ -232,6 +232,43 @@ __global__ __launch_bounds__(256) void k_grad_mc(double* __restrict__ score, con
     }
 }
 
+// Few classes (K < 16): one thread per row, the row's K scores parked in its own LDS column (no barrier); the
+// four-waves-per-row-block layout above would leave most of its waves idle.
+template <int R>
+__global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+                                                    const double* __restrict__ class_w, const double* __restrict__ sample_w,
+                                                    const uint8_t* __restrict__ row_in_bag, int2* __restrict__ gh,
+                                                    uint8_t* __restrict__ node0, long long NS, TrainConst c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* tile = reinterpret_cast<double*>(smem) + threadIdx.x;   // element k at tile[k * R]
+    const long long N = c.N;
+    const int K = c.K;
+    const long long i = (long long)blockIdx.x * R + threadIdx.x;
+    if (i >= N) return;
+    const double* sp = score + i;
+    double wmax = -INFINITY;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) { const double v = sp[(long long)k * N]; tile[k * R] = v; if (v > wmax) wmax = v; }
+    const int y = ycol[i];
+    if (node0) {
+        const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
+        for (int kk = 0; kk < K; ++kk) node0[(long long)kk * NS + i] = v;
+    }
+    if (y < 0) return;
+    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) gh[(long long)kk * N + i] = make_int2(0, 0); return; }
+    double wi = class_w ? class_w[y] : 1.0;
+    if (sample_w) wi = wi * sample_w[i];
+    wi = (double)(float)wi;
+    double wsum = 0.0;
+    for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
+    for (int kk = 0; kk < K; ++kk) {
+        const double pk = tile[kk * R] / wsum;
+        const double g = ((y == kk) ? (pk - 1.0) : pk) * wi;
+        const double h = c.factor * pk * (1.0 - pk) * wi;
+        gh[(long long)kk * N + i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: hist_build -- THE roofline kernel.
 //   grid (gx, K, nchunk), block 256.  Each lane owns one row per step: one dwordx4 load brings its
