@@ -472,7 +472,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     }
     // level grower state
     LevelConst lc; memset(&lc, 0, sizeof(lc));
-    DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
+    DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout, d_lay_table; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
     bool use_reduce = false;   // sum the per-workgroup partials in a separate kernel (many workgroups per class tree, or row-sharded)
@@ -513,12 +513,21 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             long long npg = n_exp;
             for (int ch = 0; ch < nchunk; ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
-                long long fit = (lc.lds_bytes - lv_fixed_bytes(cmeta[ch], n_exp, fm) - (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 2) / lv_node_bytes(fm, cmeta[ch], 0);
+                long long fit = (lc.lds_bytes - lv_fixed_bytes(cmeta[ch], LV_MAX_EXP, fm) - (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 2) / lv_node_bytes(fm, cmeta[ch], 0);
                 if (fit < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
                 npg = std::min(npg, fit);
             }
             lv_groups[level] = (int)((n_exp + npg - 1) / npg);
         }
+        // packed-slot layouts for every possible group size, chosen once on the host (greedy, lv_choose_layout)
+        std::vector<LvLayout> lay_table((size_t)nchunk * (LV_MAX_BUILT + 1));
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
+            for (int g = 0; g <= LV_MAX_BUILT; ++g)
+                lv_choose_layout(fm, cmeta[ch], std::max(g, 1), lc.lds_bytes - lv_fixed_bytes(cmeta[ch], LV_MAX_EXP, fm), lay_table[(size_t)ch * (LV_MAX_BUILT + 1) + g]);
+        }
+        d_lay_table.alloc(lay_table.size()); d_lay_table.upload(lay_table.data(), lay_table.size(), s);
+        HIPCHK(hipStreamSynchronize(s));   // lay_table is a local
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
@@ -614,7 +623,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     // one boosting iteration of the level grower after the gradients: an iteration-invariant launch sequence
     auto enqueue_level_growth = [&]() {
             d_count.zero(s);
-            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_fmeta.p, d_cmeta.p, n_in_ptr, (long long)n_train, lc);
+            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_fmeta.p, d_cmeta.p, n_in_ptr, (long long)n_train, lc);
             int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
             // row-sharded: partials of this rank -> compact buffer -> integer all-reduce; the split kernel then sees ONE partial
             auto exchange = [&](bool root, int nb) -> std::pair<const HistBin*, LevelConst> {
@@ -635,14 +644,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                                    d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             for (int level = 1; level < p.max_depth; ++level) {
-                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
+                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
                 launch_pass(false, 1, nchunk * lv_groups[level]);
                 auto ex = exchange(false, 1 << (level - 1));
                 hipLaunchKernelGGL(k_level_split<false>, dim3((F + 1) / 2, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
                                    cntg, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
-            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
+            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
             if (lazy_score) hipLaunchKernelGGL(k_level_final<false>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);

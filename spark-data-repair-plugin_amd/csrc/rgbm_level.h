@@ -113,30 +113,44 @@ __host__ __device__ inline long long lv_fixed_bytes(const ChunkMeta& cm, int n_e
     return 2048 + 16 + LV_LIST_BYTES + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + 64;
 }
 
+// Packed-slot layout of one chunk for `nodes` built nodes inside `avail` bytes: every feature starts un-replicated and the
+// feature with the FEWEST slots is doubled while everything still fits (replicas <= 32, <= 2048 slots per feature).  Slots per
+// feature end up roughly equal, i.e. low-cardinality features -- the ones whose lanes collide on the same LDS address -- get the
+// replication, also at the deep levels where LDS is scarce.
+__host__ __device__ inline void lv_choose_layout(const FeatMeta* fm, const ChunkMeta& cm, long long nodes, long long avail, LvLayout& L) {
+    long long slots = 0;
+    for (int j = 0; j < 16; ++j) { L.sh[j] = 0; L.fbase[j] = 0; if (j < cm.nfeat) slots += fm[j].nbins; }
+    bool stuck[16];
+    for (int j = 0; j < 16; ++j) stuck[j] = j >= cm.nfeat;
+    for (;;) {
+        int best = -1; long long bs = 0;
+        for (int j = 0; j < cm.nfeat; ++j) {
+            if (stuck[j]) continue;
+            const long long cur = (long long)fm[j].nbins << L.sh[j];
+            if (best < 0 || cur < bs) { best = j; bs = cur; }
+        }
+        if (best < 0) break;
+        const long long ns = slots + bs;   // doubling feature `best` adds its current slot count
+        if (L.sh[best] >= 5 || bs * 2 > 2048 || nodes * (ns * 8 + (long long)cm.wide_bins * 8) + ns * 2 > avail) { stuck[best] = true; continue; }
+        L.sh[best] += 1; slots = ns;
+    }
+    int off = 0;
+    for (int j = 0; j < cm.nfeat; ++j) { L.fbase[j] = off; off += fm[j].nbins << L.sh[j]; }
+    L.spn = off;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_level_init: per class tree, start of a boosting iteration
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, SNode* __restrict__ nodes,
-                                                   const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
+__global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, const LvLayout* __restrict__ lay_table /* [nchunk][LV_MAX_BUILT+1] */,
+                                                   SNode* __restrict__ nodes, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
                                                    const unsigned int* __restrict__ n_in_ptr, long long n_train, LevelConst c) {
     const int k = blockIdx.x, lane = lane_id();
     LvPlan* pp = &plan[k];
     const long long n_in = n_in_ptr ? (long long)n_in_ptr[0] : n_train;
     for (int i = lane; i < 256; i += 64) { pp->route0[i] = 0; pp->route1[i] = 0xFFFFFFFFu; }
     if (lane < c.nchunk) {
-        const ChunkMeta cm = cmeta[lane];
-        const FeatMeta* fm = fmeta + cm.first_feat;
-        LvLayout L;
-        const long long avail = c.lds_bytes - lv_fixed_bytes(cm, 0, fm);
-        int s = 5;
-        while (s > 0 && lv_layout_bytes(fm, cm, s, 1) > avail) --s;
-        int off = 0;
-        for (int j = 0; j < 16; ++j) {
-            if (j < cm.nfeat) { int cs = lv_cap_shift(fm[j].nbins); L.sh[j] = s < cs ? s : cs; L.fbase[j] = off; off += fm[j].nbins << L.sh[j]; }
-            else { L.sh[j] = 0; L.fbase[j] = 0; }
-        }
-        L.spn = off;
-        layout[(long long)k * c.nchunk + lane] = L;
+        layout[(long long)k * c.nchunk + lane] = lay_table[lane * (LV_MAX_BUILT + 1) + 1];   // one built node (the root)
     }
     if (lane == 0) {
         pp->n_nodes = 1; pp->lvl_first = 0; pp->lvl_end = 1; pp->n_exp = 0; pp->n_built = 1; pp->n_groups = 1; pp->npg = 1;
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
 // ------------------------------------------------------------------------------------------------
 // k_level_plan: one wave per class tree, before pass `level` (which routes depth level-1 -> level).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, SNode* __restrict__ nodes,
+__global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, const LvLayout* __restrict__ lay_table, SNode* __restrict__ nodes,
                                                     const Cand* __restrict__ cand, const FeatMeta* __restrict__ fmeta,
                                                     const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc) {
     __shared__ double pm[256];
@@ -694,7 +708,7 @@ __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, L
         npg = n_built;
         for (int chn = 0; chn < c.nchunk; ++chn) {
             const ChunkMeta cm = cmeta[chn]; const FeatMeta* fm = fmeta + cm.first_feat;
-            const long long avail = lc.lds_bytes - lv_fixed_bytes(cm, n_exp, fm);
+            const long long avail = lc.lds_bytes - lv_fixed_bytes(cm, LV_MAX_EXP, fm);
             long long fit = (avail - (long long)lv_slots(fm, cm.nfeat, 0) * 2) / lv_node_bytes(fm, cm, 0);
             if (fit < 1) fit = 1;
             if (fit < npg) npg = (int)fit;
@@ -702,18 +716,7 @@ __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, L
         n_groups = (n_built + npg - 1) / npg;
     }
     if (lane < c.nchunk) {
-        const ChunkMeta cm = cmeta[lane]; const FeatMeta* fm = fmeta + cm.first_feat;
-        const long long avail = lc.lds_bytes - lv_fixed_bytes(cm, n_exp, fm);
-        int s = 5;
-        while (s > 0 && lv_layout_bytes(fm, cm, s, npg) > avail) --s;
-        LvLayout L;
-        int off = 0;
-        for (int j = 0; j < 16; ++j) {
-            if (j < cm.nfeat) { int cs = lv_cap_shift(fm[j].nbins); L.sh[j] = s < cs ? s : cs; L.fbase[j] = off; off += fm[j].nbins << L.sh[j]; }
-            else { L.sh[j] = 0; L.fbase[j] = 0; }
-        }
-        L.spn = off;
-        layout[(long long)k * c.nchunk + lane] = L;
+        layout[(long long)k * c.nchunk + lane] = lay_table[lane * (LV_MAX_BUILT + 1) + (npg < 1 ? 1 : npg)];   // precomputed on the host (lv_choose_layout)
     }
     if (lane == 0) {
         pp->n_exp = n_exp; pp->n_built = n_built; pp->npg = npg; pp->n_groups = n_groups;
