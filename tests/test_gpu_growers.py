@@ -152,3 +152,25 @@ def test_random_configurations_stress():
         mo = O.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
         mg = N.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
         assert mo.save() == mg.save(), "trial %d differs: n=%d F=%d K=%d %r" % (trial, n, F, K, kw)
+
+
+@pytest.mark.parametrize("env", ["RGBM_LAZY_SCORE", "RGBM_GRAPH"])
+def test_opt_in_experiments_stay_bit_exact(env):
+    """Opt-in variants kept in the library (deferred AddScore inside the gradient kernel; hipGraph replay of an
+    iteration) must not change a bit either."""
+    from oracle import oracle as O
+    from repair import _native as N
+    X, nc, y, K = _xy(30000, 10, 7, seed=97)   # K = 24 -> multiclass
+    kw = dict(objective=1, num_class=K, n_estimators=9, learning_rate=0.2)
+    cw = balanced_weights(y, K)
+    mo = O.train(X, nc, y, K, class_weight=cw, **kw)
+    prev = os.environ.get(env)
+    os.environ[env] = "1"
+    try:
+        mg = N.train(X, nc, y, K, class_weight=cw, **kw)
+    finally:
+        if prev is None:
+            os.environ.pop(env, None)
+        else:
+            os.environ[env] = prev
+    assert mo.save() == mg.save()
