@@ -873,16 +873,23 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
 
 // score rows [row0, row0+n) of device codes (column-major, Ntab rows per column) with model m.
 // feat_col_dev: device array of the F column indices.  Outputs are device pointers (any may be null).
+// scratch of one scoring call; the chain allocates it once for all its models (hipMalloc of hundreds of MB per target was
+// most of the repair time)
+struct PredictScratch { DevBuf<uint4> rec; DevBuf<double> raw; };
+
 void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_codes, long long Ntab, long long row0, long long n,
-                    const int32_t* d_feat_cols, double* d_proba, int32_t* d_label, double* d_top) {
+                    const int32_t* d_feat_cols, double* d_proba, int32_t* d_label, double* d_top, PredictScratch* scratch = nullptr) {
     using namespace rg;
     if (n <= 0) return;
     DeviceModel* dm = device_model(m, device, s);
     const int F = m->F, nchunk = (F + 15) / 16, K = m->K;
-    DevBuf<uint4> rec((size_t)nchunk * n);
+    PredictScratch local;
+    PredictScratch& sc = scratch ? *scratch : local;
+    if (sc.rec.n < (size_t)nchunk * n) sc.rec.alloc((size_t)nchunk * n);
+    if (sc.raw.n < (size_t)K * n) sc.raw.alloc((size_t)K * n);
+    DevBuf<uint4>& rec = sc.rec; DevBuf<double>& raw = sc.raw;
     hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes, Ntab, row0, n,
                        d_feat_cols ? d_feat_cols : dm->ident.p, dm->n_codes.p, dm->lut_off.p, dm->lut.p, dm->miss.p, F, nchunk, rec.p);
-    DevBuf<double> raw((size_t)K * n);
     hipLaunchKernelGGL(k_predict_raw, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
                        dm->nodes.p, dm->leaf_value.p, m->n_iter, K, dm->node_stride, dm->leaf_stride, raw.p);
     hipLaunchKernelGGL(k_softmax_argmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw.p, n, m->objective, m->num_class, d_proba, d_label, d_top);
@@ -1012,12 +1019,18 @@ static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* tar
                         int device, hipStream_t s, int32_t* out_label, double* out_prob) {
     using namespace rg;
     DevBuf<int32_t> d_label(n); DevBuf<double> d_top(n);
+    PredictScratch scratch;
+    {   // size the scratch once for the largest model of the chain
+        size_t mr = 0, mk = 0;
+        for (int t = 0; t < T; ++t) { mr = std::max(mr, (size_t)((models[t]->F + 15) / 16)); mk = std::max(mk, (size_t)models[t]->K); }
+        scratch.rec.alloc(mr * (size_t)n); scratch.raw.alloc(mk * (size_t)n);
+    }
     for (int t = 0; t < T; ++t) {
         rgbm_model* m = models[t];
         const int F = feat_off[t + 1] - feat_off[t];
         if (F != m->F) throw std::invalid_argument("chain: feature list length differs from the model's feature count");
         DevBuf<int32_t> d_fc(F); d_fc.upload(feat_cols + feat_off[t], F, s);
-        predict_device(m, device, s, d_codes, Ntab, row0, n, d_fc.p, nullptr, d_label.p, d_top.p);
+        predict_device(m, device, s, d_codes, Ntab, row0, n, d_fc.p, nullptr, d_label.p, d_top.p, &scratch);
         if (m->objective != 2) {
             int ncc = class_off ? class_off[t + 1] - class_off[t] : m->num_class;
             DevBuf<int32_t> d_cc(std::max(ncc, 1));
