@@ -51,6 +51,7 @@ constexpr int LV_MAX_LEAVES = 128;
 #endif
 constexpr int LV_LIST = 256;                                   // ring entries per wave
 constexpr int LV_LIST_BYTES = LV_RING ? (LV_THREADS / 64) * LV_LIST * 4 : 0;
+static_assert(!LV_RING || LV_TILE <= 2048, "ring entries hold an 11-bit row offset");
 
 struct SNode {   // speculative node of one class tree
     long long Gq, Hq;
