@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A wedged collective / kernel must fail its test instead of hanging the whole run (pytest-timeout, if installed)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900 if item.get_closest_marker("gpu") else 600))
+
+
 @pytest.fixture
 def oracle_backend():
     """Routes repair.gbm to the CPU oracle for the duration of a (CPU-only) test."""
