@@ -174,3 +174,36 @@ def test_opt_in_experiments_stay_bit_exact(env):
         else:
             os.environ[env] = prev
     assert mo.save() == mg.save()
+
+
+def test_random_configurations_stress_wide_and_sampled():
+    """Second stress family: two feature chunks (F up to 24), bagging / feature sub-sampling, regression targets."""
+    from oracle import oracle as O
+    from repair import _native as N
+    rng = np.random.default_rng(777)
+    for trial in range(30):
+        n = int(rng.integers(500, 12000))
+        F = int(rng.integers(14, 25))
+        cards = rng.integers(2, 70, F)
+        z = rng.integers(0, 48, n)
+        X = np.stack([np.where(rng.random(n) < 0.7, (z * (j + 1)) % c, rng.integers(0, c, n)) for j, c in enumerate(cards)]).astype(np.int32)
+        X[rng.integers(0, F)][rng.random(n) < 0.05] = -1
+        reg = trial % 5 == 4
+        kw = dict(n_estimators=int(rng.integers(2, 6)), learning_rate=float(rng.uniform(0.05, 0.4)), num_leaves=int(rng.integers(2, 64)),
+                  max_depth=int(rng.integers(2, 8)), min_data_in_leaf=int(rng.integers(1, 40)), lambda_l2=float(rng.choice([0.0, 1.0])))
+        if trial % 3 == 0:
+            kw.update(bagging_fraction=float(rng.uniform(0.5, 0.95)), bagging_freq=int(rng.integers(1, 4)))
+        if trial % 4 == 1:
+            kw.update(feature_fraction=float(rng.uniform(0.3, 0.9)))
+        if reg:
+            vals = np.sort(rng.normal(size=25))
+            y = ((z + X[1]) % 25).astype(np.int32)
+            mo = O.train(X, cards.astype(np.int32), y, 25, y_value=vals, objective=2, num_class=2, **kw)
+            mg = N.train(X, cards.astype(np.int32), y, 25, y_value=vals, objective=2, num_class=2, **kw)
+        else:
+            K = int(rng.choice([2, 4, 7, 17]))
+            y = np.where(rng.random(n) < 0.3, rng.integers(0, K, n), (z + X[2]) % K).astype(np.int32)
+            cw = balanced_weights(y, K)
+            mo = O.train(X, cards.astype(np.int32), y, K, class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), **kw)
+            mg = N.train(X, cards.astype(np.int32), y, K, class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), **kw)
+        assert mo.save() == mg.save(), "trial %d differs: n=%d F=%d %r" % (trial, n, F, kw)
