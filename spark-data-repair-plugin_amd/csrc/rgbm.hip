@@ -528,12 +528,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         }
         d_lay_table.alloc(lay_table.size()); d_lay_table.upload(lay_table.data(), lay_table.size(), s);
         HIPCHK(hipStreamSynchronize(s));   // lay_table is a local
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
@@ -611,10 +612,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
 #define RGBM_LAUNCH_PASS(R, B, M, INBAG)                                                                                                        \
         hipLaunchKernelGGL((k_level_pass<R, B, M>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p, \
                            (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc)
-        const bool multi = nchunk > 1;
-        if (root) { if (multi) RGBM_LAUNCH_PASS(true, false, true, nullptr); else RGBM_LAUNCH_PASS(true, false, false, nullptr); }
-        else if (use_bagging) { if (multi) RGBM_LAUNCH_PASS(false, true, true, d_inbag.p); else RGBM_LAUNCH_PASS(false, true, false, d_inbag.p); }
-        else { if (multi) RGBM_LAUNCH_PASS(false, false, true, nullptr); else RGBM_LAUNCH_PASS(false, false, false, nullptr); }
+        // chunk layout: 0 = one 16-feature chunk, 2 = exactly two (both records prefetched), 3 = more
+        if (root) { RGBM_LAUNCH_PASS(true, false, 0, nullptr); }
+        else if (use_bagging) { if (nchunk == 1) RGBM_LAUNCH_PASS(false, true, 0, d_inbag.p); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, true, 2, d_inbag.p); else RGBM_LAUNCH_PASS(false, true, 3, d_inbag.p); }
+        else { if (nchunk == 1) RGBM_LAUNCH_PASS(false, false, 0, nullptr); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, false, 2, nullptr); else RGBM_LAUNCH_PASS(false, false, 3, nullptr); }
 #undef RGBM_LAUNCH_PASS
         if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };

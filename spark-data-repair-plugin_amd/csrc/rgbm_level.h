@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
 // Algorithmic bytes per accumulated row: F bin bytes + 8 B (g,h); the pass also streams the node
 // ids (1 B in, 1 B out) and the records of rows it only routes.
 // ------------------------------------------------------------------------------------------------
-template <bool ROOT, bool BAG, bool MULTI /* more than one 16-feature chunk */>
+template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */>
 __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
                                                            uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
@@ -313,9 +313,10 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     // Software pipeline: the loads of the next tile are in flight while this tile's LDS atomics run (one workgroup
     // per CU, so nothing else would hide the HBM latency).  Addresses are a uniform tile base + a 32-bit lane offset.
     constexpr int RPT = LV_TILE / LV_THREADS;
-    int cur_n[RPT], nxt_n[RPT], cur_ib[RPT], nxt_ib[RPT]; uint4 cur_r[RPT], nxt_r[RPT]; int2 cur_g[RPT], nxt_g[RPT];
+    int cur_n[RPT], nxt_n[RPT], cur_ib[RPT], nxt_ib[RPT]; uint4 cur_r[RPT], nxt_r[RPT], cur_r2[RPT], nxt_r2[RPT]; int2 cur_g[RPT], nxt_g[RPT];
+    const uint4* rec_other = rec + (long long)(MULTI == 2 ? 1 - ch : ch) * N;   // MULTI == 2: the record that holds the other 16 features
     // straight-line loads (clamped offsets, no branches) so that the in-order vmcnt bookkeeping stays exact
-    auto fetch = [&](long long t, int (&fn)[RPT], uint4 (&fr)[RPT], int2 (&fg)[RPT], int (&fib)[RPT]) __attribute__((always_inline)) {
+    auto fetch = [&](long long t, int (&fn)[RPT], uint4 (&fr)[RPT], uint4 (&fr2)[RPT], int2 (&fg)[RPT], int (&fib)[RPT]) __attribute__((always_inline)) {
         const bool tv = t < ntiles;                                   // uniform
         const long long pb = tv ? t * LV_TILE : 0;
         const long long left_rows = N - pb;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
             const unsigned oc = o < lim ? o : lim;
             const int nv = nb_[oc];
             fr[s] = rb_[oc];
+            if (!ROOT && MULTI == 2) fr2[s] = (rec_other + pb)[oc]; else fr2[s] = make_uint4(0, 0, 0, 0);
             if (ROOT || !LV_RING) fg[s] = gb_[oc]; else fg[s] = make_int2(0, 0);
             fib[s] = BAG ? (int)ib_[oc] : 1;
             fn[s] = (tv && o <= lim) ? nv : LV_INACTIVE;
@@ -336,13 +338,13 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     if (ROOT || !LV_RING) {
         // one tile: prefetch the tile after it into the other register set, then process this one (the two sets swap
         // roles from call to call, so nothing is copied)
-        auto tile_step = [&](long long t, int (&Cn)[RPT], uint4 (&Cr)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT],
-                             int (&Xn)[RPT], uint4 (&Xr)[RPT], int2 (&Xg)[RPT], int (&Xib)[RPT]) __attribute__((always_inline)) {
+        auto tile_step = [&](long long t, int (&Cn)[RPT], uint4 (&Cr)[RPT], uint4 (&Cr2)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT],
+                             int (&Xn)[RPT], uint4 (&Xr)[RPT], uint4 (&Xr2)[RPT], int2 (&Xg)[RPT], int (&Xib)[RPT]) __attribute__((always_inline)) {
             const long long p0 = t * LV_TILE;
             // one poll of the drain flag per tile, before this tile's atomics are queued: an LDS read returns behind every
             // LDS atomic issued before it, so polling inside the row steps would serialise the atomics of consecutive steps
             if (ng > 0 && LV_FLAG_LOAD()) rendezvous();
-            fetch(t + gridDim.x, Xn, Xr, Xg, Xib);
+            fetch(t + gridDim.x, Xn, Xr, Xr2, Xg, Xib);
             uint8_t* ob_ = node_out + p0;
 #pragma unroll
             for (int s = 0; s < RPT; ++s) {
@@ -355,9 +357,13 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
                 const bool expd = (e.x & (1u << 24)) != 0u;
                 const unsigned f = e.x & 0xFFu;
                 unsigned bin;
-                if (!MULTI) {
+                if (MULTI == 0 || MULTI == 2) {
                     const bool hi = (f & 8u) != 0u;
-                    const uint32_t rx = Cr[s].x, ry = Cr[s].y, rz = Cr[s].z, rw = Cr[s].w;
+                    uint32_t rx = Cr[s].x, ry = Cr[s].y, rz = Cr[s].z, rw = Cr[s].w;
+                    if (MULTI == 2) {   // the split feature may live in the other chunk's record (prefetched alongside)
+                        const bool mine = (f >> 4) == (unsigned)ch;
+                        rx = mine ? rx : Cr2[s].x; ry = mine ? ry : Cr2[s].y; rz = mine ? rz : Cr2[s].z; rw = mine ? rw : Cr2[s].w;
+                    }
                     const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
                     bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
                 } else {
@@ -381,10 +387,10 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
             }
         };
         long long t = blockIdx.x;
-        fetch(t, cur_n, cur_r, cur_g, cur_ib);
+        fetch(t, cur_n, cur_r, cur_r2, cur_g, cur_ib);
         while (t < ntiles) {
-            tile_step(t, cur_n, cur_r, cur_g, cur_ib, nxt_n, nxt_r, nxt_g, nxt_ib); t += gridDim.x; if (t >= ntiles) break;
-            tile_step(t, nxt_n, nxt_r, nxt_g, nxt_ib, cur_n, cur_r, cur_g, cur_ib); t += gridDim.x;
+            tile_step(t, cur_n, cur_r, cur_r2, cur_g, cur_ib, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib); t += gridDim.x; if (t >= ntiles) break;
+            tile_step(t, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib, cur_n, cur_r, cur_r2, cur_g, cur_ib); t += gridDim.x;
         }
     } else {
         // ---- level pass with compaction.  Phase 1 (every row): route, count, store the new node id; rows that feed a
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
         const long long gstep = gridDim.x;
         int lcount = 0, lhead = 0;            // wave-uniform ring state
         uint32_t ti = 0;                      // index of the current tile among this block's tiles
-        fetch(blockIdx.x, cur_n, cur_r, cur_g, cur_ib);
+        fetch(blockIdx.x, cur_n, cur_r, cur_r2, cur_g, cur_ib);
         for (long long t = blockIdx.x; t < ntiles; t += gstep, ++ti) {
             const long long p0 = t * LV_TILE;
             bool b_on[2]; uint4 b_r[2]; int2 b_g[2]; int b_li[2]; int b_n[2];
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
                 b_r[b] = recc[row]; b_g[b] = ghk[row];
                 lhead += nb; lcount -= nb;
             }
-            fetch(t + gstep, nxt_n, nxt_r, nxt_g, nxt_ib);
+            fetch(t + gstep, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib);
             uint8_t* ob_ = node_out + p0;
 #pragma unroll
             for (int s = 0; s < RPT; ++s) {
