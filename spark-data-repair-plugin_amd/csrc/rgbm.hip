@@ -891,8 +891,10 @@ void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_c
     DevBuf<uint4>& rec = sc.rec; DevBuf<double>& raw = sc.raw;
     hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes, Ntab, row0, n,
                        d_feat_cols ? d_feat_cols : dm->ident.p, dm->n_codes.p, dm->lut_off.p, dm->lut.p, dm->miss.p, F, nchunk, rec.p);
-    hipLaunchKernelGGL(k_predict_raw, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
-                       dm->nodes.p, dm->leaf_value.p, m->n_iter, K, dm->node_stride, dm->leaf_stride, raw.p);
+    if (nchunk == 1) hipLaunchKernelGGL(k_predict_raw<true>, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
+                                        dm->nodes.p, dm->leaf_value.p, m->n_iter, K, dm->node_stride, dm->leaf_stride, raw.p);
+    else hipLaunchKernelGGL(k_predict_raw<false>, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
+                            dm->nodes.p, dm->leaf_value.p, m->n_iter, K, dm->node_stride, dm->leaf_stride, raw.p);
     hipLaunchKernelGGL(k_softmax_argmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw.p, n, m->objective, m->num_class, d_proba, d_label, d_top);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));   // rec/raw are freed on return

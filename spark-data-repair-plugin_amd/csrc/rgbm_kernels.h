@@ -921,12 +921,15 @@ __global__ __launch_bounds__(256) void k_score_update_oob(const uint8_t* __restr
 // ------------------------------------------------------------------------------------------------
 // K9: batched leaf walk.  grid (ceil(n/256), K), block 256: thread = (row, class); 8-byte nodes.
 // ------------------------------------------------------------------------------------------------
+template <bool ONE_CHUNK /* F <= 16: the row's whole bin record stays in registers, a node visit is ONE load */>
 __global__ __launch_bounds__(256) void k_predict_raw(const uint8_t* __restrict__ rec8, long long n, const PNode* __restrict__ nodes,
                                                      const double* __restrict__ leaf_value, int n_iter, int K, int node_stride, int leaf_stride,
                                                      double* __restrict__ raw /* [K][n] */) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
     if (i >= n) return;
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (ONE_CHUNK) r = reinterpret_cast<const uint4*>(rec8)[i];
     double s = 0.0;
     for (int it = 0; it < n_iter; ++it) {
         const long long t = (long long)it * K + k;
@@ -935,7 +938,12 @@ __global__ __launch_bounds__(256) void k_predict_raw(const uint8_t* __restrict__
         for (;;) {
             const PNode p = nd[node];
             const int f = p.w0 & 0xFFFF, theta = (int)((p.w0 >> 16) & 0x1FF) - 1, dleft = (p.w0 >> 25) & 1;
-            const int bin = rec8[((long long)(f >> 4) * n + i) * 16 + (f & 15)];
+            int bin;
+            if (ONE_CHUNK) {
+                const bool hi = (f & 8) != 0;
+                const uint32_t lo32 = hi ? r.z : r.x, hi32 = hi ? r.w : r.y;
+                bin = (int)__builtin_amdgcn_perm(hi32, lo32, (uint32_t)(f & 7) | 0x0C0C0C00u);
+            } else bin = rec8[((long long)(f >> 4) * n + i) * 16 + (f & 15)];
             const bool go_left = (bin == 255) ? (dleft != 0) : (bin <= theta);
             const int nx = go_left ? (int)(short)(p.w1 & 0xFFFF) : (int)(short)(p.w1 >> 16);
             if (nx < 0) { s += leaf_value[t * leaf_stride + (~nx)]; break; }
