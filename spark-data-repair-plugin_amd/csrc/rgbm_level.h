@@ -79,6 +79,7 @@ struct LvLayout {   // per (class tree, chunk): packed-slot layout of the coming
 
 struct LevelConst {
     int32_t gx, max_built, nchunk, K, F, totbins, num_leaves, max_depth, min_data_in_leaf, lds_bytes;
+    int32_t drain_shift, pad0;   // testing: the per-lane drain budgets are shifted right by this much (0 in production), which forces drains on small inputs
     long long N, NS;   // rows; row stride of the node-id arrays (multiple of 16)
 };
 
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restri
     // smallest replication factor of this block's layout (x16..32 at the root and the shallow levels).
     int rep_min = 32;
     for (int j = 0; j < cm.nfeat; ++j) { const int r = 1 << lay.sh[j]; if (r < rep_min) rep_min = r; }
-    const unsigned LB_G = (((1u << 31) - 2048u) / LV_THREADS) * (unsigned)rep_min, LB_H = (unsigned)((((1ull << 32) - 2048ull)) / LV_THREADS) * (unsigned)rep_min;
+    const unsigned LB_G = ((((1u << 31) - 2048u) / LV_THREADS) * (unsigned)rep_min) >> c.drain_shift;
+    const unsigned LB_H = ((unsigned)((((1ull << 32) - 2048ull)) / LV_THREADS) * (unsigned)rep_min) >> c.drain_shift;
     unsigned acc_g = 0, acc_h = 0;
     auto drain = [&]() {
         // move the bits above 2^11 of both fields into the per-bin carry words

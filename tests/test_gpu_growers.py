@@ -207,3 +207,63 @@ def test_random_configurations_stress_wide_and_sampled():
             mo = O.train(X, cards.astype(np.int32), y, K, class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), **kw)
             mg = N.train(X, cards.astype(np.int32), y, K, class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), **kw)
         assert mo.save() == mg.save(), "trial %d differs: n=%d F=%d %r" % (trial, n, F, kw)
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.prev = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("shift,lds", [(5, None), (9, None), (14, None), (9, 40000)])
+def test_forced_packed_slot_drains_stay_bit_exact(shift, lds):
+    """The 32+32-bit packed LDS slots are drained into carry words when a lane's |g| / h budget runs out; at test sizes
+    that never happens by itself.  RGBM_LV_DRAIN_SHIFT shrinks the budgets (here down to a drain per row step), so the
+    flag / rendezvous protocol of k_level_pass runs in every position: inside a tile, at the tile poll, in the epilogue.
+    RGBM_LV_LDS shrinks the LDS pool as well, so deep levels run several histogram groups per pass."""
+    from oracle import oracle as O
+    from repair import _native as N
+    env = dict(RGBM_LV_DRAIN_SHIFT=shift)
+    if lds:
+        env["RGBM_LV_LDS"] = lds
+    cases = []
+    X, nc, y, K = _xy(30000, 8, 0, seed=101)                       # binary: the largest quantised gradients
+    cases.append((X, nc, y, K, dict(objective=0, num_class=2, n_estimators=5, learning_rate=0.3), balanced_weights(y, K), None))
+    X, nc, y, K = _xy(26000, 10, 7, seed=103, null_ratio=0.03)     # K = 24
+    cases.append((X, nc, y, K, dict(objective=1, num_class=K, n_estimators=3, learning_rate=0.3, min_data_in_leaf=5), balanced_weights(y, K), None))
+    rng = np.random.default_rng(107)                               # two chunks, regression
+    z = rng.integers(0, 90, 21000)
+    X = np.stack([((z * (j + 1) + rng.integers(0, 5, 21000)) % (9 + 7 * j)).astype(np.int32) for j in range(19)])
+    vals = np.sort(rng.normal(size=30) * 50.0)
+    cases.append((np.ascontiguousarray(X), np.asarray([9 + 7 * j for j in range(19)], np.int32), (z % 30).astype(np.int32), 30,
+                  dict(objective=2, num_class=2, n_estimators=4, learning_rate=0.2), None, vals))
+    for X, nc, y, K, kw, cw, yv in cases:
+        mo = O.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
+        with _env(**env):
+            mg = N.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
+        assert mo.save() == mg.save(), "objective %d differs with forced drains" % kw["objective"]
+
+
+@pytest.mark.parametrize("tgt", [0, 5])
+def test_millions_of_rows_against_the_oracle(tgt):
+    """3M rows: every workgroup streams many tiles, lanes run out of drain budget on their own at the deep levels
+    (replication 1-2), and the per-workgroup partials are summed by k_level_reduce."""
+    X, nc, y, K = _xy(3_000_000, 8, tgt, seed=109)
+    from oracle import oracle as O
+    from repair import _native as N
+    kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=3, learning_rate=0.3)
+    cw = balanced_weights(y, K)
+    mo = O.train(X, nc, y, K, class_weight=cw, **kw)
+    mg = N.train(X, nc, y, K, class_weight=cw, **kw)
+    assert mo.save() == mg.save()
