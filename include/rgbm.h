@@ -138,6 +138,41 @@ int rgbm_table_repair_chain(rgbm_table* t, const rgbm_model* const* models, int3
 /* Copy one column of the resident table back to the host. */
 int rgbm_table_read_column(const rgbm_table* t, int32_t col, int32_t* out /* [n] */);
 
+/* ---- the relational steps either side of the models, on the resident table -------
+ * Cells are (row position, column index) pairs; the host maps row ids <-> positions.  Result lists are
+ * ordered -- by position in the given column list, then ascending row -- so they are a deterministic function
+ * of the table.  A detect / rows_of_cells call leaves its result in the table object (device memory) and
+ * returns the count; rgbm_table_cells_fetch copies it out.  One such call at a time per table. */
+/* NullErrorDetector (src/main/scala/.../python/ErrorDetectorApi.scala:128-157): the NULL cells of `cols`. */
+int rgbm_table_detect_nulls(rgbm_table* t, const int32_t* cols, int32_t n_cols, int64_t* n_cells_out);
+/* ConstraintErrorDetector (ErrorDetectorApi.scala:189-244) for two-tuple denial constraints of the form
+ * t1&t2&EQ(t1.X1,t2.X1)&..&EQ(t1.Xm,t2.Xm)&IQ(t1.Y,t2.Y)  (i.e. X1..Xm -> Y): a row violates iff another row
+ * agrees with it on every X (NULL-safe, `<=>`) and differs on Y (NULL is a value of its own).  n_eq == 0 is allowed
+ * (IQ alone: every row violates as soon as Y takes two values).  Result: the violating rows x cell_cols
+ * (n_cell_cols == 0: just the rows). */
+int rgbm_table_detect_constraint(rgbm_table* t, const int32_t* eq_cols, int32_t n_eq, int32_t iq_col,
+                                 const int32_t* cell_cols, int32_t n_cell_cols,
+                                 int64_t* n_rows_out /* may be NULL */, int64_t* n_cells_out);
+/* Ascending positions of the rows that hold at least one of the given cells: the dirty rows of
+ * python/repair/model.py:549-553 (left-semi join on the row id). */
+int rgbm_table_rows_of_cells(rgbm_table* t, const int64_t* rows, int64_t n_cells, int64_t* n_rows_out);
+int rgbm_table_cells_fetch(const rgbm_table* t, int64_t* rows_out /* [n] or NULL */, int32_t* cols_out /* [n] or NULL */);
+/* convertErrorCellsToNull (src/main/scala/.../python/RepairApi.scala:171-211): NULL the listed cells whose
+ * column is one of target_cols; cells outside the table are ignored (join semantics). */
+int rgbm_table_null_cells(rgbm_table* t, const int64_t* rows, const int32_t* cols, int64_t n_cells,
+                          const int32_t* target_cols, int32_t n_targets);
+/* New resident table made of the given rows (the dirty-row frame the chained repair runs on). */
+int rgbm_table_gather_rows(const rgbm_table* t, const int64_t* rows, int64_t n_rows, rgbm_table** out);
+/* Rows per code of one column (+ NULL count): class weights (train.py:39-40,105), domain statistics. */
+int rgbm_table_count_codes(const rgbm_table* t, int32_t col, int64_t* counts_out /* [n_codes[col]] */,
+                           int64_t* n_null_out /* may be NULL */);
+/* Encoding on the device (replaces the pandas encoders of python/repair/model.py:701-729): per column, Arrow-style
+ * dictionary indices (idx < 0 = NULL) are mapped through remap[col][idx] (the rank of the dictionary value in
+ * sorted order, or -1) into the code table. */
+int rgbm_table_create_dict(const int32_t* idx_colmajor, int64_t n, int32_t c, const int32_t* const* remap,
+                           const int32_t* dict_size /* [c] */, int32_t device_id, rgbm_table** out);
+int rgbm_table_shape(const rgbm_table* t, int64_t* n_out, int32_t* c_out, int32_t* n_codes_out /* [c] or NULL */);
+
 /* ---- row-sharded multi-GPU training ------------------------------------------------------------
  * The reference parallelises training per target attribute (python/repair/model.py:817-926); a single
  * multiclass target cannot be split that way.  Here every rank (one process per GPU) uploads a ROW SHARD

@@ -26,7 +26,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/rgbm.h"
+#include "rgbm_host.h"
 #include "rgbm_kernels.h"
 #include "rgbm_level.h"
 
@@ -35,37 +35,10 @@
 namespace {
 
 thread_local std::string g_err;
-int fail(int code, const std::string& msg) { g_err = msg; return code; }
-
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) {                                                                        \
-            char b_[512];                                                                              \
-            snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            throw std::runtime_error(b_);                                                              \
-        }                                                                                              \
-    } while (0)
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr; size_t n = 0;
-    DevBuf() {}
-    explicit DevBuf(size_t count) { alloc(count); }
-    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
-    void alloc(size_t count) {
-        release(); n = count;
-        if (count) {
-            hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-            if (e != hipSuccess) { p = nullptr; char b[256]; snprintf(b, sizeof(b), "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); throw std::runtime_error(b); }
-        }
-    }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
-    ~DevBuf() { release(); }
-    void upload(const T* h, size_t count, hipStream_t s) { if (count) HIPCHK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }
-    void download(T* h, size_t count, hipStream_t s) const { if (count) HIPCHK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
-    void zero(hipStream_t s) { if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
-};
+}  // namespace
+std::string& rgh::last_error() { return g_err; }
+namespace {
+using rgh::fail; using rgh::DevBuf; using rgh::use_device; using rgh::StreamGuard; using rgh::guarded;
 
 // ---------------------------------------------------------------------------------------------
 // Row-sharded multi-GPU training (DESIGN.md "Multi-GPU"): every rank holds a row shard of the table and grows the
@@ -163,11 +136,6 @@ struct rgbm_model {
     ~rgbm_model() { for (auto& kv : dev) { (void)hipSetDevice(kv.first); delete kv.second; } }
 };
 
-struct rgbm_table {
-    int device = 0; int64_t n = 0; int32_t c = 0;
-    std::vector<int32_t> n_codes;
-    DevBuf<int32_t> codes;
-};
 
 namespace {
 
@@ -278,20 +246,6 @@ void check_params(const rgbm_params& p) {
     if (p.bagging_fraction <= 0.0 || p.bagging_fraction > 1.0) throw std::invalid_argument("bagging_fraction must be in (0, 1]");
     if (p.feature_fraction <= 0.0 || p.feature_fraction > 1.0) throw std::invalid_argument("feature_fraction must be in (0, 1]");
 }
-
-void use_device(int device_id) {
-    int nd = 0;
-    hipError_t e = hipGetDeviceCount(&nd);
-    if (e != hipSuccess || nd <= 0) throw std::domain_error("no HIP device available (this library has no CPU fallback)");
-    if (device_id < 0 || device_id >= nd) throw std::domain_error("device_id out of range: there are " + std::to_string(nd) + " HIP device(s)");
-    HIPCHK(hipSetDevice(device_id));
-}
-
-struct StreamGuard {
-    hipStream_t s = nullptr;
-    StreamGuard() { HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
-    ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
-};
 
 struct HostLabelStats {   // row-order weight sums, only used with per-row sample weights
     bool valid = false;
@@ -901,15 +855,6 @@ void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_c
     HIPCHK(hipStreamSynchronize(s));   // rec/raw are freed on return
 }
 
-template <typename Fn>
-int guarded(Fn&& fn) {
-    try { return fn(); }
-    catch (const std::invalid_argument& e) { return fail(RGBM_ERR_PARAM, e.what()); }
-    catch (const std::out_of_range& e) { return fail(RGBM_ERR_LABEL, e.what()); }
-    catch (const std::domain_error& e) { return fail(RGBM_ERR_NO_DEVICE, e.what()); }
-    catch (const std::bad_alloc&) { return fail(RGBM_ERR_NOMEM, "out of host memory"); }
-    catch (const std::exception& e) { return fail(RGBM_ERR_HIP, e.what()); }
-}
 
 void put(std::vector<uint8_t>& b, const void* p, size_t n) { const uint8_t* c = (const uint8_t*)p; b.insert(b.end(), c, c + n); }
 
@@ -935,7 +880,6 @@ std::vector<uint8_t> serialise(const rgbm_model& m) {
 // =============================================================================================
 extern "C" {
 
-#define RGBM_EXPORT __attribute__((visibility("default")))
 
 RGBM_EXPORT int rgbm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 RGBM_EXPORT const char* rgbm_last_error(void) { return g_err.c_str(); }

@@ -1,0 +1,85 @@
+// rgbm_host.h -- host-side plumbing shared by the translation units of librepairgbm.so:
+// thread-local error text, HIP error checks, device buffers, the HBM-resident table object.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <memory>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rgbm.h"
+
+#define RGBM_EXPORT __attribute__((visibility("default")))
+
+namespace rgh {
+
+std::string& last_error();                       // thread-local (defined in rgbm.hip)
+inline int fail(int code, const std::string& msg) { last_error() = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            char b_[512];                                                                              \
+            snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            throw std::runtime_error(b_);                                                              \
+        }                                                                                              \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    void alloc(size_t count) {
+        release(); n = count;
+        if (count) {
+            hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+            if (e != hipSuccess) { p = nullptr; char b[256]; snprintf(b, sizeof(b), "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); throw std::runtime_error(b); }
+        }
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    ~DevBuf() { release(); }
+    void upload(const T* h, size_t count, hipStream_t s) { if (count) HIPCHK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }
+    void download(T* h, size_t count, hipStream_t s) const { if (count) HIPCHK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
+    void zero(hipStream_t s) { if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+inline void use_device(int device_id) {
+    int nd = 0;
+    hipError_t e = hipGetDeviceCount(&nd);
+    if (e != hipSuccess || nd <= 0) throw std::domain_error("no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= nd) throw std::domain_error("device_id out of range: there are " + std::to_string(nd) + " HIP device(s)");
+    HIPCHK(hipSetDevice(device_id));
+}
+
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    StreamGuard() { HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+};
+
+// C++ exceptions never cross the C ABI: every entry point runs its body through this
+template <typename Fn>
+int guarded(Fn&& fn) {
+    try { return fn(); }
+    catch (const std::invalid_argument& e) { return fail(RGBM_ERR_PARAM, e.what()); }
+    catch (const std::out_of_range& e) { return fail(RGBM_ERR_LABEL, e.what()); }
+    catch (const std::domain_error& e) { return fail(RGBM_ERR_NO_DEVICE, e.what()); }
+    catch (const std::bad_alloc&) { return fail(RGBM_ERR_NOMEM, "out of host memory"); }
+    catch (const std::exception& e) { return fail(RGBM_ERR_HIP, e.what()); }
+}
+
+}  // namespace rgh
+
+// the label-encoded table, resident in HBM: int32 codes [c][n], column-major, -1 = NULL
+struct rgbm_table {
+    int device = 0; int64_t n = 0; int32_t c = 0;
+    std::vector<int32_t> n_codes;
+    rgh::DevBuf<int32_t> codes;
+    // result of the last rgbm_table_detect_* call (rgbm_prep.hip): cells (row, column), device resident
+    rgh::DevBuf<long long> cell_rows; rgh::DevBuf<int32_t> cell_cols; int64_t n_cells = 0;
+};

@@ -76,7 +76,10 @@ def lib():
                      "rgbm_table_create", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
                      "rgbm_model_save", "rgbm_model_load", "rgbm_model_info", "rgbm_model_importance",
                      "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
-                     "rgbm_local_group_create", "rgbm_comm_init_local"):
+                     "rgbm_local_group_create", "rgbm_comm_init_local",
+                     "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
+                     "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict",
+                     "rgbm_table_shape"):
             getattr(l, name).restype = C.c_int
         l.rgbm_local_group_free.restype = None
         l.rgbm_table_free.restype = None
@@ -91,6 +94,8 @@ EXPORTED_SYMBOLS = [
     "rgbm_model_save", "rgbm_model_load", "rgbm_model_free", "rgbm_model_info", "rgbm_model_importance",
     "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
     "rgbm_local_group_create", "rgbm_local_group_free", "rgbm_comm_init_local",
+    "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
+    "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict", "rgbm_table_shape",
 ]
 
 COMM_ID_BYTES = 128
@@ -263,6 +268,87 @@ class Table:
         _check(lib().rgbm_table_create(_p(codes, C.c_int32), C.c_int64(self.n), C.c_int32(self.c), _p(self.n_codes, C.c_int32),
                                        C.c_int32(device_id), C.byref(h)), "rgbm_table_create")
         self.h = h
+
+    @classmethod
+    def _adopt(cls, handle, device_id):
+        """Wrap a table the library has just created (gather_rows / from_dictionaries)."""
+        t = cls.__new__(cls)
+        t.h, t.device_id = handle, device_id
+        n, c = C.c_int64(0), C.c_int32(0)
+        _check(lib().rgbm_table_shape(handle, C.byref(n), C.byref(c), None), "rgbm_table_shape")
+        t.n, t.c = int(n.value), int(c.value)
+        t.n_codes = np.zeros(t.c, np.int32)
+        _check(lib().rgbm_table_shape(handle, None, None, _p(t.n_codes, C.c_int32)), "rgbm_table_shape")
+        return t
+
+    @classmethod
+    def from_dictionaries(cls, indices, remaps, device_id=0):
+        """Encode on the device: ``indices`` [C][n] int32 dictionary indices (< 0 = NULL), ``remaps[c][i]`` = code of
+        dictionary entry i of column c (its rank among the sorted distinct values; -1 = NULL)."""
+        idx = _i32(indices)
+        c, n = idx.shape
+        maps = [np.ascontiguousarray(m, np.int32) for m in remaps]
+        if len(maps) != c:
+            raise ValueError("one remap table per column expected")
+        ptrs = (C.POINTER(C.c_int32) * c)(*[_p(m if len(m) else np.zeros(1, np.int32), C.c_int32) for m in maps])
+        sizes = np.asarray([len(m) for m in maps], np.int32)
+        h = C.c_void_p()
+        _check(lib().rgbm_table_create_dict(_p(idx, C.c_int32), C.c_int64(n), C.c_int32(c), ptrs, _p(sizes, C.c_int32), C.c_int32(device_id),
+                                            C.byref(h)), "rgbm_table_create_dict")
+        return cls._adopt(h, device_id)
+
+    # ---- relational steps around the models (SURVEY 8(f) rows 2-4; csrc/rgbm_prep.hip)
+    def _fetch_cells(self, n, want_cols):
+        rows = np.zeros(n, np.int64)
+        cols = np.zeros(n, np.int32) if want_cols else None
+        if n:
+            _check(lib().rgbm_table_cells_fetch(self.h, _p(rows, C.c_int64), _p(cols, C.c_int32)), "rgbm_table_cells_fetch")
+        return (rows, cols) if want_cols else rows
+
+    def detect_nulls(self, cols):
+        """NULL cells of ``cols`` as (rows, cols), ordered by position in ``cols`` then row (ErrorDetectorApi.scala:128-157)."""
+        cc = _i32(np.asarray(cols, np.int32).reshape(-1))
+        n = C.c_int64(0)
+        _check(lib().rgbm_table_detect_nulls(self.h, _p(cc, C.c_int32), C.c_int32(len(cc)), C.byref(n)), "rgbm_table_detect_nulls")
+        return self._fetch_cells(int(n.value), True)
+
+    def detect_constraint(self, eq_cols, iq_col, cell_cols=()):
+        """Rows violating  EQ(eq_cols...) & IQ(iq_col)  (ErrorDetectorApi.scala:189-244).  Returns the ascending violating rows
+        when ``cell_cols`` is empty, else the cells (rows, cols) = violating rows x cell_cols, column-major."""
+        eq = _i32(np.asarray(eq_cols, np.int32).reshape(-1))
+        cc = _i32(np.asarray(cell_cols, np.int32).reshape(-1))
+        nr, nc = C.c_int64(0), C.c_int64(0)
+        _check(lib().rgbm_table_detect_constraint(self.h, _p(eq, C.c_int32), C.c_int32(len(eq)), C.c_int32(iq_col),
+                                                  _p(cc, C.c_int32), C.c_int32(len(cc)), C.byref(nr), C.byref(nc)), "rgbm_table_detect_constraint")
+        return self._fetch_cells(int(nc.value), len(cc) > 0)
+
+    def rows_of_cells(self, rows):
+        """Ascending positions of the rows that hold at least one of the given cells (the dirty rows, model.py:549-553)."""
+        r = np.ascontiguousarray(rows, np.int64)
+        n = C.c_int64(0)
+        _check(lib().rgbm_table_rows_of_cells(self.h, _p(r, C.c_int64), C.c_int64(len(r)), C.byref(n)), "rgbm_table_rows_of_cells")
+        return self._fetch_cells(int(n.value), False)
+
+    def null_cells(self, rows, cols, target_cols):
+        """convertErrorCellsToNull (RepairApi.scala:171-211), in place in HBM."""
+        r, c2, tc = np.ascontiguousarray(rows, np.int64), _i32(cols), _i32(np.asarray(target_cols, np.int32).reshape(-1))
+        if len(r) != len(c2):
+            raise ValueError("rows and cols must have the same length")
+        _check(lib().rgbm_table_null_cells(self.h, _p(r, C.c_int64), _p(c2, C.c_int32), C.c_int64(len(r)), _p(tc, C.c_int32), C.c_int32(len(tc))),
+               "rgbm_table_null_cells")
+
+    def gather_rows(self, rows):
+        r = np.ascontiguousarray(rows, np.int64)
+        h = C.c_void_p()
+        _check(lib().rgbm_table_gather_rows(self.h, _p(r, C.c_int64), C.c_int64(len(r)), C.byref(h)), "rgbm_table_gather_rows")
+        return Table._adopt(h, self.device_id)
+
+    def count_codes(self, col):
+        """(rows per code [n_codes[col]], NULL rows) of one column."""
+        out = np.zeros(int(self.n_codes[col]), np.int64)
+        nn = C.c_int64(0)
+        _check(lib().rgbm_table_count_codes(self.h, C.c_int32(col), _p(out, C.c_int64), C.byref(nn)), "rgbm_table_count_codes")
+        return out, int(nn.value)
 
     def close(self):
         h, self.h = getattr(self, "h", None), None

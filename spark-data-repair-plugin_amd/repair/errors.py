@@ -251,8 +251,9 @@ def _violating_rows(df: pd.DataFrame, preds: List[Predicate]) -> np.ndarray:
         else:
             gk = np.zeros(n, np.int64)
         if not iq:
-            cnt = np.bincount(gk, minlength=int(gk.max()) + 1 if n else 0)
-            return cnt[gk] > 1
+            # EQ predicates only: the reference's EXISTS sub-query ranges over ALL rows, t1 itself included
+            # (ErrorDetectorApi.scala:218-223), so every row satisfies it
+            return np.ones(n, bool)
         vk = _key(df[iq[0].left])
         pair = pd.DataFrame({"g": gk, "v": vk}).drop_duplicates()
         nd = np.bincount(pair["g"].to_numpy(), minlength=int(gk.max()) + 1 if n else 0)
