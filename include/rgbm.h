@@ -171,6 +171,15 @@ int rgbm_table_count_codes(const rgbm_table* t, int32_t col, int64_t* counts_out
  * sorted order, or -1) into the code table. */
 int rgbm_table_create_dict(const int32_t* idx_colmajor, int64_t n, int32_t c, const int32_t* const* remap,
                            const int32_t* dict_size /* [c] */, int32_t device_id, rgbm_table** out);
+/* Candidate distributions of the NULL cells of one target attribute (python/repair/model.py:1196-1212): for every row
+ * whose target cell is NULL (ascending), the model's classes by descending probability (ties keep class order), those
+ * with prob > threshold, at most top_k; class_out is padded with -1, prob_out with 0.  cur_code (optional, per cell: the
+ * code the cell held before it was NULLed, -1 = none) -> cur_prob_out = the model's probability of that value.
+ * More cells than `cap` is an error that still reports the count in n_cells_out (call again with enough room). */
+int rgbm_table_repair_pmf(rgbm_table* t, const rgbm_model* m, int32_t target_col, const int32_t* feat_cols, int32_t f,
+                          int32_t top_k, double threshold, const int32_t* cur_code, int64_t cap, int64_t* n_cells_out,
+                          int64_t* rows_out /* [cap] */, int32_t* class_out /* [cap][top_k] */,
+                          double* prob_out /* [cap][top_k] */, double* cur_prob_out /* [cap] or NULL */);
 int rgbm_table_shape(const rgbm_table* t, int64_t* n_out, int32_t* c_out, int32_t* n_codes_out /* [c] or NULL */);
 
 /* ---- row-sharded multi-GPU training ------------------------------------------------------------

@@ -875,6 +875,14 @@ std::vector<uint8_t> serialise(const rgbm_model& m) {
 
 }  // namespace
 
+void rgh::predict_proba_device(const rgbm_model* m, int device, hipStream_t s, const int32_t* d_codes, long long n, const int32_t* d_feat_cols,
+                               double* d_proba) {
+    predict_device(const_cast<rgbm_model*>(m), device, s, d_codes, n, 0, n, d_feat_cols, d_proba, nullptr, nullptr);
+}
+void rgh::model_shape(const rgbm_model* m, int32_t* objective, int32_t* num_class, int32_t* n_features) {
+    *objective = m->objective; *num_class = m->num_class; *n_features = m->F;
+}
+
 // =============================================================================================
 // C-ABI
 // =============================================================================================

@@ -73,6 +73,11 @@ int guarded(Fn&& fn) {
     catch (const std::exception& e) { return fail(RGBM_ERR_HIP, e.what()); }
 }
 
+// class probabilities [n][num_class] (row-major, device) of the n rows of a device code block [c][n]; defined in rgbm.hip
+void predict_proba_device(const rgbm_model* m, int device, hipStream_t s, const int32_t* d_codes, long long n, const int32_t* d_feat_cols,
+                          double* d_proba);
+void model_shape(const rgbm_model* m, int32_t* objective, int32_t* num_class, int32_t* n_features);
+
 }  // namespace rgh
 
 // the label-encoded table, resident in HBM: int32 codes [c][n], column-major, -1 = NULL

@@ -243,6 +243,45 @@ __global__ void k_encode_dict(const int32_t* __restrict__ idx, long long n, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// candidate distributions (python/repair/model.py:1196-1212): per cell, classes by descending probability (ties keep
+// class order), those > threshold, at most top_k.  One wave per cell: every step each lane proposes its best class
+// that comes AFTER the previous pick in (prob desc, class asc) order, a wave arg-max picks the next one.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_top_k_pmf(const double* __restrict__ proba, long long m, int K, int top_k, double threshold,
+                                                   const int32_t* __restrict__ cur_code, int32_t* __restrict__ cls_out,
+                                                   double* __restrict__ prob_out, double* __restrict__ cur_prob_out) {
+    const long long cell = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (cell >= m) return;
+    const int lane = lane_id();
+    const double* p = proba + cell * K;
+    double last_p = INFINITY; int last_c = -1;
+    for (int j = 0; j < top_k; ++j) {
+        double bp = -1.0; int bc = 0x7FFFFFFF;
+        for (int c = lane; c < K; c += 64) {
+            const double v = p[c];
+            const bool after = v < last_p || (v == last_p && c > last_c);
+            if (after && v > threshold && (v > bp || (v == bp && c < bc))) { bp = v; bc = c; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double op = __shfl_xor(bp, d); const int oc = __shfl_xor(bc, d);
+            if (op > bp || (op == bp && oc < bc)) { bp = op; bc = oc; }
+        }
+        const bool found = bc != 0x7FFFFFFF;
+        if (lane == 0) { cls_out[cell * top_k + j] = found ? bc : -1; prob_out[cell * top_k + j] = found ? bp : 0.0; }
+        if (!found) {                                   // nothing left above the threshold: pad the rest
+            for (int r = j + 1 + lane; r < top_k; r += 64) { cls_out[cell * top_k + r] = -1; prob_out[cell * top_k + r] = 0.0; }
+            break;
+        }
+        last_p = bp; last_c = bc;
+    }
+    if (cur_prob_out && lane == 0) {
+        const int cc = cur_code ? cur_code[cell] : -1;
+        cur_prob_out[cell] = (cc >= 0 && cc < K) ? p[cc] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 inline unsigned nblocks(long long n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -452,6 +491,46 @@ RGBM_EXPORT int rgbm_table_create_dict(const int32_t* idx_colmajor, int64_t n, i
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(sg.s));
         *out = t.release();
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_table_repair_pmf(rgbm_table* t, const rgbm_model* m, int32_t target_col, const int32_t* feat_cols, int32_t f, int32_t top_k,
+                                      double threshold, const int32_t* cur_code, int64_t cap, int64_t* n_cells_out, int64_t* rows_out,
+                                      int32_t* class_out, double* prob_out, double* cur_prob_out) {
+    if (!t || !m || !feat_cols || f <= 0 || target_col < 0 || target_col >= t->c || top_k <= 0 || !n_cells_out || cap < 0)
+        return fail(RGBM_ERR_ARG, "rgbm_table_repair_pmf: bad argument");
+    return guarded([&]() {
+        use_device(t->device);
+        check_cols(*t, feat_cols, f, "rgbm_table_repair_pmf");
+        int32_t obj = 0, K = 0, F = 0;
+        model_shape(m, &obj, &K, &F);
+        if (obj == 2) throw std::invalid_argument("rgbm_table_repair_pmf: a regressor has no class distribution (model.py:1214-1221 handles continuous attributes)");
+        if (F != f) throw std::invalid_argument("rgbm_table_repair_pmf: the model was trained on a different number of features");
+        StreamGuard sg;
+        DevBuf<int32_t> d_tc(1); d_tc.upload(&target_col, 1, sg.s);
+        const long long cells = compact<0>(*t, nullptr, d_tc.p, 1, false, sg.s);      // ascending rows whose target cell is NULL
+        *n_cells_out = cells;
+        if (cells == 0) return RGBM_OK;
+        if (cells > cap) throw std::invalid_argument("rgbm_table_repair_pmf: output capacity too small (n_cells_out holds the needed size)");
+        if (!rows_out || !class_out || !prob_out) throw std::invalid_argument("rgbm_table_repair_pmf: output arrays missing");
+        // the cells' rows as a small code block, scored in one go
+        DevBuf<int32_t> sub((size_t)cells * t->c);
+        hipLaunchKernelGGL(k_gather_rows, dim3(nblocks(cells, 256), (unsigned)t->c), dim3(256), 0, sg.s, t->codes.p, (long long)t->n, sub.p, cells, t->cell_rows.p);
+        DevBuf<int32_t> d_fc((size_t)f); d_fc.upload(feat_cols, (size_t)f, sg.s);
+        DevBuf<double> proba((size_t)cells * K);
+        predict_proba_device(m, t->device, sg.s, sub.p, cells, d_fc.p, proba.p);
+        DevBuf<int32_t> d_cls((size_t)cells * top_k); DevBuf<double> d_pr((size_t)cells * top_k);
+        DevBuf<int32_t> d_cur; DevBuf<double> d_cp;
+        if (cur_prob_out) { d_cp.alloc((size_t)cells); if (cur_code) { d_cur.alloc((size_t)cells); d_cur.upload(cur_code, (size_t)cells, sg.s); } }
+        hipLaunchKernelGGL(k_top_k_pmf, dim3(nblocks(cells, 4)), dim3(256), 0, sg.s, proba.p, cells, (int)K, (int)top_k, threshold,
+                           d_cur.p, d_cls.p, d_pr.p, d_cp.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(rows_out, t->cell_rows.p, (size_t)cells * 8, hipMemcpyDeviceToHost, sg.s));
+        d_cls.download(class_out, (size_t)cells * top_k, sg.s);
+        d_pr.download(prob_out, (size_t)cells * top_k, sg.s);
+        if (cur_prob_out) d_cp.download(cur_prob_out, (size_t)cells, sg.s);
+        HIPCHK(hipStreamSynchronize(sg.s));
         return RGBM_OK;
     });
 }

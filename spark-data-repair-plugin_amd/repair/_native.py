@@ -79,7 +79,7 @@ def lib():
                      "rgbm_local_group_create", "rgbm_comm_init_local",
                      "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
                      "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict",
-                     "rgbm_table_shape"):
+                     "rgbm_table_shape", "rgbm_table_repair_pmf"):
             getattr(l, name).restype = C.c_int
         l.rgbm_local_group_free.restype = None
         l.rgbm_table_free.restype = None
@@ -96,6 +96,7 @@ EXPORTED_SYMBOLS = [
     "rgbm_local_group_create", "rgbm_local_group_free", "rgbm_comm_init_local",
     "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
     "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict", "rgbm_table_shape",
+    "rgbm_table_repair_pmf",
 ]
 
 COMM_ID_BYTES = 128
@@ -342,6 +343,25 @@ class Table:
         h = C.c_void_p()
         _check(lib().rgbm_table_gather_rows(self.h, _p(r, C.c_int64), C.c_int64(len(r)), C.byref(h)), "rgbm_table_gather_rows")
         return Table._adopt(h, self.device_id)
+
+    def repair_pmf(self, model, target_col, feat_cols, top_k=32, threshold=0.0, cur_codes=None, want_cur_prob=False):
+        """Candidate distributions of the NULL cells of ``target_col`` (model.py:1196-1212).  Returns
+        (rows [m], classes [m][top_k] (-1 padded), probs [m][top_k] (0 padded)[, cur_prob [m]])."""
+        fc = _i32(feat_cols)
+        _, n_null = self.count_codes(target_col)
+        rows = np.zeros(n_null, np.int64)
+        cls = np.zeros((n_null, top_k), np.int32)
+        pr = np.zeros((n_null, top_k), np.float64)
+        cur = _i32(cur_codes)
+        if cur is not None and len(cur) != n_null:
+            raise ValueError("cur_codes must hold one code per NULL cell of the target (%d)" % n_null)
+        cp = np.zeros(n_null, np.float64) if (want_cur_prob or cur is not None) else None
+        n = C.c_int64(0)
+        _check(lib().rgbm_table_repair_pmf(self.h, model.h, C.c_int32(target_col), _p(fc, C.c_int32), C.c_int32(len(fc)), C.c_int32(top_k),
+                                           C.c_double(threshold), _p(cur, C.c_int32), C.c_int64(n_null), C.byref(n), _p(rows, C.c_int64),
+                                           _p(cls, C.c_int32), _p(pr, C.c_double), _p(cp, C.c_double)), "rgbm_table_repair_pmf")
+        assert int(n.value) == n_null
+        return (rows, cls, pr, cp) if cp is not None else (rows, cls, pr)
 
     def count_codes(self, col):
         """(rows per code [n_codes[col]], NULL rows) of one column."""

@@ -178,3 +178,51 @@ def test_millions_of_rows_properties():
     viol = tab.detect_constraint([0], 1)
     from oracle import prep as P
     assert np.array_equal(viol, P.constraint_rows(dirty, [0], 1))
+
+
+@pytest.mark.parametrize("tgt,top_k,thres", [(5, 32, 0.0), (5, 3, 0.05), (0, 2, 0.0), (0, 1, 0.6), (7, 5, 0.0)])
+def test_candidate_distributions_of_null_cells(tgt, top_k, thres):
+    """rgbm_table_repair_pmf == oracle model's predict_proba on the NULL rows, sorted / filtered / sliced by the oracle."""
+    from oracle import oracle as O
+    from oracle import prep as P
+    from repair import _native as N
+    from tests.synth import balanced_weights
+    dirty, clean, cards = make_table(9000, 8, seed=41, null_ratio=0.04)
+    feats = [c for c in range(8) if c != tgt]
+    K = int(cards[tgt])
+    rows_tr = dirty[tgt] >= 0
+    kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=12, learning_rate=0.2)
+    cw = balanced_weights(dirty[tgt], K)
+    tab = N.Table(dirty, cards)
+    mg = tab.train(tgt, feats, class_weight=cw, **kw)
+    mo = O.train(np.ascontiguousarray(dirty[feats][:, rows_tr]), cards[feats], dirty[tgt][rows_tr], K, class_weight=cw, **kw)
+    assert mo.save() == mg.save()
+    null_rows = np.flatnonzero(dirty[tgt] < 0)
+    proba = mo.predict(np.ascontiguousarray(dirty[feats][:, null_rows]))
+    want_cls, want_pr = P.top_k_pmf(proba, top_k, thres)
+    cur = clean[tgt][null_rows].astype(np.int32)
+    cur[::7] = -1
+    rows, cls, pr, cp = tab.repair_pmf(mg, tgt, feats, top_k=top_k, threshold=thres, cur_codes=cur)
+    assert np.array_equal(rows, null_rows)
+    assert np.array_equal(cls, want_cls)
+    assert np.array_equal(pr, want_pr)
+    assert np.array_equal(cp, np.where(cur >= 0, proba[np.arange(len(cur)), np.maximum(cur, 0)], 0.0))
+
+
+def test_candidate_distributions_edge_cases():
+    from repair import _native as N
+    dirty, clean, cards = make_table(3000, 5, seed=43, null_ratio=0.0)
+    tab = N.Table(dirty, cards)
+    m = tab.train(3, [0, 1, 2, 4], objective=1, num_class=int(cards[3]), n_estimators=3)
+    rows, cls, pr = tab.repair_pmf(m, 3, [0, 1, 2, 4])                  # no NULL cell at all
+    assert rows.shape == (0,) and cls.shape == (0, 32) and pr.shape == (0, 32)
+    reg = N.train(dirty[:4], cards[:4], clean[4] % 5, 5, y_value=np.arange(5.0), objective=2, num_class=2, n_estimators=2)
+    tab.null_cells([1, 2], [3, 3], [3])
+    with pytest.raises(N.RepairGbmError):
+        tab.repair_pmf(reg, 3, [0, 1, 2, 4])
+    with pytest.raises(N.RepairGbmError):
+        tab.repair_pmf(m, 3, [0, 1, 2])                                # wrong feature count
+    rows, cls, pr = tab.repair_pmf(m, 3, [0, 1, 2, 4], top_k=40, threshold=0.0)     # top_k > num_class: padded
+    K = int(cards[3])
+    assert rows.tolist() == [1, 2] and (cls[:, K:] == -1).all() and (pr[:, K:] == 0).all() and (np.sort(cls[:, :K], axis=1) == np.arange(K)).all()
+    assert (np.diff(pr[:, :K], axis=1) <= 0).all() and np.allclose(pr.sum(1), 1.0)
