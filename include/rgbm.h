@@ -161,6 +161,8 @@ int rgbm_table_cells_fetch(const rgbm_table* t, int64_t* rows_out /* [n] or NULL
  * column is one of target_cols; cells outside the table are ignored (join semantics). */
 int rgbm_table_null_cells(rgbm_table* t, const int64_t* rows, const int32_t* cols, int64_t n_cells,
                           const int32_t* target_cols, int32_t n_targets);
+/* The codes the given cells hold now (cells outside the table read as NULL): the `current_value` of the error cells. */
+int rgbm_table_read_cells(const rgbm_table* t, const int64_t* rows, const int32_t* cols, int64_t n_cells, int32_t* codes_out);
 /* New resident table made of the given rows (the dirty-row frame the chained repair runs on). */
 int rgbm_table_gather_rows(const rgbm_table* t, const int64_t* rows, int64_t n_rows, rgbm_table** out);
 /* Rows per code of one column (+ NULL count): class weights (train.py:39-40,105), domain statistics. */

@@ -199,6 +199,14 @@ __global__ void k_null_cells(int32_t* __restrict__ codes, long long n, int c, co
     codes[(long long)cc * n + r] = -1;
 }
 
+__global__ void k_read_cells(const int32_t* __restrict__ codes, long long n, int c, const long long* __restrict__ rows,
+                             const int32_t* __restrict__ cols, long long m, int32_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const long long r = rows[i]; const int cc = cols[i];
+    out[i] = (r < 0 || r >= n || cc < 0 || cc >= c) ? -1 : codes[(long long)cc * n + r];
+}
+
 __global__ void k_mark_rows(uint8_t* __restrict__ mask, long long n, const long long* __restrict__ rows, long long m) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
@@ -419,6 +427,24 @@ RGBM_EXPORT int rgbm_table_null_cells(rgbm_table* t, const int64_t* rows, const 
         hipLaunchKernelGGL(k_null_cells, dim3(nblocks(n_cells, 256)), dim3(256), 0, sg.s, t->codes.p, (long long)t->n, (int)t->c, d_rows.p, d_cols.p,
                            (long long)n_cells, d_t.p);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(sg.s));
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_table_read_cells(const rgbm_table* t, const int64_t* rows, const int32_t* cols, int64_t n_cells, int32_t* codes_out) {
+    if (!t || n_cells < 0 || (n_cells > 0 && (!rows || !cols || !codes_out))) return fail(RGBM_ERR_ARG, "rgbm_table_read_cells: bad argument");
+    return guarded([&]() {
+        use_device(t->device);
+        if (n_cells == 0) return RGBM_OK;
+        StreamGuard sg;
+        DevBuf<long long> d_rows((size_t)n_cells); d_rows.upload(reinterpret_cast<const long long*>(rows), (size_t)n_cells, sg.s);
+        DevBuf<int32_t> d_cols((size_t)n_cells); d_cols.upload(cols, (size_t)n_cells, sg.s);
+        DevBuf<int32_t> d_out((size_t)n_cells);
+        hipLaunchKernelGGL(k_read_cells, dim3(nblocks(n_cells, 256)), dim3(256), 0, sg.s, t->codes.p, (long long)t->n, (int)t->c, d_rows.p, d_cols.p,
+                           (long long)n_cells, d_out.p);
+        HIPCHK(hipGetLastError());
+        d_out.download(codes_out, (size_t)n_cells, sg.s);
         HIPCHK(hipStreamSynchronize(sg.s));
         return RGBM_OK;
     });

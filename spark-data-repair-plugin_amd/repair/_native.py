@@ -79,7 +79,7 @@ def lib():
                      "rgbm_local_group_create", "rgbm_comm_init_local",
                      "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
                      "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict",
-                     "rgbm_table_shape", "rgbm_table_repair_pmf"):
+                     "rgbm_table_shape", "rgbm_table_repair_pmf", "rgbm_table_read_cells"):
             getattr(l, name).restype = C.c_int
         l.rgbm_local_group_free.restype = None
         l.rgbm_table_free.restype = None
@@ -96,7 +96,7 @@ EXPORTED_SYMBOLS = [
     "rgbm_local_group_create", "rgbm_local_group_free", "rgbm_comm_init_local",
     "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
     "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict", "rgbm_table_shape",
-    "rgbm_table_repair_pmf",
+    "rgbm_table_repair_pmf", "rgbm_table_read_cells",
 ]
 
 COMM_ID_BYTES = 128
@@ -337,6 +337,12 @@ class Table:
             raise ValueError("rows and cols must have the same length")
         _check(lib().rgbm_table_null_cells(self.h, _p(r, C.c_int64), _p(c2, C.c_int32), C.c_int64(len(r)), _p(tc, C.c_int32), C.c_int32(len(tc))),
                "rgbm_table_null_cells")
+
+    def read_cells(self, rows, cols):
+        r, c2 = np.ascontiguousarray(rows, np.int64), _i32(cols)
+        out = np.zeros(len(r), np.int32)
+        _check(lib().rgbm_table_read_cells(self.h, _p(r, C.c_int64), _p(c2, C.c_int32), C.c_int64(len(r)), _p(out, C.c_int32)), "rgbm_table_read_cells")
+        return out
 
     def gather_rows(self, rows):
         r = np.ascontiguousarray(rows, np.int64)

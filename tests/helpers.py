@@ -67,6 +67,46 @@ class OracleEngine:
             self.n_codes = np.asarray(n_codes, np.int32)
             self.c, self.n = self.codes.shape
 
+        # the relational steps of repair.pipeline, restated by oracle/prep.py (same method names as repair._native.Table)
+        def detect_nulls(self, cols):
+            from oracle import prep as P
+            return P.detect_nulls(self.codes, list(cols))
+
+        def detect_constraint(self, eq_cols, iq_col, cell_cols=()):
+            from oracle import prep as P
+            rows, cols = P.constraint_cells(self.codes, list(eq_cols), iq_col, list(cell_cols))
+            return rows if cols is None else (rows, cols)
+
+        def read_cells(self, rows, cols):
+            return self.codes[np.asarray(cols, np.int64), np.asarray(rows, np.int64)].astype(np.int32)
+
+        def null_cells(self, rows, cols, target_cols):
+            from oracle import prep as P
+            self.codes = P.null_cells(self.codes, rows, cols, target_cols)
+
+        def rows_of_cells(self, rows):
+            from oracle import prep as P
+            return P.rows_of_cells(self.n, rows)
+
+        def gather_rows(self, rows):
+            return OracleEngine._Table(self.codes[:, np.asarray(rows, np.int64)], self.n_codes)
+
+        def count_codes(self, col):
+            from oracle import prep as P
+            return P.count_codes(self.codes, col, int(self.n_codes[col]))
+
+        def repair_pmf(self, model, target_col, feat_cols, top_k=32, threshold=0.0, cur_codes=None, want_cur_prob=False):
+            from oracle import prep as P
+            rows = np.flatnonzero(self.codes[target_col] < 0).astype(np.int64)
+            K = model.info()["num_class"]
+            proba = model.predict(np.ascontiguousarray(self.codes[list(feat_cols)][:, rows])) if len(rows) else np.zeros((0, K))
+            cls, pr = P.top_k_pmf(proba, top_k, threshold)
+            if cur_codes is None and not want_cur_prob:
+                return rows, cls, pr
+            cur = np.full(len(rows), -1, np.int32) if cur_codes is None else np.asarray(cur_codes, np.int32)
+            cp = np.where(cur >= 0, proba[np.arange(len(rows)), np.maximum(cur, 0)], 0.0) if len(rows) else np.zeros(0)
+            return rows, cls, pr, cp
+
     def upload(self, codes, n_codes):
         return OracleEngine._Table(codes, n_codes)
 
