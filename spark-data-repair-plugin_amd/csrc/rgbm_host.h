@@ -87,4 +87,9 @@ struct rgbm_table {
     rgh::DevBuf<int32_t> codes;
     // result of the last rgbm_table_detect_* call (rgbm_prep.hip): cells (row, column), device resident
     rgh::DevBuf<long long> cell_rows; rgh::DevBuf<int32_t> cell_cols; int64_t n_cells = 0;
+    // stream + scratch of the relational steps (rgbm_prep.hip), kept with the table: a hipMalloc / hipFree / stream
+    // creation per call costs more than the kernels (one call at a time per table, as the header says)
+    mutable hipStream_t stream = nullptr;
+    mutable rgh::DevBuf<unsigned char> scratch[12];
+    ~rgbm_table() { if (stream) (void)hipStreamDestroy(stream); }
 };

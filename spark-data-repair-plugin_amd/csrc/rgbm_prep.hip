@@ -163,13 +163,13 @@ __global__ __launch_bounds__(256) void k_ht_insert(const int32_t* __restrict__ c
     // so a plain read that already shows the final answer makes the atomic unnecessary: low-cardinality keys (few
     // groups, millions of rows each) would otherwise serialise on a handful of addresses.
     for (;;) {
-        unsigned long long prev = __builtin_nontemporal_load(&keys[slot]);
+        unsigned long long prev = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read at L2, never a stale L1 line
         if (prev == key) break;
         if (prev == HT_EMPTY) { prev = atomicCAS(&keys[slot], HT_EMPTY, key); if (prev == HT_EMPTY || prev == key) break; }
         slot = (slot + 1) & cap_mask;
     }
     const unsigned v = (unsigned)(codes[(long long)iq_col * n + i] + 1) + 1u;            // >= 1; NULL is a value of its own (<=>)
-    unsigned old = __builtin_nontemporal_load(&state[slot]);
+    unsigned old = __hip_atomic_load(&state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((old >> 31) || old == v) return;
     if (old == 0u) old = atomicCAS(&state[slot], 0u, v);
     if (old != 0u && (old & 0x7FFFFFFFu) != v) atomicOr(&state[slot], 0x80000000u);
@@ -294,22 +294,41 @@ __global__ __launch_bounds__(256) void k_top_k_pmf(const double* __restrict__ pr
 // ---------------------------------------------------------------------------------------------
 inline unsigned nblocks(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
+hipStream_t table_stream(const rgbm_table& t) {
+    if (!t.stream) HIPCHK(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+    return t.stream;
+}
+// scratch slot `slot` of the table, at least `count` elements of T (grown, never shrunk)
+template <typename T>
+T* scr(const rgbm_table& t, int slot, size_t count) {
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (t.scratch[slot].n < bytes) t.scratch[slot].alloc(bytes + bytes / 4);
+    return reinterpret_cast<T*>(t.scratch[slot].p);
+}
+template <typename T>
+T* scr_upload(const rgbm_table& t, int slot, const T* host, size_t count, hipStream_t s) {
+    T* d = scr<T>(t, slot, count);
+    if (count) HIPCHK(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+    return d;
+}
+
 // ordered compaction of the flagged (row, column) cells into t.cell_rows / t.cell_cols; returns the cell count
 template <int MODE>
 long long compact(rgbm_table& t, const uint8_t* d_mask, const int32_t* d_cols, int ncols, bool want_cols, hipStream_t s) {
     const long long n = t.n, nblk = (n + PROWS - 1) / PROWS, m = nblk * ncols;
-    DevBuf<unsigned long long> ballots((size_t)m * PBAL);
-    DevBuf<unsigned> bcount((size_t)m);
-    DevBuf<long long> off((size_t)m + 1);
-    hipLaunchKernelGGL(k_flag<MODE>, dim3((unsigned)nblk, (unsigned)ncols), dim3(PB), 0, s, t.codes.p, d_mask, d_cols, n, nblk, ballots.p, bcount.p);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, bcount.p, m, off.p, off.p + m);
+    unsigned long long* ballots = scr<unsigned long long>(t, 0, (size_t)m * PBAL);
+    unsigned* bcount = scr<unsigned>(t, 1, (size_t)m);
+    long long* off = scr<long long>(t, 2, (size_t)m + 1);
+    hipLaunchKernelGGL(k_flag<MODE>, dim3((unsigned)nblk, (unsigned)ncols), dim3(PB), 0, s, t.codes.p, d_mask, d_cols, n, nblk, ballots, bcount);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, bcount, m, off, off + m);
     long long total = 0;
-    HIPCHK(hipMemcpyAsync(&total, off.p + m, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&total, off + m, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    t.cell_rows.alloc((size_t)std::max<long long>(total, 1));
-    if (want_cols) t.cell_cols.alloc((size_t)std::max<long long>(total, 1)); else t.cell_cols.release();
+    if (t.cell_rows.n < (size_t)std::max<long long>(total, 1)) t.cell_rows.alloc((size_t)std::max<long long>(total, 1) * 5 / 4);
+    if (want_cols) { if (t.cell_cols.n < (size_t)std::max<long long>(total, 1)) t.cell_cols.alloc((size_t)std::max<long long>(total, 1) * 5 / 4); }
+    else t.cell_cols.release();
     if (total > 0)
-        hipLaunchKernelGGL(k_emit, dim3((unsigned)nblk, (unsigned)ncols), dim3(PB), 0, s, ballots.p, off.p, want_cols ? d_cols : nullptr, nblk,
+        hipLaunchKernelGGL(k_emit, dim3((unsigned)nblk, (unsigned)ncols), dim3(PB), 0, s, ballots, off, want_cols ? d_cols : nullptr, nblk,
                            t.cell_rows.p, want_cols ? t.cell_cols.p : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
@@ -331,9 +350,9 @@ RGBM_EXPORT int rgbm_table_detect_nulls(rgbm_table* t, const int32_t* cols, int3
         use_device(t->device);
         check_cols(*t, cols, n_cols, "rgbm_table_detect_nulls");
         if (n_cols == 0) { t->n_cells = 0; *n_cells_out = 0; return RGBM_OK; }
-        StreamGuard sg;
-        DevBuf<int32_t> d_cols((size_t)n_cols); d_cols.upload(cols, (size_t)n_cols, sg.s);
-        *n_cells_out = compact<0>(*t, nullptr, d_cols.p, n_cols, true, sg.s);
+        hipStream_t s = table_stream(*t);
+        const int32_t* d_cols = scr_upload<int32_t>(*t, 6, cols, (size_t)n_cols, s);
+        *n_cells_out = compact<0>(*t, nullptr, d_cols, n_cols, true, s);
         return RGBM_OK;
     });
 }
@@ -354,23 +373,29 @@ RGBM_EXPORT int rgbm_table_detect_constraint(rgbm_table* t, const int32_t* eq_co
             span *= ks.radix[i];
             if (span >= ((unsigned __int128)1 << 63)) throw std::invalid_argument("rgbm_table_detect_constraint: the EQ attributes span more than 2^63 value combinations");
         }
-        StreamGuard sg;
+        hipStream_t s = table_stream(*t);
         const long long n = t->n;
-        unsigned long long cap = 1024; while (cap < (unsigned long long)n * 2ull) cap <<= 1;
-        DevBuf<unsigned long long> keys((size_t)cap); DevBuf<unsigned> state((size_t)cap); DevBuf<uint8_t> mask((size_t)n);
-        HIPCHK(hipMemsetAsync(keys.p, 0xFF, (size_t)cap * 8, sg.s));
-        state.zero(sg.s);
+        // the table never needs more slots than twice the number of possible keys
+        unsigned long long want = (unsigned long long)n * 2ull;
+        if (span < (unsigned __int128)want) want = (unsigned long long)span * 2ull;
+        unsigned long long cap = 1024; while (cap < want) cap <<= 1;
+        unsigned long long* keys = scr<unsigned long long>(*t, 3, (size_t)cap);
+        unsigned* state = scr<unsigned>(*t, 4, (size_t)cap);
+        uint8_t* mask = scr<uint8_t>(*t, 5, (size_t)n);
+        HIPCHK(hipMemsetAsync(keys, 0xFF, (size_t)cap * 8, s));
+        HIPCHK(hipMemsetAsync(state, 0, (size_t)cap * 4, s));
         const unsigned nb = nblocks(n, 256);
-        hipLaunchKernelGGL(k_ht_insert, dim3(nb), dim3(256), 0, sg.s, t->codes.p, n, ks, iq_col, keys.p, state.p, cap - 1);
-        hipLaunchKernelGGL(k_ht_lookup, dim3(nb), dim3(256), 0, sg.s, t->codes.p, n, ks, keys.p, state.p, cap - 1, mask.p);
-        const long long m = compact<1>(*t, mask.p, nullptr, 1, false, sg.s);     // ascending violating rows
+        hipLaunchKernelGGL(k_ht_insert, dim3(nb), dim3(256), 0, s, t->codes.p, n, ks, iq_col, keys, state, cap - 1);
+        hipLaunchKernelGGL(k_ht_lookup, dim3(nb), dim3(256), 0, s, t->codes.p, n, ks, keys, state, cap - 1, mask);
+        const long long m = compact<1>(*t, mask, nullptr, 1, false, s);     // ascending violating rows
         if (n_rows_out) *n_rows_out = m;
         if (n_cell_cols > 0) {
-            DevBuf<long long> rows_r((size_t)std::max<long long>(m * n_cell_cols, 1)); DevBuf<int32_t> cols_r((size_t)std::max<long long>(m * n_cell_cols, 1));
-            DevBuf<int32_t> d_cc((size_t)n_cell_cols); d_cc.upload(cell_cols, (size_t)n_cell_cols, sg.s);
-            if (m > 0) hipLaunchKernelGGL(k_replicate, dim3(nblocks(m, 256)), dim3(256), 0, sg.s, t->cell_rows.p, m, d_cc.p, n_cell_cols, rows_r.p, cols_r.p);
+            const size_t tot = (size_t)std::max<long long>(m * n_cell_cols, 1);
+            DevBuf<long long> rows_r(tot); DevBuf<int32_t> cols_r(tot);
+            const int32_t* d_cc = scr_upload<int32_t>(*t, 6, cell_cols, (size_t)n_cell_cols, s);
+            if (m > 0) hipLaunchKernelGGL(k_replicate, dim3(nblocks(m, 256)), dim3(256), 0, s, t->cell_rows.p, m, d_cc, n_cell_cols, rows_r.p, cols_r.p);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(sg.s));
+            HIPCHK(hipStreamSynchronize(s));
             std::swap(t->cell_rows.p, rows_r.p); std::swap(t->cell_rows.n, rows_r.n);
             std::swap(t->cell_cols.p, cols_r.p); std::swap(t->cell_cols.n, cols_r.n);
             t->n_cells = m * n_cell_cols;
@@ -384,13 +409,13 @@ RGBM_EXPORT int rgbm_table_rows_of_cells(rgbm_table* t, const int64_t* rows, int
     if (!t || !n_rows_out || n_cells < 0 || (n_cells > 0 && !rows)) return fail(RGBM_ERR_ARG, "rgbm_table_rows_of_cells: bad argument");
     return guarded([&]() {
         use_device(t->device);
-        StreamGuard sg;
-        DevBuf<uint8_t> mask((size_t)t->n); mask.zero(sg.s);
-        DevBuf<long long> d_rows((size_t)std::max<int64_t>(n_cells, 1));
+        hipStream_t s = table_stream(*t);
+        uint8_t* mask = scr<uint8_t>(*t, 5, (size_t)t->n);
+        HIPCHK(hipMemsetAsync(mask, 0, (size_t)t->n, s));
         static_assert(sizeof(long long) == sizeof(int64_t), "row positions are 64-bit");
-        d_rows.upload(reinterpret_cast<const long long*>(rows), (size_t)n_cells, sg.s);
-        if (n_cells > 0) hipLaunchKernelGGL(k_mark_rows, dim3(nblocks(n_cells, 256)), dim3(256), 0, sg.s, mask.p, (long long)t->n, d_rows.p, (long long)n_cells);
-        *n_rows_out = compact<1>(*t, mask.p, nullptr, 1, false, sg.s);
+        const long long* d_rows = scr_upload<long long>(*t, 7, reinterpret_cast<const long long*>(rows), (size_t)n_cells, s);
+        if (n_cells > 0) hipLaunchKernelGGL(k_mark_rows, dim3(nblocks(n_cells, 256)), dim3(256), 0, s, mask, (long long)t->n, d_rows, (long long)n_cells);
+        *n_rows_out = compact<1>(*t, mask, nullptr, 1, false, s);
         return RGBM_OK;
     });
 }
@@ -418,16 +443,16 @@ RGBM_EXPORT int rgbm_table_null_cells(rgbm_table* t, const int64_t* rows, const 
         use_device(t->device);
         check_cols(*t, target_cols, n_targets, "rgbm_table_null_cells");
         if (n_cells == 0 || n_targets == 0) return RGBM_OK;
-        StreamGuard sg;
+        hipStream_t s = table_stream(*t);
         std::vector<uint8_t> is_t((size_t)t->c, 0);
         for (int i = 0; i < n_targets; ++i) is_t[target_cols[i]] = 1;
-        DevBuf<uint8_t> d_t((size_t)t->c); d_t.upload(is_t.data(), is_t.size(), sg.s);
-        DevBuf<long long> d_rows((size_t)n_cells); d_rows.upload(reinterpret_cast<const long long*>(rows), (size_t)n_cells, sg.s);
-        DevBuf<int32_t> d_cols((size_t)n_cells); d_cols.upload(cols, (size_t)n_cells, sg.s);
-        hipLaunchKernelGGL(k_null_cells, dim3(nblocks(n_cells, 256)), dim3(256), 0, sg.s, t->codes.p, (long long)t->n, (int)t->c, d_rows.p, d_cols.p,
-                           (long long)n_cells, d_t.p);
+        const uint8_t* d_t = scr_upload<uint8_t>(*t, 6, is_t.data(), is_t.size(), s);
+        const long long* d_rows = scr_upload<long long>(*t, 7, reinterpret_cast<const long long*>(rows), (size_t)n_cells, s);
+        const int32_t* d_cols = scr_upload<int32_t>(*t, 8, cols, (size_t)n_cells, s);
+        hipLaunchKernelGGL(k_null_cells, dim3(nblocks(n_cells, 256)), dim3(256), 0, s, t->codes.p, (long long)t->n, (int)t->c, d_rows, d_cols,
+                           (long long)n_cells, d_t);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(sg.s));
+        HIPCHK(hipStreamSynchronize(s));      // is_t and the caller's arrays are read by the async copies
         return RGBM_OK;
     });
 }
@@ -437,15 +462,15 @@ RGBM_EXPORT int rgbm_table_read_cells(const rgbm_table* t, const int64_t* rows, 
     return guarded([&]() {
         use_device(t->device);
         if (n_cells == 0) return RGBM_OK;
-        StreamGuard sg;
-        DevBuf<long long> d_rows((size_t)n_cells); d_rows.upload(reinterpret_cast<const long long*>(rows), (size_t)n_cells, sg.s);
-        DevBuf<int32_t> d_cols((size_t)n_cells); d_cols.upload(cols, (size_t)n_cells, sg.s);
-        DevBuf<int32_t> d_out((size_t)n_cells);
-        hipLaunchKernelGGL(k_read_cells, dim3(nblocks(n_cells, 256)), dim3(256), 0, sg.s, t->codes.p, (long long)t->n, (int)t->c, d_rows.p, d_cols.p,
-                           (long long)n_cells, d_out.p);
+        hipStream_t s = table_stream(*t);
+        const long long* d_rows = scr_upload<long long>(*t, 7, reinterpret_cast<const long long*>(rows), (size_t)n_cells, s);
+        const int32_t* d_cols = scr_upload<int32_t>(*t, 8, cols, (size_t)n_cells, s);
+        int32_t* d_out = scr<int32_t>(*t, 9, (size_t)n_cells);
+        hipLaunchKernelGGL(k_read_cells, dim3(nblocks(n_cells, 256)), dim3(256), 0, s, t->codes.p, (long long)t->n, (int)t->c, d_rows, d_cols,
+                           (long long)n_cells, d_out);
         HIPCHK(hipGetLastError());
-        d_out.download(codes_out, (size_t)n_cells, sg.s);
-        HIPCHK(hipStreamSynchronize(sg.s));
+        HIPCHK(hipMemcpyAsync(codes_out, d_out, (size_t)n_cells * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
         return RGBM_OK;
     });
 }
@@ -455,15 +480,15 @@ RGBM_EXPORT int rgbm_table_gather_rows(const rgbm_table* t, const int64_t* rows,
     return guarded([&]() {
         use_device(t->device);
         for (int64_t i = 0; i < n_rows; ++i) if (rows[i] < 0 || rows[i] >= t->n) throw std::invalid_argument("rgbm_table_gather_rows: row position out of range");
-        StreamGuard sg;
+        hipStream_t s = table_stream(*t);
         std::unique_ptr<rgbm_table> o(new rgbm_table());
         o->device = t->device; o->n = n_rows; o->c = t->c; o->n_codes = t->n_codes;
         o->codes.alloc((size_t)n_rows * t->c);
-        DevBuf<long long> d_rows((size_t)n_rows); d_rows.upload(reinterpret_cast<const long long*>(rows), (size_t)n_rows, sg.s);
-        hipLaunchKernelGGL(k_gather_rows, dim3(nblocks(n_rows, 256), (unsigned)t->c), dim3(256), 0, sg.s, t->codes.p, (long long)t->n, o->codes.p,
-                           (long long)n_rows, d_rows.p);
+        const long long* d_rows = scr_upload<long long>(*t, 7, reinterpret_cast<const long long*>(rows), (size_t)n_rows, s);
+        hipLaunchKernelGGL(k_gather_rows, dim3(nblocks(n_rows, 256), (unsigned)t->c), dim3(256), 0, s, t->codes.p, (long long)t->n, o->codes.p,
+                           (long long)n_rows, d_rows);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(sg.s));
+        HIPCHK(hipStreamSynchronize(s));
         *out = o.release();
         return RGBM_OK;
     });
@@ -473,15 +498,16 @@ RGBM_EXPORT int rgbm_table_count_codes(const rgbm_table* t, int32_t col, int64_t
     if (!t || !counts_out || col < 0 || col >= t->c) return fail(RGBM_ERR_ARG, "rgbm_table_count_codes: bad argument");
     return guarded([&]() {
         use_device(t->device);
-        StreamGuard sg;
+        hipStream_t s = table_stream(*t);
         const int nc = t->n_codes[col];
-        DevBuf<unsigned long long> d_cnt((size_t)nc + 1); d_cnt.zero(sg.s);
+        unsigned long long* d_cnt = scr<unsigned long long>(*t, 9, (size_t)nc + 1);
+        HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)nc + 1) * 8, s));
         const unsigned nb = std::min<unsigned>(nblocks(t->n, 256 * 16), 256u * 8u);
-        hipLaunchKernelGGL(k_count_codes, dim3(std::max(nb, 1u)), dim3(256), 0, sg.s, t->codes.p + (size_t)col * t->n, (long long)t->n, nc, d_cnt.p);
+        hipLaunchKernelGGL(k_count_codes, dim3(std::max(nb, 1u)), dim3(256), 0, s, t->codes.p + (size_t)col * t->n, (long long)t->n, nc, d_cnt);
         HIPCHK(hipGetLastError());
         std::vector<unsigned long long> h((size_t)nc + 1);
-        d_cnt.download(h.data(), h.size(), sg.s);
-        HIPCHK(hipStreamSynchronize(sg.s));
+        HIPCHK(hipMemcpyAsync(h.data(), d_cnt, h.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
         for (int i = 0; i < nc; ++i) counts_out[i] = (int64_t)h[i];
         if (n_null_out) *n_null_out = (int64_t)h[nc];
         return RGBM_OK;
@@ -533,9 +559,9 @@ RGBM_EXPORT int rgbm_table_repair_pmf(rgbm_table* t, const rgbm_model* m, int32_
         model_shape(m, &obj, &K, &F);
         if (obj == 2) throw std::invalid_argument("rgbm_table_repair_pmf: a regressor has no class distribution (model.py:1214-1221 handles continuous attributes)");
         if (F != f) throw std::invalid_argument("rgbm_table_repair_pmf: the model was trained on a different number of features");
-        StreamGuard sg;
-        DevBuf<int32_t> d_tc(1); d_tc.upload(&target_col, 1, sg.s);
-        const long long cells = compact<0>(*t, nullptr, d_tc.p, 1, false, sg.s);      // ascending rows whose target cell is NULL
+        struct { hipStream_t s; } sg{table_stream(*t)};
+        const int32_t* d_tc = scr_upload<int32_t>(*t, 6, &target_col, 1, sg.s);
+        const long long cells = compact<0>(*t, nullptr, d_tc, 1, false, sg.s);      // ascending rows whose target cell is NULL
         *n_cells_out = cells;
         if (cells == 0) return RGBM_OK;
         if (cells > cap) throw std::invalid_argument("rgbm_table_repair_pmf: output capacity too small (n_cells_out holds the needed size)");
