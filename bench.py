@@ -132,6 +132,7 @@ def main():
     null_cells = dirty_rows < 0
     del dirty, train_src
 
+    row_sharding_note = None
     # ---- warm-up: W boosting iterations of one model (kernel load, allocator, clocks)
     if a.warmup > 0:
         t = targets[min(4, len(targets) - 1)]
@@ -140,9 +141,28 @@ def main():
         m = eng.train(train_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
         warm = eng.upload(dirty_rows[:, :min(4096, dirty_rows.shape[1])], cards)
         eng.repair_chain(warm, [m], [t], [feats], 0, warm.n)
+        m_bytes = m.save()
         del warm, m
-        if row_tab is not None:   # collective warm-up (RCCL kernels, channels)
-            eng.train_row_sharded(row_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
+        if row_tab is not None:
+            # collective warm-up (RCCL kernels, channels) that doubles as a self-check: the row-sharded model must be the
+            # bytes of the single-device model trained a moment ago.  Any failure or mismatch on any rank -> every rank drops
+            # the communicator and the job runs target-sharded (the reference's own parallel mode).
+            ok = 1
+            try:
+                ms = eng.train_row_sharded(row_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
+                ok = int(ms.save() == m_bytes)
+            except Exception as e:  # noqa: BLE001
+                print("[bench] row-sharded warm-up failed on rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+                ok = 0
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                from repair import _native
+                _native.comm_finalize()
+                row_tab = None
+                row_sharding_note = "disabled: the row-sharded warm-up model differed from the single-device one (or failed)"
 
     # ---- timed region
     params = dict(BASE_PARAMS, n_estimators=a.steps)
@@ -189,6 +209,8 @@ def main():
                          "alg_bytes_per_launch": hist_bytes_all / max(launches_all, 1),
                          "root_scan_GBps_rank0": root_bytes / max(root_ms, 1e-9) * 1e-6},
         }
+        if row_sharding_note:
+            out["config"]["row_sharding"] = row_sharding_note
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.rows, a.cols, a.steps)
     # tear the communicators down first, flush whatever the C side (RCCL prints a version banner through stdio)
