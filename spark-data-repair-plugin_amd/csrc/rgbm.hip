@@ -442,7 +442,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         lc.lds_bytes = LV_LDS_BYTES;
         if (const char* e = getenv("RGBM_LV_LDS")) { int v = atoi(e); if (v >= 16384 && v <= LV_LDS_BYTES) lc.lds_bytes = v; }
         if (const char* e = getenv("RGBM_LV_DRAIN_SHIFT")) { int v = atoi(e); if (v >= 0 && v <= 31) lc.drain_shift = v; }   // testing: force packed-slot drains
-        const long long cu_slots = 256ll * std::max(1, std::min(2, LV_LDS_BYTES / lc.lds_bytes));   // resident workgroups
+        const long long cu_slots = 256ll * std::max(1, std::min(LV_LDS_TOTAL / lc.lds_bytes, 2048 / LV_THREADS));   // resident workgroups
         const long long per = (long long)K * nchunk;
         long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
         long long gx = gmin; double best_eff = -1.0;

@@ -38,9 +38,16 @@ constexpr int LV_INACTIVE = 255;     // node id of rows that do not take part (t
 constexpr int LV_MAX_EXP = 64;       // expanded parents per level (depth <= 6)
 constexpr int LV_MAX_BUILT = 32;     // built children per level (parents of depth <= 5)
 constexpr int LV_CNT_REP = 16;
-constexpr int LV_THREADS = 1024;
-constexpr int LV_TILE = 2048;
-constexpr int LV_LDS_BYTES = 160 * 1024;
+#ifndef LV_THREADS_N
+#define LV_THREADS_N 1024    // threads of a level-pass workgroup
+#endif
+#ifndef LV_BLOCKS_PER_CU
+#define LV_BLOCKS_PER_CU 1   // resident level-pass workgroups per CU; they share the 160 KB of LDS
+#endif
+constexpr int LV_THREADS = LV_THREADS_N;
+constexpr int LV_TILE = 2 * LV_THREADS;      // two rows per lane and tile
+constexpr int LV_LDS_TOTAL = 160 * 1024;
+constexpr int LV_LDS_BYTES = (LV_LDS_TOTAL / LV_BLOCKS_PER_CU) & ~1023;
 constexpr int LV_CARRY_SHIFT = 11;
 constexpr int LV_MAX_DEPTH = 7;
 constexpr int LV_MAX_LEAVES = 128;
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
 // ids (1 B in, 1 B out) and the records of rows it only routes.
 // ------------------------------------------------------------------------------------------------
 template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */>
-__global__ __launch_bounds__(LV_THREADS) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
+__global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
                                                            uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
                                                            const LvLayout* __restrict__ layout, HistBin* __restrict__ part,

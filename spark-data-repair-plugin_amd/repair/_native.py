@@ -66,7 +66,7 @@ def lib():
     """Load librepairgbm.so (fails loudly when it has not been built)."""
     global _lib
     if _lib is None:
-        path = os.path.abspath(LIB_PATH)
+        path = os.path.abspath(os.environ.get("RGBM_LIB_PATH") or LIB_PATH)   # RGBM_LIB_PATH: A/B runs of differently built libraries
         if not os.path.exists(path):
             raise RepairGbmError("librepairgbm.so is not built (%s); run `python __graft_entry__.py` or `make -C "
                                  "spark-data-repair-plugin_amd/csrc`" % path)
