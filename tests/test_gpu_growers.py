@@ -267,3 +267,49 @@ def test_millions_of_rows_against_the_oracle(tgt):
     mo = O.train(X, nc, y, K, class_weight=cw, **kw)
     mg = N.train(X, nc, y, K, class_weight=cw, **kw)
     assert mo.save() == mg.save()
+
+
+def test_three_and_more_feature_chunks():
+    """F = 40 and F = 70: more than two 16-feature chunks (the split feature of a node may live in any record)."""
+    rng = np.random.default_rng(131)
+    for F, n in ((40, 9000), (70, 5000)):
+        z = rng.integers(0, 50, n)
+        cards = [int(c) for c in rng.integers(2, 30, F)]
+        X = np.stack([np.where(rng.random(n) < 0.6, (z * (j + 2)) % c, rng.integers(0, c, n)) for j, c in enumerate(cards)]).astype(np.int32)
+        X[rng.integers(0, F)][rng.random(n) < 0.05] = -1
+        y = ((z + X[F - 1] + X[17]) % 6).astype(np.int32)
+        _three_way(np.ascontiguousarray(X), cards, y, 6, 1, cw=balanced_weights(y, 6), n_estimators=4, learning_rate=0.3)
+
+
+@pytest.mark.parametrize("K", [113, 150, 219])
+def test_hundreds_of_classes(K):
+    """The reference's logs show targets with 52..219 classes; the gradient kernel switches layout above 112."""
+    from oracle import oracle as O
+    from repair import _native as N
+    rng = np.random.default_rng(K)
+    n = 30000
+    z = rng.integers(0, K, n)
+    X = np.stack([(z * (j + 1) + rng.integers(0, 3, n)) % (20 + 13 * j) for j in range(6)]).astype(np.int32)
+    y = np.where(rng.random(n) < 0.2, rng.integers(0, K, n), z).astype(np.int32)
+    cards = [20 + 13 * j for j in range(6)]
+    kw = dict(objective=1, num_class=K, n_estimators=2, learning_rate=0.3)
+    cw = balanced_weights(y, K)
+    mo = O.train(X, cards, y, K, class_weight=cw, **kw)
+    mg = N.train(X, cards, y, K, class_weight=cw, **kw)
+    assert mo.save() == mg.save()
+    assert np.array_equal(mo.predict(X[:, :2000]), mg.predict(X[:, :2000]))
+
+
+def test_regression_with_thousands_of_distinct_targets_and_small_max_bin():
+    from oracle import oracle as O
+    from repair import _native as N
+    rng = np.random.default_rng(137)
+    n = 40000
+    X = np.stack([rng.integers(0, c, n) for c in (700, 40, 9, 300)]).astype(np.int32)
+    vals = np.sort(rng.normal(size=3000) * 10.0)
+    y = ((X[0] * 3 + X[1]) % 3000).astype(np.int32)
+    for max_bin in (15, 63, 255):
+        kw = dict(objective=2, num_class=2, n_estimators=6, learning_rate=0.2, max_bin=max_bin)
+        mo = O.train(X, [700, 40, 9, 300], y, 3000, y_value=vals, **kw)
+        mg = N.train(X, [700, 40, 9, 300], y, 3000, y_value=vals, **kw)
+        assert mo.save() == mg.save(), "max_bin=%d" % max_bin
