@@ -35,6 +35,10 @@ class HipEngine:
     def upload(self, codes, n_codes):
         return _native.Table(codes, n_codes, device_id=self.device_id)
 
+    def upload_dictionaries(self, indices, remaps):
+        """Encode on the device: Arrow dictionary indices + sorted-rank remap tables -> resident code table."""
+        return _native.Table.from_dictionaries(indices, remaps, device_id=self.device_id)
+
     def train(self, table, target, feats, class_weight, params, y_value=None, want_stats=False):
         return table.train(target, feats, y_value=y_value, class_weight=class_weight, want_stats=want_stats, **params)
 

@@ -113,3 +113,76 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
     times.update(detect=t_detect, prepare=t_prep, shape=t_shape)
     out["times"] = times
     return out
+
+
+def encode_frame(df, columns):
+    """Arrow dictionary encoding of the listed columns: (indices [C][n] int32 with -1 = NULL, remaps, dictionaries).
+
+    `remaps[c][i]` is the code of dictionary entry i: its rank among the column's distinct values in ascending order
+    (strings by code point, numbers numerically) -- the contract of repair.encode, so codes mean the same on both paths.
+    The per-row work (value -> dictionary index) is Arrow's; the index -> code gather runs on the device
+    (`Table.from_dictionaries`)."""
+    import pandas as pd
+    import pyarrow as pa
+    idx, remaps, dicts = [], [], []
+    for c in columns:
+        s = df[c]
+        numeric = pd.api.types.is_numeric_dtype(s) and not pd.api.types.is_bool_dtype(s)
+        arr = pa.array(s.astype("float64") if numeric else s.astype(object), from_pandas=True).dictionary_encode()
+        vals = np.asarray(arr.dictionary.to_pylist(), dtype=np.float64 if numeric else object)
+        order = np.argsort(vals, kind="stable")
+        remap = np.empty(len(vals), np.int32)
+        remap[order] = np.arange(len(vals), dtype=np.int32)
+        idx.append(np.asarray(arr.indices.fill_null(-1), np.int32))
+        remaps.append(remap)
+        dicts.append(vals[order])
+    return (np.stack(idx) if idx else np.zeros((0, len(df)), np.int32)), remaps, dicts
+
+
+def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=None, want_pmf=False, top_k=32, threshold=0.0):
+    """DataFrame in, the reference's result frame out: (row_id, attribute, current_value, repaired, prob[, pmf]) -- the
+    shape of `RepairModel.run()` / `run(compute_repair_candidate_prob=True)` (python/repair/model.py:1398-1419).
+
+    Every column is treated as discrete (one class per distinct value); `constraints` are `X1,..,Xm -> Y` dependencies
+    given as ([x names], y name).  Continuous targets, regex / outlier detectors, rule-based repairs and cost functions
+    stay with `repair.model.RepairModel` (the value-space API)."""
+    import pandas as pd
+    cols = [c for c in df.columns if c != row_id]
+    targets = list(targets) if targets is not None else list(cols)
+    unknown = [t for t in targets if t not in cols]
+    if unknown:
+        raise ValueError("Target attributes not found in the input: %s" % ",".join(unknown))
+    indices, remaps, dicts = encode_frame(df, cols)
+    table = engine.upload_dictionaries(indices, remaps)
+    pos = {c: i for i, c in enumerate(cols)}
+    cons = [([pos[x] for x in xs], pos[y]) for xs, y in constraints]
+    res = repair_table(engine, table, [pos[t] for t in targets], dict(base_params or {}), constraints=cons, want_pmf=want_pmf,
+                       top_k=top_k, threshold=threshold)
+    rows, ccols = res["rows"], res["cols"]
+
+    def decode(codes, col_idx):
+        out = np.empty(len(codes), object)
+        for j in np.unique(col_idx):
+            sel = col_idx == j
+            d = dicts[j]
+            c = codes[sel]
+            v = np.empty(len(c), object)
+            ok = c >= 0
+            v[ok] = d[c[ok]]
+            v[~ok] = None
+            out[sel] = v
+        return out
+
+    frame = pd.DataFrame({row_id: df[row_id].to_numpy()[rows], "attribute": np.asarray(cols, object)[ccols],
+                          "current_value": decode(res["current"], ccols), "repaired": decode(res["repaired"], ccols)})
+    if res.get("prob") is not None:
+        frame["prob"] = res["prob"]
+    if want_pmf and len(rows):
+        pc, pp = res["pmf_class"], res["pmf_prob"]
+        pmf = []
+        for i in range(len(rows)):
+            d = dicts[ccols[i]]
+            pmf.append([{"class": d[k], "prob": float(p)} for k, p in zip(pc[i], pp[i]) if k >= 0])
+        frame["pmf"] = pmf
+        frame["current_prob"] = res["current_prob"]
+    return frame

@@ -110,6 +110,11 @@ class OracleEngine:
     def upload(self, codes, n_codes):
         return OracleEngine._Table(codes, n_codes)
 
+    def upload_dictionaries(self, indices, remaps):
+        from oracle import prep as P
+        codes = P.encode_dictionaries(np.asarray(indices, np.int32), remaps)
+        return OracleEngine._Table(codes, [max(int(np.max(m)) + 1 if len(m) else 0, 0) for m in remaps])
+
     def train(self, table, target, feats, class_weight, params, y_value=None, want_stats=False):
         from oracle import oracle as O
         rows = table.codes[target] >= 0

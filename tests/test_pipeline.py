@@ -87,3 +87,60 @@ def test_pipeline_hip_engine_equals_oracle_engine(kw):
     for k in ("rows", "cols", "current", "repaired", "prob", "dirty_rows") + (("pmf_class", "pmf_prob", "current_prob") if "pmf_class" in b else ()):
         assert np.array_equal(a[k], b[k]), k
     assert a["models"] == b["models"]
+
+
+def _people(n=1500, seed=7):
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    city = rng.choice(["Lyon", "Paris", "Nice", "Lille", "Brest", "Metz"], n)
+    zipc = np.array([{"Lyon": "69000", "Paris": "75000", "Nice": "06000", "Lille": "59000", "Brest": "29200", "Metz": "57000"}[c] for c in city], object)
+    region = np.array([{"Lyon": "ARA", "Paris": "IDF", "Nice": "PACA", "Lille": "HDF", "Brest": "BRE", "Metz": "GES"}[c] for c in city], object)
+    grade = np.where(np.isin(city, ["Lyon", "Paris"]), rng.choice([3, 4], n), rng.choice([1, 2], n))
+    df = pd.DataFrame({"tid": np.arange(n) + 100, "city": city, "zip": zipc, "region": region, "grade": grade})
+    truth = df.copy()
+    for c, k in (("zip", 30), ("grade", 25)):             # no NULL in `region`: a NULL is a value of its own for IQ and would flag its whole city
+        df.loc[rng.choice(n, k, replace=False), c] = None
+    wrong = rng.choice(np.flatnonzero(df["region"].notna().to_numpy() & (city == "Metz")), 3, replace=False)
+    df.loc[wrong, "region"] = "IDF"                      # violates city -> region; the whole Metz group gets flagged
+    return df, truth, wrong
+
+
+def test_repair_frame_value_space_round_trip():
+    from repair.pipeline import encode_frame, repair_frame
+    from repair.encode import TableEncoder
+    from tests.helpers import OracleEngine
+    df, truth, wrong = _people()
+    cols = ["city", "zip", "region", "grade"]
+    idx, remaps, dicts = encode_frame(df, cols)
+    enc = TableEncoder(df, cols)
+    from oracle import prep as P
+    assert np.array_equal(P.encode_dictionaries(idx, remaps), enc.encode(df))            # same codes as the pandas encoder
+    out = repair_frame(OracleEngine(), df, "tid", targets=["zip", "region"], constraints=[(["city"], "region")],
+                       base_params=dict(n_estimators=15, learning_rate=0.3, min_data_in_leaf=5), want_pmf=True, top_k=3)
+    assert list(out.columns) == ["tid", "attribute", "current_value", "repaired", "prob", "pmf", "current_prob"]
+    by = {(int(r.tid), r.attribute): r for r in out.itertuples()}
+    nulls = [(int(t), "zip") for t in df["tid"][df["zip"].isna()]]
+    assert set(nulls) <= set(by)
+    pos = {int(t): i for i, t in enumerate(df["tid"])}
+    right = sum(by[k].repaired == truth[k[1]].iloc[pos[k[0]]] for k in nulls)
+    assert right / len(nulls) > 0.9                                                       # zip / region follow the city
+    for k in nulls:
+        assert by[k].current_value is None and by[k].pmf[0]["prob"] >= by[k].pmf[-1]["prob"] and 1 <= len(by[k].pmf) <= 3
+    # the Metz rows are flagged by the constraint and carry their current value (and its probability under the model)
+    metz = [int(t) for t in df["tid"][(df["city"] == "Metz") & df["region"].notna()]]
+    assert all((t, "region") in by for t in metz)
+    assert sorted(by[(int(df["tid"].iloc[w]), "region")].current_value for w in wrong) == ["IDF"] * 3
+    with pytest.raises(ValueError, match="Target attributes not found"):
+        repair_frame(OracleEngine(), df, "tid", targets=["nope"])
+
+
+@pytest.mark.gpu
+def test_repair_frame_hip_engine_equals_oracle_engine():
+    from repair.engine import HipEngine
+    from repair.pipeline import repair_frame
+    from tests.helpers import OracleEngine
+    df, truth, wrong = _people(4000, seed=11)
+    kw = dict(targets=["zip", "region", "grade"], constraints=[(["city"], "region")], base_params=dict(n_estimators=10, learning_rate=0.3), want_pmf=True, top_k=4)
+    a = repair_frame(HipEngine(), df, "tid", **kw)
+    b = repair_frame(OracleEngine(), df, "tid", **kw)
+    assert a.equals(b)
