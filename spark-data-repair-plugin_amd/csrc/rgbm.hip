@@ -37,6 +37,82 @@ namespace {
 thread_local std::string g_err;
 }  // namespace
 std::string& rgh::last_error() { return g_err; }
+
+// ---- caching device-memory pool (rgbm_host.h)
+namespace {
+struct PoolBlock { void* p; size_t bytes; unsigned long long stamp; };
+struct DevPool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, PoolBlock> free_blocks;     // (device, bytes) -> block
+    size_t cached = 0; unsigned long long clock = 0;
+    size_t cap() {
+        static const size_t c = [] { const char* e = getenv("RGBM_POOL_MB"); long long mb = e ? atoll(e) : 65536; return (size_t)std::max<long long>(mb, 0) << 20; }();
+        return c;
+    }
+    // drop the least recently freed blocks until at most `keep` bytes stay cached (mu held)
+    void trim_locked(size_t keep) {
+        while (cached > keep && !free_blocks.empty()) {
+            auto victim = free_blocks.begin();
+            for (auto it = free_blocks.begin(); it != free_blocks.end(); ++it) if (it->second.stamp < victim->second.stamp) victim = it;
+            int cur = 0; (void)hipGetDevice(&cur);
+            if (cur != victim->first.first) (void)hipSetDevice(victim->first.first);
+            (void)hipFree(victim->second.p);
+            if (cur != victim->first.first) (void)hipSetDevice(cur);
+            cached -= victim->second.bytes;
+            free_blocks.erase(victim);
+        }
+    }
+    ~DevPool() { /* process exit: the driver reclaims device memory; HIP may already be shut down here */ }
+};
+DevPool& pool() { static DevPool* p = new DevPool(); return *p; }
+}  // namespace
+
+void* rgh::pool_alloc(size_t bytes, size_t* block_bytes, int* device) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    *device = dev;
+    DevPool& P = pool();
+    // round up so that nearly equal requests can share blocks: 256 B below 1 MB, 2 MB above
+    const size_t want = bytes < (1u << 20) ? ((bytes + 255) & ~(size_t)255) : ((bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1));
+    if (P.cap() > 0) {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free_blocks.lower_bound(std::make_pair(dev, want));
+        // a request never swallows a much larger block (up to 8x its size, 4x below 1 MB)
+        if (it != P.free_blocks.end() && it->first.first == dev && it->first.second <= want * (want >= (1u << 20) ? 8 : 4)) {
+            void* p = it->second.p; *block_bytes = it->second.bytes;
+            P.cached -= it->second.bytes;
+            P.free_blocks.erase(it);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && P.cap() > 0) {       // out of memory with blocks parked in the pool: give them back and retry once
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> lk(P.mu); P.trim_locked(0); }
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); char b[256]; snprintf(b, sizeof(b), "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e)); throw std::runtime_error(b); }
+    *block_bytes = want;
+    return p;
+}
+
+void rgh::pool_free(void* p, size_t block_bytes, int device) {
+    if (!p) return;
+    DevPool& P = pool();
+    if (P.cap() == 0 || block_bytes > P.cap()) {
+        int cur = 0; (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipFree(p);
+        if (cur != device) (void)hipSetDevice(cur);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.free_blocks.emplace(std::make_pair(device, block_bytes), PoolBlock{p, block_bytes, ++P.clock});
+    P.cached += block_bytes;
+    if (P.cached > P.cap()) P.trim_locked(P.cap());
+}
+
+void rgh::pool_trim(size_t keep_bytes) { DevPool& P = pool(); std::lock_guard<std::mutex> lk(P.mu); P.trim_locked(keep_bytes); }
 namespace {
 using rgh::fail; using rgh::DevBuf; using rgh::use_device; using rgh::StreamGuard; using rgh::guarded;
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <utility>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -28,21 +29,28 @@ inline int fail(int code, const std::string& msg) { last_error() = msg; return c
         }                                                                                              \
     } while (0)
 
+// Device memory comes from a small caching pool: a training call on K class trees allocates ~1.2 KB per row and class
+// tree (scores, gradients, node ids, ...) and hipMalloc/hipFree of 12 GB cost 0.3 s -- more than 15 boosting iterations.
+// Freed blocks are kept (best fit: the smallest cached block that is large enough) up to RGBM_POOL_MB (default 65536;
+// 0 = plain hipMalloc/hipFree); callers release buffers only after synchronising the stream that used them.
+void* pool_alloc(size_t bytes, size_t* block_bytes, int* device);     // defined in rgbm.hip; throws std::runtime_error
+void pool_free(void* p, size_t block_bytes, int device);
+void pool_trim(size_t keep_bytes);
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr; size_t n = 0;
+    size_t block_bytes = 0; int device = 0;
     DevBuf() {}
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
     void alloc(size_t count) {
         release(); n = count;
-        if (count) {
-            hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-            if (e != hipSuccess) { p = nullptr; char b[256]; snprintf(b, sizeof(b), "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); throw std::runtime_error(b); }
-        }
+        if (count) p = static_cast<T*>(pool_alloc(count * sizeof(T), &block_bytes, &device));
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    void release() { if (p) { pool_free(p, block_bytes, device); p = nullptr; } n = 0; block_bytes = 0; }
     ~DevBuf() { release(); }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(block_bytes, o.block_bytes); std::swap(device, o.device); }
     void upload(const T* h, size_t count, hipStream_t s) { if (count) HIPCHK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }
     void download(T* h, size_t count, hipStream_t s) const { if (count) HIPCHK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
     void zero(hipStream_t s) { if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }

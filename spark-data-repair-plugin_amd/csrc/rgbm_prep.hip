@@ -396,8 +396,8 @@ RGBM_EXPORT int rgbm_table_detect_constraint(rgbm_table* t, const int32_t* eq_co
             if (m > 0) hipLaunchKernelGGL(k_replicate, dim3(nblocks(m, 256)), dim3(256), 0, s, t->cell_rows.p, m, d_cc, n_cell_cols, rows_r.p, cols_r.p);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(s));
-            std::swap(t->cell_rows.p, rows_r.p); std::swap(t->cell_rows.n, rows_r.n);
-            std::swap(t->cell_cols.p, cols_r.p); std::swap(t->cell_cols.n, cols_r.n);
+            t->cell_rows.swap(rows_r);
+            t->cell_cols.swap(cols_r);
             t->n_cells = m * n_cell_cols;
         }
         *n_cells_out = t->n_cells;
