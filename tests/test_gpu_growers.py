@@ -134,7 +134,7 @@ def test_random_configurations_stress():
     from oracle import oracle as O
     from repair import _native as N
     rng = np.random.default_rng(20260922)
-    for trial in range(40):
+    for trial in range(24):
         n = int(rng.integers(300, 9000))
         F = int(rng.integers(2, 12))
         cards = rng.integers(2, 40, F)
@@ -181,7 +181,7 @@ def test_random_configurations_stress_wide_and_sampled():
     from oracle import oracle as O
     from repair import _native as N
     rng = np.random.default_rng(777)
-    for trial in range(30):
+    for trial in range(18):
         n = int(rng.integers(500, 12000))
         F = int(rng.integers(14, 25))
         cards = rng.integers(2, 70, F)
@@ -255,11 +255,11 @@ def test_forced_packed_slot_drains_stay_bit_exact(shift, lds):
         assert mo.save() == mg.save(), "objective %d differs with forced drains" % kw["objective"]
 
 
-@pytest.mark.parametrize("tgt", [0, 5])
+@pytest.mark.parametrize("tgt", [0, 3])
 def test_millions_of_rows_against_the_oracle(tgt):
-    """3M rows: every workgroup streams many tiles, lanes run out of drain budget on their own at the deep levels
-    (replication 1-2), and the per-workgroup partials are summed by k_level_reduce."""
-    X, nc, y, K = _xy(3_000_000, 8, tgt, seed=109)
+    """2.5M rows: every workgroup streams many tiles, lanes run out of drain budget on their own at the deep levels
+    (replication 1-2), and the per-workgroup partials are summed by k_level_reduce.  (100M rows: tools/big_rows_check.py.)"""
+    X, nc, y, K = _xy(2_500_000, 8, tgt, seed=109)
     from oracle import oracle as O
     from repair import _native as N
     kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=3, learning_rate=0.3)
@@ -281,7 +281,7 @@ def test_three_and_more_feature_chunks():
         _three_way(np.ascontiguousarray(X), cards, y, 6, 1, cw=balanced_weights(y, 6), n_estimators=4, learning_rate=0.3)
 
 
-@pytest.mark.parametrize("K", [113, 150, 219])
+@pytest.mark.parametrize("K", [113, 219])
 def test_hundreds_of_classes(K):
     """The reference's logs show targets with 52..219 classes; the gradient kernel switches layout above 112."""
     from oracle import oracle as O

@@ -156,7 +156,7 @@ def test_millions_of_rows_properties():
     """Full-size properties that need no oracle: the cell list is ordered, complete and consistent with the counts;
     nulling the detected cells of a table and detecting again is idempotent; dirty rows are the distinct rows."""
     from repair import _native as N
-    n = 6_000_000
+    n = 4_000_000
     dirty, clean, cards = make_table(n, 8, seed=29, null_ratio=0.01)
     tab = N.Table(dirty, cards)
     rows, cols = tab.detect_nulls(list(range(8)))
