@@ -106,3 +106,51 @@ def test_two_rank_gloo_hybrid_job_equals_single_process():
         assert models == sorted(single["models"].items())
     # at least one target went through the collective path on both ranks
     assert set(outs[0][4]) & set(outs[1][4])
+
+
+def _pipeline_job():
+    from repair.pipeline import repair_table
+    from tests.helpers import OracleEngine
+    dirty, clean, cards = make_table(5000, 6, seed=23, null_ratio=0.03, cards=[2, 3, 4, 64, 8, 6])
+    noisy = dirty.copy()
+    noisy[3] = clean[3]                                   # determinant of the constraint: clean, 64 groups
+    noisy[5] = (clean[3] * 5 + 2) % 6
+    noisy[5][[11, 222, 3333]] = (noisy[5][[11, 222, 3333]] + 1) % 6
+    eng = OracleEngine()
+    p = {k: v for k, v in PARAMS.items()}
+    return repair_table(eng, eng.upload(noisy, cards), [0, 2, 4, 5], p, constraints=[([3], 5)], want_pmf=True, top_k=3, threshold=0.0)
+
+
+def _pipeline_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spark-data-repair-plugin_amd"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = _pipeline_job()
+        q.put((rank, {k: res[k] for k in ("rows", "cols", "current", "repaired", "prob", "dirty_rows", "pmf_class", "pmf_prob", "current_prob")},
+               sorted(res["models"].items())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_pipeline_equals_single_process():
+    """repair.pipeline.repair_table under 2 ranks: detection / null-out / split run replicated on every rank, training is
+    target-sharded, the chained repair row-sharded -- every rank ends with the single-process result."""
+    import torch.multiprocessing as mp
+    single = _pipeline_job()
+    assert len(single["rows"]) > 100 and (single["cols"] == 5).any()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, arrays, models in outs:
+        for k, v in arrays.items():
+            assert np.array_equal(v, single[k]), "rank %d: %s" % (rank, k)
+        assert models == sorted(single["models"].items())
