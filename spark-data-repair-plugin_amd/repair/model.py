@@ -483,16 +483,30 @@ class RepairModel():
         return top
 
     def _repair_attrs(self, updates: DataFrame, base: DataFrame) -> DataFrame:
-        """RepairMiscApi.repairAttrsFrom: apply (row_id, attribute, repaired) updates to a table."""
+        """RepairMiscApi.repairAttrsFrom (RepairMiscApi.scala:184-247): apply (row_id, attribute, repaired) updates to a table.
+        `repaired` arrives as strings; continuous attributes are cast back (`CAST(.. AS DOUBLE)` accepts Java's `3.1D`
+        spelling), integral ones through `round` (half-up, as Spark rounds doubles) first (lines 224-229)."""
         out = base.copy()
         pos = pd.Series(np.arange(len(out)), index=out[self._row_id].to_numpy())
         for a, grp in updates.groupby("attribute"):
-            rows = pos.reindex(grp[self._row_id].to_numpy()).to_numpy(np.int64)
-            col = out[a].astype(object) if not is_numeric_column(out[a]) else out[a].astype("float64")
-            vals = grp["repaired"].to_numpy(dtype=object)
+            if a not in out.columns:
+                continue
+            rows = pos.reindex(grp[self._row_id].to_numpy()).to_numpy(np.float64)
+            keep = ~np.isnan(rows)                            # updates of unknown rows vanish in the LEFT OUTER JOIN
+            rows = rows[keep].astype(np.int64)
+            vals = grp["repaired"].to_numpy(dtype=object)[keep]
             if is_numeric_column(base[a]):
-                vals = pd.to_numeric(pd.Series(vals), errors="coerce").to_numpy()
-            col.iloc[rows] = vals
+                num = np.array([_to_double(v) for v in vals], np.float64)
+                if is_integral_column(base[a]):
+                    num = np.where(np.isnan(num), np.nan, np.sign(num) * np.floor(np.abs(num) + 0.5))
+                    col = out[a].astype("Int64")
+                    col.iloc[rows] = pd.array([pd.NA if np.isnan(v) else int(v) for v in num], dtype="Int64")
+                else:
+                    col = out[a].astype("float64")
+                    col.iloc[rows] = num
+            else:
+                col = out[a].astype(object)
+                col.iloc[rows] = vals
             out[a] = col
         return out
 
@@ -617,6 +631,22 @@ class RepairModel():
                                 compute_repair_prob, compute_repair_score, repair_data, maximal_likelihood_repair)
         _logger.info("!!!Total Processing time is %s(s)!!!" % elapsed)
         return df
+
+
+def _to_double(v: Any) -> float:
+    """Spark's CAST(string AS DOUBLE): Java `Double.parseDouble` after trimming, which also takes a d/D/f/F suffix; anything
+    else is NULL."""
+    if v is None or (isinstance(v, float) and np.isnan(v)):
+        return float("nan")
+    if isinstance(v, (int, float, np.integer, np.floating)):
+        return float(v)
+    t = str(v).strip()
+    if t[-1:] in "dDfF" and len(t) > 1:
+        t = t[:-1]
+    try:
+        return float(t)
+    except ValueError:
+        return float("nan")
 
 
 def _to_str(v: Any) -> str:

@@ -259,3 +259,17 @@ def test_batched_hp_search_equals_sequential(oracle_backend):
         assert m is not None
         outs.append((score, m.booster_bytes_, m.get_params()["num_leaves"]))
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_repair_attrs_from_golden():
+    """RepairMiscSuite.scala:124-144 ("repairAttrsFrom"): integral attributes are rounded, doubles parsed Java-style."""
+    from repair.model import RepairModel
+    base = pd.DataFrame({"tid": [1, 2, 3], "x": pd.array([None, None, 1], dtype="Int64"), "y": ["test-1", None, "test-2"], "z": [1.0, 2.0, None]})
+    updates = pd.DataFrame({"tid": [1, 2, 2, 3, 9], "attribute": ["x", "x", "y", "z", "x"], "repaired": ["2.4", "2.6", "test-3", "3.1D", "7"]})
+    m = RepairModel().setRowId("tid")
+    out = m._repair_attrs(updates, base)
+    assert out["x"].tolist() == [2, 3, 1] and out["y"].tolist() == ["test-1", "test-3", "test-2"] and out["z"].tolist() == [1.0, 2.0, 3.1]
+    assert str(out["x"].dtype) == "Int64" and base["x"].isna().sum() == 2              # the input frame is left alone
+    # half-up like Spark's round(), unparsable text becomes NULL
+    upd = pd.DataFrame({"tid": [1, 2, 3], "attribute": ["x"] * 3, "repaired": ["2.5", "-2.5", "abc"]})
+    assert m._repair_attrs(upd, base)["x"].tolist()[:2] == [3, -3] and m._repair_attrs(upd, base)["x"].isna().tolist() == [False, False, True]
