@@ -186,3 +186,23 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
         frame["pmf"] = pmf
         frame["current_prob"] = res["current_prob"]
     return frame
+
+
+def constraint_to_columns(preds, columns):
+    """Parsed denial constraint (repair.errors.parse_constraint) -> (eq column indices, iq column index) when it has the form
+    the device detector handles -- two tuples, same attribute on both sides, EQ predicates plus exactly one IQ -- else None
+    (single-tuple constant predicates, LT/GT, several IQs stay with the pandas detector)."""
+    pos = {c: i for i, c in enumerate(columns)}
+    eq, iq = [], []
+    for p in preds:
+        if p.constant is not None or p.right is None or p.left != p.right or p.left not in pos:
+            return None
+        if p.op == "EQ":
+            eq.append(pos[p.left])
+        elif p.op == "IQ":
+            iq.append(pos[p.left])
+        else:
+            return None
+    if len(iq) != 1 or len(eq) > 12:
+        return None
+    return eq, iq[0]

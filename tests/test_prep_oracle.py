@@ -126,3 +126,118 @@ def test_encode_dictionaries_equals_table_encoder():
         remaps.append(np.argsort(np.argsort(np.asarray(vals, dtype=object if c == "s" else np.float64), kind="stable"), kind="stable").astype(np.int32))
     got = P.encode_dictionaries(np.stack(idx), remaps)
     assert np.array_equal(got, want)
+
+
+def _sorted_cells(df):
+    return sorted(map(tuple, df.values.tolist()))
+
+
+def test_null_detector_scala_golden_rows():
+    """ErrorDetectorSuite.scala:50-71 ("NULL-based error detector"), host detector and code-space oracle."""
+    df = pd.DataFrame({"tid": ["1", "2", "3", "4"], "v1": pd.array([100000, None, 300000, 400000], dtype="Int64"),
+                       "v2": [3.0, 8.0, 1.0, None], "v3": ["test-1", "test-2", None, "test-4"]})
+    cols = ["v1", "v2", "v3"]
+    _, codes = _encode(df, cols)
+    for targets, expected in ((["v1", "v2", "v3"], [("2", "v1"), ("3", "v3"), ("4", "v2")]), (["v1"], [("2", "v1")]),
+                              (["v2", "v3"], [("3", "v3"), ("4", "v2")]), (["v3", "v1"], [("2", "v1"), ("3", "v3")]),
+                              (["v3", "v2", "v5"], [("3", "v3"), ("4", "v2")])):
+        host = NullErrorDetector().setUp("tid", df, ["v1", "v2"], targets).detect()
+        assert _sorted_cells(host) == sorted(expected)
+        rows, ccols = P.detect_nulls(codes, [cols.index(t) for t in targets if t in cols])
+        assert sorted((df["tid"][r], cols[c]) for r, c in zip(rows, ccols)) == sorted(expected)
+
+
+def test_regex_detector_scala_golden_rows():
+    """ErrorDetectorSuite.scala:73-101 ("RegEx-based error detector"): `CAST(attr AS STRING) NOT RLIKE regex OR attr IS NULL`."""
+    from repair.errors import RegExErrorDetector
+    df = pd.DataFrame({"tid": ["1", "2", "3", "4"], "v1": [123, 123456, 123000, 987654321], "v2": [53.0, 123.0, 456.0, None],
+                       "v3": ["123-abc", "456-efg", None, "123-hij"]})
+    for targets, attr, regex, expected in (
+            (["v1", "v2", "v3"], "v3", "123-hij", [("1", "v3"), ("2", "v3"), ("3", "v3")]),
+            (["v1", "v2", "v3"], "v3", "123.*", [("2", "v3"), ("3", "v3")]),
+            (["v1", "v2", "v3"], "v1", "123.*", [("4", "v1")]),
+            (["v3"], "v3", "123.*", [("2", "v3"), ("3", "v3")]),
+            (["v2", "v3"], "v2", "123.*", [("1", "v2"), ("3", "v2"), ("4", "v2")])):
+        got = RegExErrorDetector(attr, regex).setUp("tid", df, ["v1", "v2"], targets).detect()
+        assert _sorted_cells(got) == sorted(expected), (targets, attr, regex)
+
+
+def test_constraint_detector_adult_golden_rows():
+    """ErrorDetectorSuite.scala:188-201 ("Constraint-based error detector - adult"): tids 4 and 11, Sex and Relationship."""
+    from tests.helpers import frame, load_golden
+    g = load_golden("adult")
+    df = frame(g["input"])
+    det = ConstraintErrorDetector(constraints=g["constraints"].replace("\n", ";")).setUp("tid", df, [], ["Sex", "Relationship"])
+    got = sorted((str(t), a) for t, a in det.detect().values.tolist())
+    assert got == sorted([("4", "Relationship"), ("4", "Sex"), ("11", "Relationship"), ("11", "Sex")])
+
+
+def test_outlier_detector_scala_golden_rows():
+    """ErrorDetectorSuite.scala:219-233 ("Outlier-based error detector"): 1000 x 100.0 and one 0.0."""
+    from repair.errors import GaussianOutlierErrorDetector
+    df = pd.DataFrame({"tid": np.arange(1001), "value": [100.0] * 1000 + [0.0]})
+    for approx in (False, True):
+        for targets in (["value"], ["v", "value"]):
+            got = GaussianOutlierErrorDetector(approx_enabled=approx).setUp("tid", df, ["value"], targets).detect()
+            assert got.values.tolist() == [[1000, "value"]]
+
+
+def test_constraint_parser_scala_goldens():
+    """DenialConstraintsSuite.scala:27-93: valid syntax (with blanks), the invalid cases and their log line."""
+    import logging
+    from repair.errors import parse_and_verify_constraints, parse_constraint
+
+    def render(p):
+        if p.constant is not None:
+            return {"EQ": "t1.%s <=> %s", "IQ": "NOT(t1.%s <=> %s)", "LT": "t1.%s < %s", "GT": "t1.%s > %s"}[p.op] % (p.left, p.constant)
+        return {"EQ": "t1.%s <=> t2.%s", "IQ": "NOT(t1.%s <=> t2.%s)", "LT": "t1.%s < t2.%s", "GT": "t1.%s > t2.%s"}[p.op] % (p.left, p.right)
+
+    for stmt, preds, refs in (
+            ('t1&EQ(t1.v1,"abc")&EQ(t1.v2,"def")', {'t1.v1 <=> "abc"', 't1.v2 <=> "def"'}, {"v1", "v2"}),
+            ("t1&t2&EQ(t1.v1,t2.v1)&IQ(t1.v2,t2.v2)", {"t1.v1 <=> t2.v1", "NOT(t1.v2 <=> t2.v2)"}, {"v1", "v2"}),
+            ("t1&t2&LT(t1.v1,t2.v1)&GT(t1.v2,t2.v2)&EQ(t1.v1,t2.v1)", {"t1.v1 < t2.v1", "t1.v2 > t2.v2", "t1.v1 <=> t2.v1"}, {"v1", "v2"}),
+            (' t1 & EQ ( t1.v1 , "abc") & EQ ( t1.v2 , "def" ) ', {'t1.v1 <=> "abc"', 't1.v2 <=> "def"'}, {"v1", "v2"}),
+            ("t1 & t2 & EQ ( t1.v1 , t2.v1 ) & IQ ( t1.v2 , t2.v2 ) ", {"t1.v1 <=> t2.v1", "NOT(t1.v2 <=> t2.v2)"}, {"v1", "v2"})):
+        ps = parse_constraint(stmt)
+        assert {render(p) for p in ps} == preds, stmt
+        assert {r for p in ps for r in p.references} == refs
+    records = []
+    handler = logging.Handler()
+    handler.emit = records.append
+    logging.getLogger("repair").addHandler(handler)
+    try:
+        for bad in ('EQ(t1.v1,"abc")', '1a&IQ(1a.v,"abc")', 'key&EQ(noexistent.v1,"abc")&EQ(key,"def")', 't1&1a&EQ(t1.v,"abc")&IQ(1a.v,"def")',
+                    't1&EQ(t1.v1,"abc")&IL(t1.v1, "def")&EQ(t1.v2,"ghi")', 't1&t2&GT(t3.v0,"abc")&EQ(t1.v1,t2.v1)&IQ(t1.v2,t2.v2)',
+                    't1&t2&GT(t3.v0,"abc")&EQ(t1.v1,t2.v1)&IL(t1.v2,t2.v2)', 't1&EQ(t1.v1,"abc")', "t1&", "t1", "a&b&", "k1&k2"):
+            with pytest.raises(ValueError, match="Failed to parse an input string|Illegal predicates found|At least two predicate candidates should be given"):
+                parse_constraint(bad)
+            del records[:]
+            assert parse_and_verify_constraints([bad], ["v1", "v2"]) == []
+            assert sum(("Illegal constraint format found: %s" % bad) in r.getMessage() for r in records) == 1, bad
+    finally:
+        logging.getLogger("repair").removeHandler(handler)
+
+
+def test_hospital_constraints_take_the_device_form():
+    """DenialConstraintsSuite.scala:107-168 ("constraint parsing - hospital"): all 15 are EQ.. & IQ on two tuples, i.e. what
+    rgbm_table_detect_constraint evaluates; the adult ones (single tuple, constants) are not."""
+    from repair.errors import parse_and_verify_constraints
+    from repair.pipeline import constraint_to_columns
+    from tests.helpers import frame, load_golden
+    g = load_golden("hospital")
+    cols = [c for c in frame(g["input"], dtypes=False).columns if c != "tid"]
+    plist = parse_and_verify_constraints([l for l in g["constraints"].splitlines() if l.strip()], cols)
+    assert len(plist) == 15
+    forms = [constraint_to_columns(ps, cols) for ps in plist]
+    assert all(f is not None for f in forms)
+    assert sorted(len(f[0]) for f in forms) == [1] * 13 + [2, 3]
+    ga = load_golden("adult")
+    acols = [c for c in frame(ga["input"]).columns if c != "tid"]
+    aps = parse_and_verify_constraints(ga["constraints"].splitlines(), acols)
+    assert len(aps) == 2 and all(constraint_to_columns(ps, acols) is None for ps in aps)
+    # the device-form detector on the encoded hospital table == the pandas detector, constraint by constraint
+    df = frame(g["input"], dtypes=False)
+    _, codes = _encode(df, cols)
+    from repair.errors import _violating_rows
+    for ps, (eq, iq) in zip(plist, forms):
+        assert np.array_equal(P.constraint_rows(codes, eq, iq), np.flatnonzero(_violating_rows(df, ps)))
