@@ -421,8 +421,17 @@ class ErrorModel:
         attrs = [c for c in columns if c != self.row_id]
         return [c for c in attrs if c in set(self.targets)] if self.targets else attrs
 
+    def _checked_options(self) -> Dict[str, Any]:
+        """The error-model options are cast and validated as the reference does when it reads them (errors.py:440-470,
+        `_get_option_value`): a malformed value fails the run under testing and falls back to the default otherwise."""
+        from repair.utils import get_option_value
+        return {o.key: get_option_value(self.opts, *o) for o in (
+            self._opt_attr_freq_ratio_threshold, self._opt_pairwise_freq_ratio_threshold, self._opt_max_attrs_to_compute_pairwise_stats,
+            self._opt_max_attrs_to_compute_domains, self._opt_domain_threshold_alpha, self._opt_domain_threshold_beta)}
+
     def detect(self, input_df: pd.DataFrame, continous_columns: List[str]) -> Tuple[pd.DataFrame, List[str], Dict[str, Any], Dict[str, int]]:
         rid = self.row_id
+        self._checked_options()
         if self.error_cells is not None:
             cells = self.error_cells[[rid, "attribute"]]
             if cells[rid].dtype != input_df[rid].dtype:   # e.g. 'tid STRING' cells against an int row id

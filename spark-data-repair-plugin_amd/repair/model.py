@@ -234,17 +234,27 @@ class RepairModel():
         return not bool(self._get_option_value(*self._opt_repair_by_functional_deps_disabled)) and self.repair_by_rules
 
     # ------------------------------------------------------------------ input checks
+    def _qualified_input_name(self) -> str:
+        """`db.table` / `table` as the reference's messages print it; a DataFrame input has no name of its own."""
+        if isinstance(self.input, str):
+            return ("%s.%s" % (self.db_name, self.input)) if self.db_name else self.input
+        return "input"
+
     def _check_input_table(self) -> Tuple[DataFrame, List[str]]:
         """RepairApi.checkInputTable (RepairApi.scala:34-67)."""
         df = session.resolve(self.input)
         rid = self._row_id
+        name = self._qualified_input_name()
         if rid not in df.columns:
-            raise ValueError("Column '%s' does not exist in the input table" % rid)
+            raise ValueError("Column '%s' does not exist in '%s'." % (rid, name))
+        unsupported = [t for t in (_sql_type_name(df[c]) for c in df.columns) if t not in _SUPPORTED_TYPES]
+        if unsupported:
+            raise ValueError("Supported types are %s, but unsupported ones found: %s" % (",".join(_SUPPORTED_TYPES), ",".join(unsupported)))
         if len(df.columns) < 3:
-            raise ValueError("A least three columns (`%s` columns + two more ones) in the input table" % rid)
+            raise ValueError("A least three columns (`%s` columns + two more ones) in table '%s'" % (rid, name))
         if df[rid].nunique(dropna=False) != len(df):
-            raise ValueError("Uniqueness does not hold in column '%s' of the input table (# of distinct '%s': %d, # of rows: %d)" % (
-                rid, rid, df[rid].nunique(dropna=False), len(df)))
+            raise ValueError("Uniqueness does not hold in column '%s' of table '%s' (# of distinct '%s': %d, # of rows: %d)" % (
+                rid, name, rid, df[rid].nunique(dropna=False), len(df)))
         continous = [c for c in df.columns if c != rid and is_numeric_column(df[c])]
         _logger.info("input_table: (%d rows x %d columns)" % (len(df), len(df.columns) - 1))
         return df.reset_index(drop=True), continous
@@ -625,12 +635,42 @@ class RepairModel():
         if maximal_likelihood_repair and len(continous_columns) != 0:
             raise ValueError("Cannot enable the maximal likelihood repair mode when continous attributes found")
         if self.targets and len(set(self.targets) & set(input_df.columns)) == 0:
-            raise ValueError("Target attributes not found in the input table: %s" % to_list_str(self.targets))
+            # the reference names the (qualified) input table here (model.py:1525-1526); a DataFrame input has no name
+            raise ValueError("Target attributes not found in %s: %s" % (self._qualified_input_name(), to_list_str(self.targets)))
         self.opts.setdefault("model.gpu.device_id", self.opts.get("model.gpu.device_id", "0"))
         df, elapsed = self._run(input_df, continous_columns, detect_errors_only, compute_repair_candidate_prob,
                                 compute_repair_prob, compute_repair_score, repair_data, maximal_likelihood_repair)
         _logger.info("!!!Total Processing time is %s(s)!!!" % elapsed)
         return df
+
+
+# RepairBase.scala:41-47: the column types the reference accepts, in the order its message prints them
+_SUPPORTED_TYPES = ["tinyint", "float", "smallint", "string", "double", "int", "bigint"]
+
+
+def _sql_type_name(s: Any) -> str:
+    """Spark SQL name of a pandas column's type (only what `checkInputTable` needs to tell apart)."""
+    import datetime
+    k = s.dtype.kind
+    if k == "M":
+        return "timestamp"
+    if k == "m":
+        return "interval"
+    if k == "b" or str(s.dtype) == "boolean":
+        return "boolean"
+    if k in "iu" or str(s.dtype).startswith(("Int", "UInt")):
+        bits = "".join(ch for ch in str(s.dtype) if ch.isdigit())
+        return {"8": "tinyint", "16": "smallint", "32": "int"}.get(bits, "bigint")
+    if k == "f" or str(s.dtype).startswith("Float"):
+        return "float" if "32" in str(s.dtype) else "double"
+    vals = s.dropna()
+    if len(vals) and all(isinstance(v, datetime.datetime) for v in vals):
+        return "timestamp"
+    if len(vals) and all(isinstance(v, datetime.date) for v in vals):
+        return "date"
+    if len(vals) and all(isinstance(v, (bool, np.bool_)) for v in vals):
+        return "boolean"
+    return "string"
 
 
 def _to_double(v: Any) -> float:
