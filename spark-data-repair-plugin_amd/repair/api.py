@@ -5,6 +5,7 @@ from typing import Any
 import pandas as pd
 
 from repair import session
+from repair.misc import RepairMisc
 from repair.model import RepairModel
 
 
@@ -27,6 +28,11 @@ class Delphi():
     def repair(self) -> RepairModel:
         """Returns :class:`RepairModel` to repair input data."""
         return RepairModel()
+
+    @property
+    def misc(self) -> RepairMisc:
+        """Returns :class:`RepairMisc` for misc helper functions."""
+        return RepairMisc()
 
     @staticmethod
     def version() -> str:

@@ -253,3 +253,147 @@ def test_timeout_option_stops_the_search(adult):
     out = _build_model().setTableName("adult").setRowId("tid").setErrorCells("adult_dirty").option("model.hp.max_evals", "10000000") \
         .option("model.hp.no_progress_loss", "100000").option("model.hp.timeout", "3").run()
     assert len(out) == 7 and time.time() - t0 < 120
+
+
+MIXED = [(1, 0, 1.0, 1.0, "a"), (2, 1, 1.5, 1.5, "b"), (3, 0, 1.4, None, "b"), (4, 1, 1.3, 1.3, "b"), (5, 1, 1.2, 1.1, "b"), (6, 1, 1.1, 1.2, "b"),
+         (7, 0, None, 1.4, "b"), (8, 1, 1.4, 1.0, "b"), (9, 0, 1.2, 1.1, "b"), (10, None, 1.3, 1.2, "b"), (11, 0, 1.0, 1.9, "b"), (12, 0, 1.9, 1.2, "b"),
+         (13, 0, 1.2, 1.3, "b"), (14, 0, 1.8, 1.2, None), (15, 0, 1.3, 1.1, "b"), (16, 1, 1.3, 1.0, "b"), (17, 0, 1.3, 1.0, "b")]
+MIXED_ERRORS = [[3, "v3", None], [7, "v2", None], [10, "v1", None], [14, "v4", None]]
+
+
+@pytest.fixture
+def mixed(oracle_backend):
+    from repair.api import Delphi
+    df = pd.DataFrame(MIXED, columns=["tid", "v1", "v2", "v3", "v4"]).astype({"v1": "Int64"})
+    Delphi.register_table("mixed_input", df)
+    return df
+
+
+def test_invalid_running_modes(mixed, adult):
+    """test_invalid_running_modes (test_model.py:231-266)."""
+    from repair.costs import Levenshtein
+    from repair.model import RepairModel
+    m = RepairModel().setTableName("mixed_input").setRowId("tid").setRepairDelta(1).setUpdateCostFunction(Levenshtein())
+    with pytest.raises(ValueError, match="Cannot enable the maximal likelihood repair mode when continous attributes found"):
+        m.run(maximal_likelihood_repair=True)
+    m = RepairModel().setTableName("adult").setRowId("tid").setRepairByRules(True).setUpdateCostFunction(Levenshtein()).setRepairDelta(3) \
+        .option("model.rule.repair_by_nearest_values.disabled", "")
+    msg = "Cannot repair data by nearest values when enabling `maximal_likelihood_repair`, `compute_repair_candidate_prob`, `compute_repair_prob`, or `compute_repair_score`"
+    for kw in (dict(maximal_likelihood_repair=True), dict(compute_repair_candidate_prob=True), dict(compute_repair_prob=True), dict(compute_repair_score=True)):
+        with pytest.raises(ValueError, match=msg):
+            m.run(**kw)
+
+
+def test_compute_repair_prob_for_continouos_values(mixed):
+    """test_compute_repair_prob_for_continouos_values (test_model.py:1095-1118)."""
+    from repair.costs import Levenshtein
+    for f in (lambda m: m, lambda m: m.setUpdateCostFunction(Levenshtein())):
+        m = f(_build_model().setTableName("mixed_input").setRowId("tid"))
+        out = m.run(compute_repair_candidate_prob=True)
+        assert list(out.columns) == ["tid", "attribute", "current_value", "pmf"]
+        got = sorted([int(t), a] for t, a in zip(out["tid"], out["attribute"]))
+        assert got == [r[:2] for r in MIXED_ERRORS]
+        out = m.run(compute_repair_prob=True)
+        assert list(out.columns) == ["tid", "attribute", "current_value", "repaired", "prob"]
+        assert _rows(out, ("tid", "attribute", "current_value")) == MIXED_ERRORS
+
+
+def test_training_data_rebalancing(mixed):
+    """test_training_data_rebalancing (test_model.py:1197-1214)."""
+    out = _build_model().setTableName("mixed_input").setRowId("tid").setTrainingDataRebalancingEnabled(True).run()
+    assert _rows(out, ("tid", "attribute", "current_value")) == MIXED_ERRORS
+    assert out["repaired"].notna().all()
+
+
+def test_rule_based_model_and_poor_model():
+    """test_rule_based_model, test_PoorModel (test_model.py:1148-1181)."""
+    from repair.model import FunctionalDepModel, PoorModel
+    model = FunctionalDepModel("x", {1: "test-1", 2: "test-1", 3: "test-2"})
+    pdf = pd.DataFrame([[3], [1], [2], [4]], columns=["x"])
+    assert model.classes_.tolist() == ["test-1", "test-2"]
+    assert model.predict(pdf) == ["test-2", "test-1", "test-1", None]
+    pmf = model.predict_proba(pdf)
+    assert len(pmf) == 4 and pmf[0].tolist() == [0.0, 1.0] and pmf[1].tolist() == [1.0, 0.0] and pmf[2].tolist() == [1.0, 0.0] and pmf[3] is None
+    for v in (None, "test"):
+        model = PoorModel(v)
+        assert model.classes_.tolist() == [v] and model.predict(pdf) == [v] * 4
+        pmf = model.predict_proba(pdf)
+        assert len(pmf) == 4 and all(p.tolist() == [1.0] for p in pmf)
+
+
+def test_compute_weighted_probs_for_target_attributes(adult, tmp_path):
+    """test_compute_weighted_probs_for_target_attributes (test_model.py:1017-1052): a huge cost weight on `Sex` drives the top
+    candidate's probability to 1 there and leaves `Relationship` alone."""
+    from repair.costs import Levenshtein
+    from repair.errors import ConstraintErrorDetector
+    path = tmp_path / "adult_constraints.txt"
+    path.write_text(adult["constraints"])
+    m = _build_model().setTableName("adult").setRowId("tid").setTargets(["Sex", "Relationship"]).setErrorDetectors([ConstraintErrorDetector(str(path))]) \
+        .option("model.hp.max_evals", "40").option("model.hp.no_progress_loss", "20")
+
+    def top(df):
+        df = df.sort_values(["tid", "attribute"])
+        return [(int(t), a, p[0]["class"], p[0]["prob"]) for t, a, p in zip(df["tid"], df["attribute"], df["pmf"])]
+    base = top(m.run(compute_repair_candidate_prob=True))
+    weighted = top(m.setUpdateCostFunction(Levenshtein(targets=["Sex"])).option("repair.pmf.cost_weight", "100000000.0").run(compute_repair_candidate_prob=True))
+    assert [r[:2] for r in base] == [r[:2] for r in weighted] == [(4, "Relationship"), (4, "Sex"), (11, "Relationship"), (11, "Sex")]
+    for r1, r2 in zip(base, weighted):
+        if r1[1] == "Sex":
+            assert r1[3] < 0.95 and r2[3] > 0.9999
+        else:
+            assert r1[3] < 0.95 and r2[3] < 0.95
+
+
+def test_repair_updates_through_misc(adult):
+    """test_repair_updates (test_model.py:985-1001): `RepairMisc().repair()` applied to the predicted updates gives adult_clean."""
+    from repair.api import Delphi
+    from repair.misc import RepairMisc
+    updates = _build_model().setTableName("adult").setRowId("tid").run()
+    Delphi.register_table("repair_updates_view", updates)
+    out = RepairMisc().option("repair_updates", "repair_updates_view").option("table_name", "adult").option("row_id", "tid").repair()
+    clean = frame(load_golden("adult")["clean"]).sort_values("tid").reset_index(drop=True)
+    assert out.sort_values("tid").reset_index(drop=True).astype(str).values.tolist() == clean.astype(str).values.tolist()
+    assert isinstance(Delphi.getOrCreate().misc, RepairMisc)
+    with pytest.raises(ValueError, match="Table 'adult' must have 'tid', 'attribute', and 'repaired' columns"):
+        RepairMisc().options({"repair_updates": "adult", "table_name": "adult", "row_id": "tid"}).repair()
+
+
+def test_misc_flatten_inject_null_and_argument_checks():
+    """test_misc.py:49-111 (test_argtype_check, test_flatten, test_splitInputTable_invalid_params, test_injectNull) and
+    RepairMiscSuite.scala:49-64,100-122 (flattenTable, injectNullAt)."""
+    from repair.api import Delphi
+    from repair.misc import RepairMisc
+    with pytest.raises(TypeError, match="`key` should be provided as str, got int"):
+        RepairMisc().option(1, "value")
+    with pytest.raises(TypeError, match="`value` should be provided as str, got int"):
+        RepairMisc().option("key", 1)
+    with pytest.raises(TypeError, match=r"`options` should be provided as dict\[str,str\], got int"):
+        RepairMisc().options(1)
+    with pytest.raises(TypeError, match=r"`options` should be provided as dict\[str,str\], got int in keys"):
+        RepairMisc().options({"1": "v1", 2: "v2"})
+    with pytest.raises(TypeError, match=r"`options` should be provided as dict\[str,str\], got float in values"):
+        RepairMisc().options({"1": "v1", "2": 1.1})
+    Delphi.register_table("tempView", pd.DataFrame([(1, "a"), (2, "b"), (3, "c")], columns=["tid", "v"]))
+    out = RepairMisc().options({"table_name": "tempView", "row_id": "tid"}).flatten()
+    assert out.sort_values("tid").values.tolist() == [[1, "v", "a"], [2, "v", "b"], [3, "v", "c"]]
+    Delphi.register_table("t", pd.DataFrame({"tid": ["1", "2", "3", "4"], "v1": [100000, 200000, 300000, 400000], "v2": ["test-1", "test-2", "test-3", "test-4"]}))
+    out = RepairMisc().options({"table_name": "t", "row_id": "tid"}).flatten()
+    assert sorted(map(tuple, out.values.tolist())) == sorted([("1", "v1", "100000"), ("2", "v1", "200000"), ("3", "v1", "300000"), ("4", "v1", "400000"),
+                                                              ("1", "v2", "test-1"), ("2", "v2", "test-2"), ("3", "v2", "test-3"), ("4", "v2", "test-4")])
+    with pytest.raises(ValueError, match="Required options not found: table_name, row_id, k"):
+        RepairMisc().splitInputTable()
+    with pytest.raises(ValueError, match="Option 'k' must be an integer, but 'x' found"):
+        RepairMisc().options({"table_name": "t", "row_id": "tid", "k": "x"}).splitInputTable()
+    Delphi.register_table("tempView", pd.DataFrame([(1, "a", 1), (2, "b", 1), (3, "c", 1), (4, "d", 2)], columns=["tid", "v1", "v2"]))
+    out = RepairMisc().options({"table_name": "tempView", "target_attr_list": "v1", "null_ratio": "1.0"}).injectNull()
+    assert out["v1"].isna().all() and out["v2"].tolist() == [1, 1, 1, 2] and out["tid"].tolist() == [1, 2, 3, 4]
+    out = RepairMisc().options({"table_name": "t", "target_attr_list": "v1", "null_ratio": "1.0"}).injectNull()
+    assert out["v1"].isna().all() and out["v2"].tolist() == ["test-1", "test-2", "test-3", "test-4"]
+    with pytest.raises(ValueError, match=r"Option 'null_ratio' must be a float in \(0.0, 1.0\], but '0.0' found"):
+        RepairMisc().options({"table_name": "t", "target_attr_list": "v2", "null_ratio": "0.0"}).injectNull()
+    with pytest.raises(ValueError, match="Columns 'non-existent' do not exist in 'default.t'"):
+        RepairMisc().options({"db_name": "default", "table_name": "t", "target_attr_list": "non-existent", "null_ratio": "1.0"}).injectNull()
+    big = pd.DataFrame({"tid": np.arange(20000), "x": np.arange(20000) % 7, "y": ["s"] * 20000})
+    Delphi.register_table("big", big)
+    out = RepairMisc().options({"table_name": "big", "target_attr_list": "x,y", "null_ratio": "0.1"}).injectNull()
+    assert 0.08 < out["x"].isna().mean() < 0.12 and 0.08 < out["y"].isna().mean() < 0.12 and not out["tid"].isna().any()
