@@ -397,3 +397,22 @@ def test_misc_flatten_inject_null_and_argument_checks():
     Delphi.register_table("big", big)
     out = RepairMisc().options({"table_name": "big", "target_attr_list": "x,y", "null_ratio": "0.1"}).injectNull()
     assert 0.08 < out["x"].isna().mean() < 0.12 and 0.08 < out["y"].isna().mean() < 0.12 and not out["tid"].isna().any()
+
+
+def test_escaped_column_names_every_mode(oracle_backend):
+    """test_escaped_column_names (test_model.py:687-735): column names with blanks through every run mode."""
+    from repair.costs import Levenshtein
+    rows = [(1, "1", None, 1.0), (2, None, "test-2", 2.0), (3, "1", "test-1", 1.0), (4, "2", "test-2", 2.0), (5, "2", "test-2", 1.0), (6, "1", "test-1", 1.0)]
+    df = pd.DataFrame(rows, columns=["t i d", "x x", "y y", "z z"])
+    m = _build_model().setInput(df).setRowId("t i d").setDiscreteThreshold(10)
+    out = m.run().sort_values(["t i d", "attribute"])
+    assert out.values.tolist() == [[1, "y y", None, "test-1"], [2, "x x", None, "2"]]
+    for kw in (dict(compute_repair_candidate_prob=True), dict(compute_repair_prob=True)):
+        got = m.run(**kw).sort_values(["t i d", "attribute"])
+        assert got[["t i d", "attribute"]].values.tolist() == [[1, "y y"], [2, "x x"]]
+    rep = m.run(repair_data=True)
+    rep = rep[rep["t i d"].isin([1, 2])].sort_values("t i d")
+    assert rep.values.tolist() == [[1, "1", "test-1", 1.0], [2, "2", "test-2", 2.0]]
+    m2 = _build_model().setInput(df[["t i d", "x x", "y y"]]).setRowId("t i d").setDiscreteThreshold(10).setUpdateCostFunction(Levenshtein()).setRepairDelta(3)
+    got = m2.run(compute_repair_score=True).sort_values(["t i d", "attribute"])
+    assert got[["t i d", "attribute"]].values.tolist() == [[1, "y y"], [2, "x x"]]
