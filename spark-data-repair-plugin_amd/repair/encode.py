@@ -42,8 +42,8 @@ class ColumnDict:
             code[~ok] = -1
             out[notna] = code
         else:
-            idx = self._index
-            out[notna] = np.fromiter((idx.get(x, -1) for x in s[notna].tolist()), np.int32, count=int(notna.sum()))
+            # hashed in C: position of each value among the (sorted) dictionary entries, -1 for NULL / unseen values
+            out[:] = pd.Categorical(s.astype(object), categories=pd.Index(self.values, dtype=object)).codes
         return out
 
     def decode(self, codes: np.ndarray) -> np.ndarray:
@@ -76,7 +76,7 @@ class TableEncoder:
             if num:
                 arr = np.unique(pd.to_numeric(vals, errors="coerce").dropna().to_numpy(np.float64))
             else:
-                arr = np.array(sorted(set(vals.tolist())), dtype=object)
+                arr = np.array(sorted(pd.unique(vals.astype(object)).tolist()), dtype=object)
             self.dicts[c] = ColumnDict(arr, num)
 
     @property
