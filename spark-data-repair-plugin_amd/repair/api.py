@@ -1,47 +1,45 @@
-"""`Delphi` facade (reference python/repair/api.py:26-63): `Delphi.getOrCreate().repair` gives a fresh
-RepairModel, `.version()` the package version.  `register_table` stands in for Spark's catalog."""
-from typing import Any
-
+"""Entry point kept from the reference: `Delphi.getOrCreate().repair` hands out a fresh `RepairModel`, `.misc` a
+`RepairMisc`, `.version()` the package version (reference python/repair/api.py:26-63).  Tables the reference would find in
+Spark's catalog are pandas frames registered by name with `Delphi.register_table`."""
 import pandas as pd
 
 from repair import session
 from repair.misc import RepairMisc
 from repair.model import RepairModel
 
+__version__ = "0.1.0-mi355x"
+
 
 class Delphi():
-    """A Delphi API set for data repairing."""
+    """Process-wide facade; every call of `Delphi()` / `Delphi.getOrCreate()` yields the same object."""
 
-    _instance: Any = None
-    __version__ = "0.1.0-mi355x"
+    _the_one = None
 
-    def __new__(cls, *args, **kwargs):  # type: ignore
-        if cls._instance is None:
-            cls._instance = super(Delphi, cls).__new__(cls)
-        return cls._instance
+    def __new__(cls):  # type: ignore
+        if Delphi._the_one is None:
+            Delphi._the_one = object.__new__(cls)
+        return Delphi._the_one
+
+    @classmethod
+    def getOrCreate(cls) -> "Delphi":
+        return cls()
 
     @staticmethod
-    def getOrCreate() -> "Delphi":
-        return Delphi()
+    def version() -> str:
+        return __version__
+
+    @staticmethod
+    def register_table(name: str, df: pd.DataFrame) -> None:
+        """Stands in for `createOrReplaceTempView` / `saveAsTable`: makes `df` reachable as `setTableName(name)`."""
+        session.register_table(name, df)
 
     @property
     def repair(self) -> RepairModel:
-        """Returns :class:`RepairModel` to repair input data."""
         return RepairModel()
 
     @property
     def misc(self) -> RepairMisc:
-        """Returns :class:`RepairMisc` for misc helper functions."""
         return RepairMisc()
-
-    @staticmethod
-    def version() -> str:
-        return Delphi.__version__
-
-    @staticmethod
-    def register_table(name: str, df: pd.DataFrame) -> None:
-        """Registers a DataFrame under a table name (stands in for createOrReplaceTempView)."""
-        session.register_table(name, df)
 
 
 delphi = Delphi.getOrCreate()
