@@ -968,6 +968,7 @@ extern "C" {
 RGBM_EXPORT int rgbm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 RGBM_EXPORT const char* rgbm_last_error(void) { return g_err.c_str(); }
 RGBM_EXPORT int rgbm_version(void) { return RGBM_VERSION; }
+RGBM_EXPORT int rgbm_release_cache(void) { return guarded([&]() { rgh::pool_trim(0); return RGBM_OK; }); }
 
 RGBM_EXPORT int rgbm_table_create(const int32_t* codes, int64_t n, int32_t c, const int32_t* n_codes, int32_t device_id, rgbm_table** out) {
     if (!codes || !n_codes || !out || n <= 0 || c <= 0) return fail(RGBM_ERR_ARG, "rgbm_table_create: bad argument");

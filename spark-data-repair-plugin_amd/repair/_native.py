@@ -72,7 +72,7 @@ def lib():
                                  "spark-data-repair-plugin_amd/csrc`" % path)
         l = C.CDLL(path)
         l.rgbm_last_error.restype = C.c_char_p
-        for name in ("rgbm_device_count", "rgbm_version", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
+        for name in ("rgbm_device_count", "rgbm_version", "rgbm_release_cache", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
                      "rgbm_table_create", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
                      "rgbm_model_save", "rgbm_model_load", "rgbm_model_info", "rgbm_model_importance",
                      "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
@@ -89,7 +89,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = [
-    "rgbm_device_count", "rgbm_last_error", "rgbm_version", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
+    "rgbm_device_count", "rgbm_last_error", "rgbm_version", "rgbm_release_cache", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
     "rgbm_table_create", "rgbm_table_free", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
     "rgbm_model_save", "rgbm_model_load", "rgbm_model_free", "rgbm_model_info", "rgbm_model_importance",
     "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
@@ -150,6 +150,11 @@ def _check(rc, what):
 
 def device_count():
     return int(lib().rgbm_device_count())
+
+
+def release_cache():
+    """Return the device blocks parked in the library's caching pool to the driver (include/rgbm.h)."""
+    _check(lib().rgbm_release_cache(), "rgbm_release_cache")
 
 
 def _p(a, t):
