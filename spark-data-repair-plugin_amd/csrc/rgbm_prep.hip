@@ -530,7 +530,7 @@ RGBM_EXPORT int rgbm_table_create_dict(const int32_t* idx_colmajor, int64_t n, i
                 if (r < -1) throw std::invalid_argument("rgbm_table_create_dict: remap entries must be codes >= 0 or -1 (NULL)");
                 flat.push_back(r); mx = std::max(mx, r);
             }
-            ncodes[j] = mx + 1;
+            ncodes[j] = std::max(mx + 1, 1);      // an all-NULL column still counts as a one-code domain (repair.encode does the same)
         }
         std::unique_ptr<rgbm_table> t(new rgbm_table());
         t->device = device_id; t->n = n; t->c = c; t->n_codes = ncodes;

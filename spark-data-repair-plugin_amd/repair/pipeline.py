@@ -139,13 +139,15 @@ def encode_frame(df, columns):
     return (np.stack(idx) if idx else np.zeros((0, len(df)), np.int32)), remaps, dicts
 
 
-def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=None, want_pmf=False, top_k=32, threshold=0.0):
+def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=None, want_pmf=False, top_k=32, threshold=0.0,
+                 error_cells=None, detect_nulls=True):
     """DataFrame in, the reference's result frame out: (row_id, attribute, current_value, repaired, prob[, pmf]) -- the
     shape of `RepairModel.run()` / `run(compute_repair_candidate_prob=True)` (python/repair/model.py:1398-1419).
 
     Every column is treated as discrete (one class per distinct value); `constraints` are `X1,..,Xm -> Y` dependencies
-    given as ([x names], y name).  Continuous targets, regex / outlier detectors, rule-based repairs and cost functions
-    stay with `repair.model.RepairModel` (the value-space API)."""
+    given as ([x names], y name); `error_cells` is a frame with `row_id` and `attribute` columns (RepairModel.setErrorCells).
+    Continuous targets, regex / outlier detectors, rule-based repairs and cost functions stay with
+    `repair.model.RepairModel` (the value-space API)."""
     import pandas as pd
     cols = [c for c in df.columns if c != row_id]
     targets = list(targets) if targets is not None else list(cols)
@@ -156,8 +158,16 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
     table = engine.upload_dictionaries(indices, remaps)
     pos = {c: i for i, c in enumerate(cols)}
     cons = [([pos[x] for x in xs], pos[y]) for xs, y in constraints]
-    res = repair_table(engine, table, [pos[t] for t in targets], dict(base_params or {}), constraints=cons, want_pmf=want_pmf,
-                       top_k=top_k, threshold=threshold)
+    cells = None
+    if error_cells is not None:
+        if row_id not in error_cells.columns or "attribute" not in error_cells.columns:
+            raise ValueError("Error cells should have `%s` and `attribute` in columns" % row_id)
+        rpos = pd.Series(np.arange(len(df)), index=df[row_id].to_numpy()).reindex(error_cells[row_id].to_numpy()).to_numpy(np.float64)
+        cpos = np.array([pos.get(a, -1) for a in error_cells["attribute"]], np.int64)
+        ok = ~np.isnan(rpos) & (cpos >= 0)                      # cells of unknown rows / attributes drop out (join semantics)
+        cells = (rpos[ok].astype(np.int64), cpos[ok].astype(np.int32))
+    res = repair_table(engine, table, [pos[t] for t in targets], dict(base_params or {}), constraints=cons, detect_nulls=detect_nulls,
+                       error_cells=cells, want_pmf=want_pmf, top_k=top_k, threshold=threshold)
     rows, ccols = res["rows"], res["cols"]
 
     def decode(codes, col_idx):

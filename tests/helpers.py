@@ -113,7 +113,7 @@ class OracleEngine:
     def upload_dictionaries(self, indices, remaps):
         from oracle import prep as P
         codes = P.encode_dictionaries(np.asarray(indices, np.int32), remaps)
-        return OracleEngine._Table(codes, [max(int(np.max(m)) + 1 if len(m) else 0, 0) for m in remaps])
+        return OracleEngine._Table(codes, [max(int(np.max(m)) + 1 if len(m) else 0, 1) for m in remaps])
 
     def train(self, table, target, feats, class_weight, params, y_value=None, want_stats=False):
         from oracle import oracle as O

@@ -144,3 +144,39 @@ def test_repair_frame_hip_engine_equals_oracle_engine():
     a = repair_frame(HipEngine(), df, "tid", **kw)
     b = repair_frame(OracleEngine(), df, "tid", **kw)
     assert a.equals(b)
+
+
+def test_hospital_through_the_pipeline_on_the_oracle_engine():
+    """BASELINE configs[1] (hospital.csv + its 15 denial constraints) through repair.pipeline: the constraints all take the
+    device form and detection equals the pandas ConstraintErrorDetector cell for cell; with the ground-truth error cells
+    handed over (as the reference's benchmark does) the repairs reach the precision floor of tests/test_quality.py."""
+    from repair.errors import ConstraintErrorDetector, parse_and_verify_constraints
+    from repair.pipeline import constraint_to_columns, repair_frame
+    from tests.helpers import OracleEngine, frame, load_golden
+    g = load_golden("hospital")
+    df = frame(g["input"], dtypes=False)
+    df["tid"] = df["tid"].astype(int)
+    cols = [c for c in df.columns if c != "tid"]
+    stmts = [l for l in g["constraints"].splitlines() if l.strip()]
+    plist = parse_and_verify_constraints(stmts, cols)
+    forms = [constraint_to_columns(ps, cols) for ps in plist]
+    constraints = [([cols[i] for i in eq], cols[iq]) for eq, iq in forms]
+    host = ConstraintErrorDetector(constraints=";".join(stmts)).setUp("tid", df, [], cols).detect()
+    targets = sorted(set(host["attribute"]))
+    out = repair_frame(OracleEngine(), df, "tid", targets=targets, constraints=constraints,
+                       base_params=dict(n_estimators=40, learning_rate=0.1, min_data_in_leaf=5))
+    got = set(map(tuple, out[["tid", "attribute"]].values.tolist()))
+    want = set(map(tuple, host.values.tolist())) | set((int(t), a) for a in targets for t in df["tid"][df[a].isna()])
+    assert got == want
+    # the reference's own hospital benchmark hands the ground-truth error cells over (test_model_perf.py:296-309):
+    # same call through the pipeline, same precision floor as tests/test_quality.py
+    cells = frame(g["error_cells"], dtypes=False)
+    cells["tid"] = cells["tid"].astype(int)
+    from tests.test_quality import HOSPITAL_TARGETS
+    out = repair_frame(OracleEngine(), df, "tid", targets=HOSPITAL_TARGETS, error_cells=cells[["tid", "attribute"]],
+                       base_params=dict(n_estimators=300, learning_rate=0.01, min_data_in_leaf=20))
+    clean = frame(g["clean"], dtypes=False)
+    clean["tid"] = clean["tid"].astype(int)
+    c = out.merge(clean, on=["tid", "attribute"], how="inner")
+    assert len(c) > 150
+    assert (c["repaired"] == c["correct_val"]).mean() > 0.9
