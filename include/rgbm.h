@@ -76,6 +76,8 @@ typedef struct {
     int64_t root_rows;       /* of which full-table (root) scans */
     double root_ms;          /* hist_build time spent in root scans */
     int64_t trees;           /* trees grown */
+    double route_ms;         /* level grower, split mode: time of the k_level_route launches (DataPartition::Split of a level) */
+    int64_t route_launches;
 } rgbm_train_stats;
 
 /* Number of usable HIP devices (0 if none). */

@@ -505,6 +505,8 @@ static int ceil_log2(double v) {   /* smallest e with 2^e >= v, v>0 */
     return (m == 0.5) ? ex - 1 : ex;
 }
 
+static int frexp_exp(double v) { int ex; (void)frexp(v, &ex); return ex; }   /* v < 2^ex strictly, v >= 2^(ex-1) */
+
 ORC_API void orc_model_free(orc_model* m);
 
 /* ------------------------------------------------------------------ GBDT::Train */
@@ -603,7 +605,10 @@ ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_c
     if (obj == 2) { bound_g = (ymax - ymin) * w_max; if (!(bound_g > 0.0)) bound_g = 1.0; bound_h = w_max; }
     else if (obj == 0) { bound_g = w_max; bound_h = 0.25 * w_max; }
     else { bound_g = w_max; bound_h = factor * 0.25 * w_max; }
-    const int e_g = 20 - ceil_log2(bound_g), e_h = 21 - ceil_log2(bound_h);
+    /* hessians reach their bound exactly (regression: h = w, so the heaviest rows have h = bound): the scale is the largest
+     * power of two with bound * 2^e_h STRICTLY below 2^21, i.e. 21 - (frexp exponent), one less than for the gradients
+     * when the bound is an exact power of two -- otherwise h = 1 would be clamped to 2^21 - 1 (a 2^-21 bias in every leaf). */
+    const int e_g = 20 - ceil_log2(bound_g), e_h = 21 - frexp_exp(bound_h);
     const double sg = pow2(e_g), sh = pow2(e_h);
     t.ctx.inv_sg = pow2(-e_g); t.ctx.inv_sh = pow2(-e_h); t.ctx.p = p;
 

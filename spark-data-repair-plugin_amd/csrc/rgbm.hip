@@ -30,7 +30,7 @@
 #include "rgbm_kernels.h"
 #include "rgbm_level.h"
 
-#define RGBM_VERSION 100   // numerics spec v1.00
+#define RGBM_VERSION 101   // numerics spec v1.01 (hessian scale: exact when the bound is a power of two)
 
 namespace {
 
@@ -458,7 +458,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (obj == 2) { bound_g = (ymax - ymin) * w_max; if (!(bound_g > 0.0)) bound_g = 1.0; bound_h = w_max; }
     else if (obj == 0) { bound_g = w_max; bound_h = 0.25 * w_max; }
     else { bound_g = w_max; bound_h = factor * 0.25 * w_max; }
-    const int e_g = 20 - ceil_log2(bound_g), e_h = 21 - ceil_log2(bound_h);
+    // hessians reach their bound exactly (regression: h = w): bound * 2^e_h must stay STRICTLY below 2^21, so the scale uses the
+    // frexp exponent (one less than the gradients' rule when the bound is an exact power of two; numerics spec v1.01)
+    int ex_h = 0; (void)std::frexp(bound_h, &ex_h);
+    const int e_g = 20 - ceil_log2(bound_g), e_h = 21 - ex_h;
 
     TrainConst tc; memset(&tc, 0, sizeof(tc));
     tc.sg = std::ldexp(1.0, e_g); tc.sh = std::ldexp(1.0, e_h); tc.inv_sg = std::ldexp(1.0, -e_g); tc.inv_sh = std::ldexp(1.0, -e_h);
@@ -505,6 +508,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout, d_lay_table; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
+    bool split_mode = false; DevBuf<uint32_t> d_list; DevBuf<unsigned int> d_lcnt;
     bool use_reduce = false;   // sum the per-workgroup partials in a separate kernel (many workgroups per class tree, or row-sharded)
     // Experiment (RGBM_LAZY_SCORE=1, off): defer AddScore into the next iteration's gradient kernel so that the scores are touched
     // once per iteration.  Measured on MI355X (K=64, 10M rows): k_level_final 2.48 -> 0.70 ms, but the per-(row, class) gather of
@@ -532,7 +536,19 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         lc.gx = (int)gx; lc.max_built = 1 << std::max(0, p.max_depth - 2); lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
         lc.num_leaves = NL; lc.max_depth = p.max_depth; lc.min_data_in_leaf = p.min_data_in_leaf; lc.N = N; lc.NS = (N + 15) & ~15ll;
         n_hnodes = (1 << p.max_depth) - 1;
-        d_node_a.alloc((size_t)K * lc.NS); d_node_b.alloc((size_t)K * lc.NS);
+        // Split mode (route + list-accumulate kernels) pays off once a level pass is bound by its traffic / LDS atomics rather
+        // than by launch latency; small fits keep the fused pass (one launch fewer per level).  RGBM_LEVEL_SPLIT=0/1 overrides.
+        split_mode = N < (1ll << LV_ROW_BITS) && p.max_depth >= 2 && (long long)K * N >= (1ll << 21);
+        if (const char* e = getenv("RGBM_LEVEL_SPLIT")) split_mode = N < (1ll << LV_ROW_BITS) && p.max_depth >= 2 && atoi(e) != 0;
+        lc.split_mode = split_mode ? 1 : 0;
+        lc.sib_local = (dp && g_comm.rank == 0) ? 1 : 0;
+        d_node_a.alloc((size_t)K * lc.NS);
+        if (!split_mode) d_node_b.alloc((size_t)K * lc.NS);            // split mode routes in place
+        if (split_mode) {
+            const long long nwt = (N + RT_WT_ROWS - 1) / RT_WT_ROWS;
+            lc.list_cap = ((nwt + LV_LIST_SHARDS - 1) / LV_LIST_SHARDS) * RT_WT_ROWS;
+            d_list.alloc((size_t)K * LV_LIST_SHARDS * (size_t)lc.list_cap); d_lcnt.alloc((size_t)K * LV_LIST_SHARDS); d_lcnt.zero(s);
+        }
         d_plan.alloc(K); d_layout.alloc((size_t)K * nchunk); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
         d_part.alloc((size_t)K * gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
         d_count.alloc((size_t)K * 256); use_reduce = dp || lc.gx > 4;
@@ -566,6 +582,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
@@ -636,15 +653,32 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     };
 
     const int score_gx = (int)std::max<long long>(1, std::min<long long>((N + 1023) / 1024, (2048 + K - 1) / K));
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> route_ev;
+    uint8_t* const node_b_p = split_mode ? d_node_a.p : d_node_b.p;      // split mode: one node-id array, updated in place
+    const int route_gx = (int)std::max<long long>(1, std::min<long long>(((N + RT_WT_ROWS - 1) / RT_WT_ROWS + 3) / 4, 256ll * 8 / std::max(1, (K + RT_KS - 1) / RT_KS)));
+    auto launch_route = [&]() {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (stats) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
+        const dim3 g(route_gx, (K + RT_KS - 1) / RT_KS), blk(RT_THREADS);
+#define RGBM_LAUNCH_ROUTE(B, NC, INBAG) hipLaunchKernelGGL((k_level_route<B, NC>), g, blk, 0, s, d_rec.p, d_node_a.p, (const uint8_t*)(INBAG), d_plan.p, d_list.p, d_lcnt.p, lc)
+        if (use_bagging) { if (nchunk == 1) RGBM_LAUNCH_ROUTE(true, 1, d_inbag.p); else if (nchunk == 2) RGBM_LAUNCH_ROUTE(true, 2, d_inbag.p); else RGBM_LAUNCH_ROUTE(true, 0, d_inbag.p); }
+        else { if (nchunk == 1) RGBM_LAUNCH_ROUTE(false, 1, nullptr); else if (nchunk == 2) RGBM_LAUNCH_ROUTE(false, 2, nullptr); else RGBM_LAUNCH_ROUTE(false, 0, nullptr); }
+#undef RGBM_LAUNCH_ROUTE
+        if (stats) { HIPCHK(hipEventRecord(b, s)); route_ev.emplace_back(a, b); }
+    };
     auto launch_pass = [&](bool root, int with_hist, int gz) {
         hipEvent_t a = nullptr, b = nullptr;
         const bool timed = stats && with_hist;
+        if (split_mode && !root) launch_route();
         if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
 #define RGBM_LAUNCH_PASS(R, B, M, INBAG)                                                                                                        \
-        hipLaunchKernelGGL((k_level_pass<R, B, M>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, d_node_b.p, \
+        hipLaunchKernelGGL((k_level_pass<R, B, M>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, node_b_p, \
                            (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc)
         // chunk layout: 0 = one 16-feature chunk, 2 = exactly two (both records prefetched), 3 = more
         if (root) { RGBM_LAUNCH_PASS(true, false, 0, nullptr); }
+        else if (split_mode)
+            hipLaunchKernelGGL((k_level_pass<false, false, 0, true>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, node_b_p,
+                               (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc, d_list.p, d_lcnt.p);
         else if (use_bagging) { if (nchunk == 1) RGBM_LAUNCH_PASS(false, true, 0, d_inbag.p); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, true, 2, d_inbag.p); else RGBM_LAUNCH_PASS(false, true, 3, d_inbag.p); }
         else { if (nchunk == 1) RGBM_LAUNCH_PASS(false, false, 0, nullptr); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, false, 2, nullptr); else RGBM_LAUNCH_PASS(false, false, 3, nullptr); }
 #undef RGBM_LAUNCH_PASS
@@ -672,22 +706,22 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             launch_pass(true, 1, nchunk);
             {
                 auto ex = exchange(true, 1);
-                hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p, cntg, d_fmeta.p,
+                hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p, cntg, d_count.p, d_fmeta.p,
                                    d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             for (int level = 1; level < p.max_depth; ++level) {
-                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
+                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc, split_mode ? d_lcnt.p : (unsigned int*)nullptr);
                 launch_pass(false, 1, nchunk * lv_groups[level]);
                 auto ex = exchange(false, 1 << (level - 1));
                 hipLaunchKernelGGL(k_level_split<false>, dim3((F + 1) / 2, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
-                                   cntg, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
+                                   cntg, d_count.p, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
-            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
+            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc, (unsigned int*)nullptr);
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
-            if (lazy_score) hipLaunchKernelGGL(k_level_final<false>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
+            if (lazy_score) hipLaunchKernelGGL(k_level_final<false>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, node_b_p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
-            else hipLaunchKernelGGL(k_level_final<true>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, d_node_b.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
+            else hipLaunchKernelGGL(k_level_final<true>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, node_b_p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                     d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
             if (dp) { HIPCHK(hipMemcpyAsync(d_count_g.p, d_count.p, (size_t)K * 256 * 4, hipMemcpyDeviceToDevice, s)); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
             hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, d_it.p, tc);
@@ -703,7 +737,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         else if (obj == 1 && K <= 112) {
             PendingTree pend; memset(&pend, 0, sizeof(pend));
             if (lazy_score) {
-                pend.node_a = d_node_a.p; pend.node_b = d_node_b.p; pend.buf = &d_plan.p[0].buf; pend.buf_stride = (long long)(sizeof(LvPlan) / sizeof(int32_t));
+                pend.node_a = d_node_a.p; pend.node_b = node_b_p; pend.buf = &d_plan.p[0].buf; pend.buf_stride = (long long)(sizeof(LvPlan) / sizeof(int32_t));
                 pend.node_delta = d_ndelta.p; pend.tree_L = t_L.p; pend.itp = d_it.p;
             }
             hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8 + (size_t)K * 64, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, pend, tc);
@@ -811,7 +845,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const int64_t rows_acc = dp ? (int64_t)(h_statrows / (unsigned long long)g_comm.nranks) : (int64_t)h_statrows;
             if (dp) root_rows /= g_comm.nranks;
             stats->hist_rows = rows_acc; stats->root_rows = root_rows;
-            stats->hist_bytes = rows_acc * ((int64_t)F + 8);
+            // algorithmic bytes: F bin bytes + 8 B (g,h) per accumulated row, + 4 B where the row is reached through an index list
+            stats->hist_bytes = rows_acc * ((int64_t)F + 8) + (split_mode ? (rows_acc - root_rows) * 4 : 0);
+            for (auto& ev : route_ev) {
+                float m2 = 0.f; HIPCHK(hipEventElapsedTime(&m2, ev.first, ev.second));
+                stats->route_ms += m2; stats->route_launches += 1;
+                (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+            }
             (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
             return guard.release();
         }
@@ -1130,6 +1170,12 @@ RGBM_EXPORT int rgbm_model_load(const void* buf, size_t len, rgbm_model** out) {
             std::unique_ptr<rgbm_model> m(new rgbm_model());
             m->objective = hdr[2]; m->num_class = hdr[3]; m->K = hdr[4]; m->n_iter = hdr[5]; m->F = hdr[6];
             if (m->F < 0 || m->K < 1 || m->n_iter < 0 || m->F > 65535) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad header");
+            // the predictor indexes its K x n score scratch by num_class: the header must be self-consistent
+            if (m->objective < 0 || m->objective > 2 || m->num_class < 1) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad objective / num_class");
+            if (m->objective == 1 ? m->K != m->num_class : m->K != 1) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: class-tree count does not match the objective");
+            if (m->objective == 0 && m->num_class != 2) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: binary model with num_class != 2");
+            // every tree needs at least 16 bytes (L + one leaf value + one leaf count): bound the allocation by the buffer
+            if ((unsigned long long)m->n_iter * (unsigned long long)m->K > (unsigned long long)(end - p) / 16ull) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: tree count exceeds the buffer");
             m->feats.resize(m->F);
             for (Feat& f : m->feats) {
                 need(12); int32_t h3[3]; memcpy(h3, p, 12); p += 12;
@@ -1149,6 +1195,7 @@ RGBM_EXPORT int rgbm_model_load(const void* buf, size_t len, rgbm_model** out) {
                 rd64(t.leaf_value, t.L); rd32(t.leaf_count, t.L);
                 for (size_t j = 0; j < n; ++j) {
                     if (t.feat[j] < 0 || t.feat[j] >= m->F) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: node feature out of range");
+                    if (t.theta[j] < -1 || t.theta[j] > 254) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: node threshold out of range");
                     auto okc = [&](int ch) { return ch < 0 ? (~ch) < t.L : ch < (int)n && ch > (int)j; };
                     if (!okc(t.left[j]) || !okc(t.right[j])) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad child link");
                 }

@@ -51,6 +51,13 @@ constexpr int LV_LDS_BYTES = (LV_LDS_TOTAL / LV_BLOCKS_PER_CU) & ~1023;
 constexpr int LV_CARRY_SHIFT = 11;
 constexpr int LV_MAX_DEPTH = 7;
 constexpr int LV_MAX_LEAVES = 128;
+// split mode (k_level_route + k_level_pass<LIST>): built-row lists
+constexpr int LV_LIST_SHARDS = 8;                       // per class tree: one append counter + region per (wave tile mod 8)
+constexpr int LV_ROW_BITS = 27;                         // list entry = row | built slot << 27  (N < 2^27 rows)
+constexpr uint32_t LV_ROW_MASK = (1u << LV_ROW_BITS) - 1u;
+constexpr int RT_KS = 32;                               // class trees per route workgroup (LDS route tables: 512 B each)
+constexpr int RT_THREADS = 256;
+constexpr int RT_WT_ROWS = 256;                         // rows of one wave tile: 4 consecutive rows per lane
 #ifndef LV_RING
 #define LV_RING 0       // 1: level passes compact the rows that feed a histogram into full waves (per-wave LDS ring).
                         // Measured on MI355X (K=64, 10M rows): halves the LDS atomic instructions but the pass time is unchanged
@@ -87,7 +94,10 @@ struct LvLayout {   // per (class tree, chunk): packed-slot layout of the coming
 struct LevelConst {
     int32_t gx, max_built, nchunk, K, F, totbins, num_leaves, max_depth, min_data_in_leaf, lds_bytes;
     int32_t drain_shift, pad0;   // testing: the per-lane drain budgets are shifted right by this much (0 in production), which forces drains on small inputs
+    int32_t split_mode;          // 1: route + list-accumulate kernels (k_level_route / k_level_pass<LIST>); sibling counts are parent - built
+    int32_t sib_local;           // split mode: k_level_split also writes the derived sibling count into the LOCAL count array (row-sharded: rank 0 only)
     long long N, NS;   // rows; row stride of the node-id arrays (multiple of 16)
+    long long list_cap;          // split mode: entries per (class tree, shard) region of the built-row lists
 };
 
 __device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
@@ -169,21 +179,27 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
 // Algorithmic bytes per accumulated row: F bin bytes + 8 B (g,h); the pass also streams the node
 // ids (1 B in, 1 B out) and the records of rows it only routes.
 // ------------------------------------------------------------------------------------------------
-template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */>
+//   LIST (split mode): no routing at all -- the rows that feed a histogram were listed by k_level_route
+//         (entry = row | built slot << 27); every lane of every wave holds a built row, so the packed atomics
+//         run on full waves only.  The workgroup takes an equal slice of each of the class tree's list shards,
+//         gathers record + (g,h) of the listed rows and counts the rows per built child (the sibling's count
+//         is parent - built, k_level_split).
+template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */, bool LIST = false>
 __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
                                                            uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
                                                            const LvLayout* __restrict__ layout, HistBin* __restrict__ part,
                                                            int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta,
-                                                           const ChunkMeta* __restrict__ cmeta, int with_hist, LevelConst c) {
+                                                           const ChunkMeta* __restrict__ cmeta, int with_hist, LevelConst c,
+                                                           const uint32_t* __restrict__ list = nullptr, const unsigned int* __restrict__ lcnt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int k = blockIdx.y, ch = blockIdx.z % c.nchunk, grp = blockIdx.z / c.nchunk;
     const LvPlan* pp = &plan[k];
     if (pp->done) return;
-    const int n_exp = ROOT ? 0 : pp->n_exp;
+    const int n_exp = (ROOT || LIST) ? 0 : pp->n_exp;
     const int n_built = with_hist ? pp->n_built : 0;
     const int npg = pp->npg;
-    const bool writer = !ROOT && ch == 0 && grp == 0;
+    const bool writer = !ROOT && !LIST && ch == 0 && grp == 0;
     const int g0 = grp * npg;
     int ng = n_built - g0; if (ng > npg) ng = npg; if (ng < 0) ng = 0;
     if (grp >= pp->n_groups && !writer) return;
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
     int32_t* drain_flag = reinterpret_cast<int32_t*>(route + 256);                      // [4] (16 B), relaxed atomic accesses
     uint32_t* lst = reinterpret_cast<uint32_t*>(route + 256) + 4 + (tid >> 6) * LV_LIST;   // this wave's ring (LV_RING)
     int32_t* cnt = reinterpret_cast<int32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4;
-    const int ncnt = 2 * n_exp * LV_CNT_REP;
+    const int ncnt = LIST ? ng * LV_CNT_REP : 2 * n_exp * LV_CNT_REP;   // LIST: rows per built child of this group
     int32_t* wide_g = cnt + ncnt;
     uint32_t* wide_h = reinterpret_cast<uint32_t*>(wide_g + (size_t)ng * wb);
     uint32_t* w_slot = wide_h + (size_t)ng * wb;          // [wb] first packed slot of the bin | sh << 24
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
     off = (off + 15) & ~(size_t)15;
     unsigned long long* fast = reinterpret_cast<unsigned long long*>(smem + off);
 
-    if (!ROOT) for (int i = tid; i < 256; i += LV_THREADS) {
+    if (!ROOT && !LIST) for (int i = tid; i < 256; i += LV_THREADS) {
         // LDS copy of the route table, specialised for this block: built slots become group-local (0xFF = the child's
         // histogram is not this block's business) and an unexpanded node routes to itself, so the row loop needs no selects
         const uint32_t w0 = pp->route0[i]; uint32_t w1 = pp->route1[i];
@@ -306,7 +322,11 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             acc_g += ag; acc_h += ah;
             unsigned char* fb = reinterpret_cast<unsigned char*>(fast) + (unsigned)li * (unsigned)(spn * 8);
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#ifdef LV_DBG_NO_ATOM   // timing experiment: everything but the LDS atomics (results are wrong)
+#define LV_ATOM(j) asm volatile("" :: "v"(fb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << fsh3[j])), "v"(packed))
+#else
 #define LV_ATOM(j) atomicAdd(reinterpret_cast<unsigned long long*>(fb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << fsh3[j])), packed)
+#endif
             if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
                 LV_ATOM(0); LV_ATOM(1); LV_ATOM(2); LV_ATOM(3); LV_ATOM(4); LV_ATOM(5); LV_ATOM(6); LV_ATOM(7);
                 LV_ATOM(8); LV_ATOM(9); LV_ATOM(10); LV_ATOM(11); LV_ATOM(12); LV_ATOM(13); LV_ATOM(14);
@@ -344,7 +364,61 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             fn[s] = (tv && o <= lim) ? nv : LV_INACTIVE;
         }
     };
-    if (ROOT || !LV_RING) {
+    if (LIST) {
+        // ---- split mode: this workgroup's equal slice of every list shard of class tree k.  Two-deep software pipeline:
+        // the entries of tile t+2 and the gathered (record, g, h) of tile t+1 are in flight while tile t runs its atomics.
+        // All loads are issued unconditionally on clamped indices (straight-line code keeps the vmcnt bookkeeping exact).
+        const uint32_t* lk = list + (long long)k * LV_LIST_SHARDS * c.list_cap;
+        for (int shd = 0; shd < LV_LIST_SHARDS; ++shd) {
+            const unsigned cnt_s = lcnt[k * LV_LIST_SHARDS + shd];
+            const unsigned lo = (unsigned)((unsigned long long)cnt_s * blockIdx.x / gridDim.x);
+            const unsigned hi = (unsigned)((unsigned long long)cnt_s * (blockIdx.x + 1) / gridDim.x);
+            if (hi <= lo) continue;                                     // uniform
+            const uint32_t* ls = lk + (long long)shd * c.list_cap;
+            const unsigned ntl = (hi - lo + LV_TILE - 1) / LV_TILE;
+            uint32_t ea[RPT], eb[RPT]; bool va[RPT], vb[RPT];
+            auto load_ent = [&](unsigned t, uint32_t (&e)[RPT], bool (&v)[RPT]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int s = 0; s < RPT; ++s) {
+                    const unsigned long long i = (unsigned long long)lo + (unsigned long long)t * LV_TILE + (unsigned)(s * LV_THREADS + tid);
+                    v[s] = i < hi;
+                    e[s] = ls[v[s] ? i : (unsigned long long)(hi - 1)];
+                }
+            };
+            auto gather = [&](const uint32_t (&e)[RPT], const bool (&v)[RPT], int (&fn)[RPT], uint4 (&fr)[RPT], int2 (&fg)[RPT]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int s = 0; s < RPT; ++s) {
+                    const uint32_t row = e[s] & LV_ROW_MASK;
+                    fr[s] = recc[row]; fg[s] = ghk[row];
+                    const int li = (int)(e[s] >> LV_ROW_BITS) - g0;             // group-local built slot
+                    fn[s] = (v[s] && li >= 0 && li < ng) ? li : -1;
+                }
+            };
+            auto process = [&](const int (&fn)[RPT], const uint4 (&fr)[RPT], const int2 (&fg)[RPT]) __attribute__((always_inline)) {
+                if (LV_FLAG_LOAD()) rendezvous();
+#pragma unroll
+                for (int s = 0; s < RPT; ++s) {
+                    const int li = fn[s];
+                    if (ch == 0 && li >= 0) atomicAdd(&cnt[li * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                    accumulate(li >= 0, li < 0 ? 0 : li, fr[s], fg[s]);
+                }
+            };
+            load_ent(0, ea, va);
+            gather(ea, va, cur_n, cur_r, cur_g);
+            load_ent(1 < ntl ? 1 : 0, eb, vb);
+            unsigned t = 0;
+            while (true) {
+                gather(eb, vb, nxt_n, nxt_r, nxt_g);                     // tile t+1 (a clamped replay of a valid tile past the end)
+                load_ent(t + 2 < ntl ? t + 2 : ntl - 1, ea, va);
+                process(cur_n, cur_r, cur_g);
+                if (++t >= ntl) break;
+                gather(ea, va, cur_n, cur_r, cur_g);
+                load_ent(t + 2 < ntl ? t + 2 : ntl - 1, eb, vb);
+                process(nxt_n, nxt_r, nxt_g);
+                if (++t >= ntl) break;
+            }
+        }
+    } else if (ROOT || !LV_RING) {
         // one tile: prefetch the tile after it into the other register set, then process this one (the two sets swap
         // roles from call to call, so nothing is copied)
         auto tile_step = [&](long long t, int (&Cn)[RPT], uint4 (&Cr)[RPT], uint4 (&Cr2)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT],
@@ -504,10 +578,152 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             if (tot) atomicAdd(&count[(long long)k * 256 + child_first + ci], tot);
         }
     }
+    if (LIST && ch == 0) {   // exact row counts of the built children of this group (k_level_plan numbers the children of parent ei as child_first + 2 ei, + 1)
+        for (int ci = tid; ci < ng; ci += LV_THREADS) {
+            int tot = 0;
+            for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
+            const int ei = g0 + ci;
+            if (tot) atomicAdd(&count[(long long)k * 256 + child_first + 2 * ei + (pp->built_is_left[ei] ? 0 : 1)], tot);
+        }
+    }
 }
 
 #undef LV_FLAG_LOAD
 #undef LV_FLAG_STORE
+
+
+// ------------------------------------------------------------------------------------------------
+// k_level_route (split mode): DataPartition::Split of a whole level for ALL class trees of a row tile.
+// A lane owns 4 consecutive rows: their bin records are loaded ONCE and stay in registers while the
+// lane walks the class trees of its slice -- per class tree it reads one dword of node ids, looks the
+// (at most 64) nodes of the level up in an LDS route table, moves the rows to their children in place
+// (only changed dwords are stored) and appends the rows that fell into a BUILT child to that class
+// tree's list (entry = row | built slot << 27).  No (g,h), no histogram, no counting: the pass costs
+// 1 B per (row, class tree) of HBM traffic instead of 10 B, and k_level_pass<LIST> afterwards runs the
+// packed LDS atomics on full waves of listed rows only.
+// List appends: one returning global atomic per (wave tile, class tree) on one of LV_LIST_SHARDS counters
+// (shard = wave tile mod 8, so a shard region never receives more than ceil(tiles / 8) * 256 entries);
+// the entries of class tree kk are stored while class tree kk+1 is being routed, which hides the atomic's
+// round trip.  Entry order inside a list depends on timing; every sum downstream is an exact integer, so
+// the model does not.
+// grid (persistent, ceil(K / RT_KS)), block RT_THREADS.
+// ------------------------------------------------------------------------------------------------
+template <bool BAG, int NCH /* 1, 2: the row's one / two 16-byte records live in registers; 0: any number of chunks, the split byte is gathered */>
+__global__ __launch_bounds__(RT_THREADS) void k_level_route(const uint4* __restrict__ rec, uint8_t* __restrict__ node /* [K][NS], updated in place */,
+                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
+                                                            uint32_t* __restrict__ list, unsigned int* __restrict__ lcnt, LevelConst c) {
+    __shared__ uint2 rt[RT_KS][64];
+    __shared__ int s_base[RT_KS], s_live[RT_KS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.y * RT_KS;
+    const int nk = (c.K - k0) < RT_KS ? (c.K - k0) : RT_KS;
+    for (int i = tid; i < nk * 64; i += RT_THREADS) {
+        const int kk = i >> 6, j = i & 63;
+        const LvPlan* pp = &plan[k0 + kk];
+        const bool live = !pp->done && pp->n_exp > 0;
+        const int base = live ? (int)pp->exp[0] : 0;          // expanded parents are listed in ascending node id; a level has <= 64 nodes
+        const int n = base + j;
+        uint2 e = make_uint2(0u, 0u);
+        if (live && n < 256) e = make_uint2(pp->route0[n], pp->route1[n]);
+        rt[kk][j] = e;
+        if (j == 0) { s_base[kk] = base; s_live[kk] = live ? 1 : 0; }
+    }
+    __syncthreads();
+    const long long N = c.N, NS = c.NS;
+    const long long nwt = (N + RT_WT_ROWS - 1) / RT_WT_ROWS;
+    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    for (long long wt = (long long)blockIdx.x * (RT_THREADS / 64) + wave; wt < nwt; wt += (long long)gridDim.x * (RT_THREADS / 64)) {
+        const long long row0 = wt * RT_WT_ROWS + lane * 4;
+        const bool lane_on = row0 < N;
+        uint4 r[4], r2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            long long rr = row0 + j; if (rr >= N) rr = N - 1;
+            if (NCH >= 1) r[j] = rec[rr]; else r[j] = make_uint4(0, 0, 0, 0);
+            if (NCH == 2) r2[j] = rec[N + rr]; else r2[j] = make_uint4(0, 0, 0, 0);
+        }
+        uint32_t ib4 = 0x01010101u;
+        if (BAG) { ib4 = 0u; if (lane_on) ib4 = *reinterpret_cast<const uint32_t*>(inbag + row0); }
+        // rows past the end of the table never take part (their node bytes are uninitialised)
+        uint32_t rowmask = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (row0 + j < N) rowmask |= 0xFFu << (8 * j);
+        ib4 &= rowmask;
+        const unsigned shard = (unsigned)(wt & (LV_LIST_SHARDS - 1));
+        // appends of the previous class tree, still waiting for their list position
+        bool p_any = false; unsigned p_base = 0u; uint32_t p_ent[4] = {0, 0, 0, 0}; unsigned long long p_m[4] = {0, 0, 0, 0}; uint32_t* p_lst = nullptr;
+        auto flush = [&]() __attribute__((always_inline)) {
+            if (p_any) {
+                unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)p_base);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if ((p_m[j] >> lane) & 1ull) p_lst[off + (unsigned)__popcll(p_m[j] & lane_lt)] = p_ent[j];
+                    off += (unsigned)__popcll(p_m[j]);
+                }
+            }
+        };
+        // node ids of the NEXT class tree are requested before this class tree's store / list atomic are issued: vmcnt retires in
+        // order, so waiting for them never waits for the atomic behind them
+        uint32_t n4_next = 0xFFFFFFFFu;
+        if (lane_on) n4_next = *reinterpret_cast<const uint32_t*>(node + (long long)k0 * NS + row0);
+        for (int kk = 0; kk < nk; ++kk) {
+            uint32_t* np = reinterpret_cast<uint32_t*>(node + (long long)(k0 + kk) * NS + row0);
+            const uint32_t n4 = n4_next;
+            if (kk + 1 < nk && lane_on) n4_next = *reinterpret_cast<const uint32_t*>(node + (long long)(k0 + kk + 1) * NS + row0);
+            if (!s_live[kk]) continue;                                   // uniform
+            const uint32_t base = (uint32_t)s_base[kk];
+            uint32_t idx[4]; bool in[4]; bool any_in = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                idx[j] = ((n4 >> (8 * j)) & 0xFFu) - base;
+                in[j] = idx[j] < 64u && ((rowmask >> (8 * j)) & 1u);
+                any_in |= in[j];
+            }
+            if (__ballot(any_in) == 0ull) continue;                      // no row of this wave tile sits in a node of the level
+            uint32_t out4 = n4; uint32_t ent[4]; bool built[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint2 e = rt[kk][idx[j] & 63u];
+                const bool expd = in[j] && (e.x & (1u << 24)) != 0u;
+                const unsigned f = e.x & 0xFFu;
+                unsigned bin;
+                if (NCH == 0) {
+                    bin = 0u;
+                    if (expd) bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)];
+                } else {
+                    uint32_t rx = r[j].x, ry = r[j].y, rz = r[j].z, rw = r[j].w;
+                    if (NCH == 2) { const bool second = (f >> 4) != 0u; rx = second ? r2[j].x : rx; ry = second ? r2[j].y : ry; rz = second ? r2[j].z : rz; rw = second ? r2[j].w : rw; }
+                    const bool hi = (f & 8u) != 0u;
+                    const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
+                    bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
+                }
+                const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
+                const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, built slot in bits 16..23 (0xFF: not built)
+                const unsigned li = (sel >> 16) & 0xFFu;
+                if (expd) out4 = (out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j));
+                built[j] = expd && li != 0xFFu && ((ib4 >> (8 * j)) & 0xFFu) != 0u;
+                ent[j] = (uint32_t)(row0 + j) | (li << LV_ROW_BITS);
+            }
+            if (out4 != n4) *np = out4;
+            unsigned long long m[4]; unsigned total = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { m[j] = __ballot(built[j]); total += (unsigned)__popcll(m[j]); }
+            unsigned my_base = 0u;
+            unsigned int* cp = lcnt + (long long)(k0 + kk) * LV_LIST_SHARDS + shard;
+#ifdef RT_DBG_NO_APPEND
+            total = 0u;
+#endif
+            if (total != 0u && lane == 0) my_base = atomicAdd(cp, total);
+            flush();                                                     // the previous class tree's entries: its atomic has long returned
+            p_any = total != 0u; p_base = my_base;
+            p_lst = list + ((long long)(k0 + kk) * LV_LIST_SHARDS + shard) * c.list_cap;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { p_ent[j] = ent[j]; p_m[j] = m[j]; }
+        }
+        flush();
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_level_reduce: sum the gx workgroup partials of every built child into one compact [K][nb][totbins] buffer.
@@ -552,7 +768,7 @@ __global__ __launch_bounds__(256) void k_counts_unpack(const long long* __restri
 // ------------------------------------------------------------------------------------------------
 template <bool ROOT>
 __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__ part, HistBin* __restrict__ pool, LvPlan* __restrict__ plan,
-                                                     SNode* __restrict__ nodes, const int32_t* __restrict__ count,
+                                                     SNode* __restrict__ nodes, int32_t* __restrict__ count, int32_t* __restrict__ count_local,
                                                      const FeatMeta* __restrict__ fmeta, const uint8_t* __restrict__ used_all /* [NE][K][F] */,
                                                      Cand* __restrict__ cand /* [K][256][F] */, unsigned long long* __restrict__ stat_rows,
                                                      const int32_t* __restrict__ itp /* device-side iteration counter */,
@@ -613,7 +829,19 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int b = lane * 4 + j; if (b < fm.nbins) { HistBin v; v.g = ag[j]; v.h = ah[j]; hm[b] = v; } }
-    const int nl = count[(long long)k * 256 + l], nr = count[(long long)k * 256 + r];
+    int nl = count[(long long)k * 256 + l], nr = count[(long long)k * 256 + r];
+    if (lc.split_mode) {
+        // only the built child was counted (k_level_pass<LIST>); its sibling holds the rest of the parent's rows.  The derived
+        // count is published for the leaf counts; row-sharded training sums the LOCAL arrays, so exactly one rank also
+        // stores it there (lc.sib_local).
+        const int nb = bl ? nl : nr, ns = P.count - nb;
+        if (bl) nr = ns; else nl = ns;
+        if (f == 0 && lane == 0 && side == 0) {
+            const int sib = bl ? r : l;
+            count[(long long)k * 256 + sib] = ns;
+            if (lc.sib_local && count_local != count) count_local[(long long)k * 256 + sib] = ns;
+        }
+    }
     // SerialTreeLearner::BeforeFindBestSplit: both children too small -> neither is searched
     const bool go = !(nr < c.min_data_in_leaf * 2 && nl < c.min_data_in_leaf * 2);
     if (f == 0 && lane == 0) {
@@ -632,10 +860,12 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, const LvLayout* __restrict__ lay_table, SNode* __restrict__ nodes,
                                                     const Cand* __restrict__ cand, const FeatMeta* __restrict__ fmeta,
-                                                    const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc) {
+                                                    const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc,
+                                                    unsigned int* __restrict__ lcnt /* split mode: list append counters [K][LV_LIST_SHARDS], reset here; else null */) {
     __shared__ double pm[256];
     const int k = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
     LvPlan* pp = &plan[k];
+    if (lcnt && threadIdx.x < LV_LIST_SHARDS) lcnt[k * LV_LIST_SHARDS + threadIdx.x] = 0u;
     if (pp->done) return;
     SNode* nk = nodes + (long long)k * 256;
     const Cand* ck = cand + (long long)k * 256 * c.F;

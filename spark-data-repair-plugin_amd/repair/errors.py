@@ -448,7 +448,10 @@ class ErrorModel:
             frames = [d.setUp(rid, input_df, continous_columns, tattrs).detect() for d in dets]
             cells = _concat(frames, pd.DataFrame({rid: pd.Series([], dtype=input_df[rid].dtype), "attribute": pd.Series([], dtype=object)}))
         cells = cells.drop_duplicates(ignore_index=True)
-        cells = cells[cells["attribute"].isin([c for c in input_df.columns if c != rid])].reset_index(drop=True)
+        cells = cells[cells["attribute"].isin([c for c in input_df.columns if c != rid])]
+        # RepairApi.withCurrentValues is an INNER join on the row id (RepairApi.scala:91-101): cells of rows the input does not
+        # hold are dropped silently
+        cells = cells[cells[rid].isin(input_df[rid])].reset_index(drop=True)
         if len(cells) == 0:
             cells = cells.assign(current_value=pd.Series([], dtype=object))
             return cells, [], {}, {}
@@ -458,7 +461,8 @@ class ErrorModel:
         rpos = pos.reindex(cells[rid].to_numpy()).to_numpy()
         for a, idx in cells.groupby("attribute").indices.items():
             col = input_df[a]
-            vals = col.to_numpy()[rpos[idx].astype(np.int64)]
+            # object dtype keeps nullable integers integral (CAST(int AS STRING) gives '2', never '2.0')
+            vals = col.to_numpy(dtype=object)[rpos[idx].astype(np.int64)]
             cur[idx] = [None if pd.isna(v) else _to_sql_string(v) for v in vals]
         cells = cells.assign(current_value=cur)
         noisy_columns = [c for c in input_df.columns if c in set(cells["attribute"])]

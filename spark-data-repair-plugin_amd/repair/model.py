@@ -23,6 +23,7 @@ from repair.costs import UpdateCostFunction
 from repair.encode import is_integral_column, is_numeric_column
 from repair.errors import ConstraintErrorDetector, ErrorDetector, ErrorModel, RegExErrorDetector, parse_constraint, load_constraints
 from repair.train import build_model, compute_class_nrow_stdv, rebalance_training_data, train_option_keys
+from repair.train import _opt_gpu_device_id as _train_opt_gpu_device_id
 from repair.utils import argtype_check, elapsed_time, get_option_value, job_group, setup_logger, to_list_str
 
 _logger = setup_logger()
@@ -93,8 +94,8 @@ class RepairModel():
     _opt_cost_weight = _option("repair.pmf.cost_weight", 0.1, float, lambda v: v > 0.0, "`{}` should be positive")
     _opt_prob_threshold = _option("repair.pmf.prob_threshold", 0.0, float, None, None)
     _opt_prob_top_k = _option("repair.pmf.prob_top_k", 32, int, lambda v: v >= 3, "`{}` should be greater than 2")
-    # new in this engine: which HIP device trains/predicts
-    _opt_gpu_device_id = _option("model.gpu.device_id", 0, int, lambda v: v >= 0, "`{}` should be non-negative")
+    # new in this engine: which HIP device trains/predicts (read by repair.train.fixed_params)
+    _opt_gpu_device_id = _train_opt_gpu_device_id
 
     option_keys = set([o.key for o in (
         _opt_max_training_row_num, _opt_max_training_column_num, _opt_small_domain_threshold, _opt_repair_by_regex_disabled,
@@ -457,11 +458,16 @@ class RepairModel():
             if probs is None:
                 cls, pr = [], []
             else:
-                cls, pr = [_to_str(c) for c in classes], [float(p) for p in np.asarray(probs)[:len(classes)]]
-            if self.cf is not None and pr and (not self.cf.targets or attr in self.cf.targets):
-                costs = [self.cf.compute(cur, c) for c in cls] if cur else None
-                if costs is not None:
-                    pr = [p * (1.0 / (1.0 + weight * c)) if c is not None else p for p, c in zip(pr, costs)]
+                # a PoorModel(None) target (every label NULL) has the single class NULL, not the string 'None'
+                cls = [None if c is None else _to_str(c) for c in classes]
+                pr = [float(p) for p in np.asarray(probs)[:len(classes)]]
+            if self.cf is not None and pr:
+                # _compute_weighted_probs (model.py:1145-1165): costs weigh the probs of the cost function's targets only,
+                # but the renormalisation runs for every attribute once a cost function is set
+                if not self.cf.targets or attr in self.cf.targets:
+                    costs = [self.cf.compute(cur, c) for c in cls] if cur else None
+                    if costs is not None:
+                        pr = [p * (1.0 / (1.0 + weight * c)) if c is not None else p for p, c in zip(pr, costs)]
                 norm = sum(pr)
                 pr = [p / norm for p in pr] if norm > 0 else pr
             cur_prob = pr[cls.index(cur)] if cur in cls else 0.0

@@ -45,6 +45,8 @@ _opt_timeout = _option("model.hp.timeout", 0, int, None, None)
 _opt_max_evals = _option("model.hp.max_evals", 100000000, int, lambda v: v > 0, "`{}` should be positive")
 _opt_no_progress_loss = _option("model.hp.no_progress_loss", 50, int, lambda v: v > 0, "`{}` should be positive")
 _opt_batch_size = _option("model.hp.batch_size", 8, int, lambda v: v > 0, "`{}` should be positive")
+# new in this engine: which HIP device trains / predicts (one process per GPU: every rank names its own)
+_opt_gpu_device_id = _option("model.gpu.device_id", 0, int, lambda v: v >= 0, "`{}` should be non-negative")
 
 train_option_keys = [o.key for o in (
     _opt_boosting_type, _opt_class_weight, _opt_learning_rate, _opt_max_depth, _opt_max_bin, _opt_reg_alpha,
@@ -70,7 +72,8 @@ def fixed_params(opts: Dict[str, str], is_discrete: bool, num_class: int, n_jobs
     p = {"boosting_type": g(_opt_boosting_type), "objective": objective, "class_weight": g(_opt_class_weight),
          "learning_rate": g(_opt_learning_rate), "max_depth": g(_opt_max_depth), "max_bin": g(_opt_max_bin),
          "reg_alpha": g(_opt_reg_alpha), "min_split_gain": g(_opt_min_split_gain), "n_estimators": g(_opt_n_estimators),
-         "importance_type": g(_opt_importance_type), "random_state": 42, "n_jobs": n_jobs}
+         "importance_type": g(_opt_importance_type), "random_state": 42, "n_jobs": n_jobs,
+         "device_id": g(_opt_gpu_device_id)}
     if objective == "multiclass":
         p["num_class"] = num_class
     return p

@@ -75,3 +75,27 @@ def test_params_struct_layout_matches_oracle():
     from repair import _native
     assert [f[0] for f in O.OrcParams._fields_] == [f[0] for f in _native.RgbmParams._fields_]
     assert ctypes.sizeof(O.OrcParams) == ctypes.sizeof(_native.RgbmParams) == 104
+
+
+def test_model_load_rejects_inconsistent_headers():
+    """A blob travels through pickle and the cross-rank all-gather: objective / num_class / K must agree with each other
+    (the predictor sizes its score scratch by them) and the tree count must fit the buffer."""
+    import struct
+    from oracle import oracle as O
+    from repair import _native
+    rng = np.random.default_rng(1)
+    X = rng.integers(0, 4, (2, 300)).astype(np.int32); y = (X[0] + X[1]) % 3
+    blob = O.train(X, [4, 4], y, 3, objective=1, num_class=3, n_estimators=3, min_data_in_leaf=5).save()
+    hdr = list(struct.unpack_from("7i", blob, 0))          # magic, version, objective, num_class, K, n_iter, F
+
+    def with_header(**kw):
+        h = list(hdr)
+        for k, v in kw.items():
+            h[dict(objective=2, num_class=3, K=4, n_iter=5)[k]] = v
+        return struct.pack("7i", *h) + blob[28:]
+
+    for bad in (with_header(objective=7), with_header(objective=-1), with_header(num_class=9), with_header(num_class=0),
+                with_header(objective=0), with_header(objective=2), with_header(n_iter=1 << 28)):
+        with pytest.raises(_native.RepairGbmError):
+            _native.Model.load(bad)
+    assert _native.Model.load(with_header()).save() == blob

@@ -16,21 +16,24 @@ pytestmark = pytest.mark.gpu
 
 
 class _grower:
+    """level = the fused level pass; split = route + list-accumulate kernels (the default for large fits); leafwise."""
+
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
-        self.prev = os.environ.get("RGBM_GROWER")
+        self.prev = {k: os.environ.get(k) for k in ("RGBM_GROWER", "RGBM_LEVEL_SPLIT")}
+        os.environ.pop("RGBM_GROWER", None)
         if self.name == "leafwise":
             os.environ["RGBM_GROWER"] = "leafwise"
-        else:
-            os.environ.pop("RGBM_GROWER", None)
+        os.environ["RGBM_LEVEL_SPLIT"] = "1" if self.name == "split" else "0"
 
     def __exit__(self, *a):
-        if self.prev is None:
-            os.environ.pop("RGBM_GROWER", None)
-        else:
-            os.environ["RGBM_GROWER"] = self.prev
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def _three_way(X, n_codes, y, K, obj, cw=None, yv=None, **kw):
@@ -40,10 +43,13 @@ def _three_way(X, n_codes, y, K, obj, cw=None, yv=None, **kw):
     mo = O.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
     with _grower("level"):
         ml = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
+    with _grower("split"):
+        ms = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
     with _grower("leafwise"):
         mw = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
     bo = mo.save()
-    assert ml.save() == bo, "level grower differs from the oracle"
+    assert ml.save() == bo, "level grower (fused pass) differs from the oracle"
+    assert ms.save() == bo, "level grower (route + list passes) differs from the oracle"
     assert mw.save() == bo, "leaf-wise grower differs from the oracle"
     po = mo.predict(X)
     assert np.array_equal(po, ml.predict(X))

@@ -16,6 +16,13 @@ from tests.synth import make_table, balanced_weights
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["fused", "split"], autouse=True)
+def level_pass_kind(request, monkeypatch):
+    """Every case runs with the fused level pass and with the route + list-accumulate kernels (the default for large fits)."""
+    monkeypatch.setenv("RGBM_LEVEL_SPLIT", "1" if request.param == "split" else "0")
+    return request.param
+
+
 def _train_sharded(dirty, cards, bounds, target, feats, cw, kw):
     from repair import _native as N
     nr = len(bounds) - 1

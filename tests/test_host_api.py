@@ -273,3 +273,35 @@ def test_repair_attrs_from_golden():
     # half-up like Spark's round(), unparsable text becomes NULL
     upd = pd.DataFrame({"tid": [1, 2, 3], "attribute": ["x"] * 3, "repaired": ["2.5", "-2.5", "abc"]})
     assert m._repair_attrs(upd, base)["x"].tolist()[:2] == [3, -3] and m._repair_attrs(upd, base)["x"].isna().tolist() == [False, False, True]
+
+
+def test_error_cells_of_unknown_rows_are_dropped(oracle_backend):
+    """RepairApi.withCurrentValues is an inner join on the row id (RepairApi.scala:91-101): a caller-supplied
+    error cell whose row the input does not hold vanishes instead of crashing the run."""
+    df = _adult()
+    cells = pd.DataFrame({"tid": [3, 12, 999], "attribute": ["Sex", "Age", "Sex"]})
+    m = RepairModel().setInput(df).setRowId("tid").setErrorCells(cells).option("model.hp.max_evals", "1")
+    det = m.run(detect_errors_only=True)
+    assert sorted(zip(det["tid"], det["attribute"])) == [(3, "Sex"), (12, "Age")]
+    out = m.run()
+    assert set(out["tid"]) <= {3, 12}
+
+
+def test_current_value_of_nullable_integers_is_integral():
+    """CAST(int AS STRING) renders 2 as '2' even when the column holds NULLs (pandas would widen it to 2.0)."""
+    from repair.errors import ErrorModel
+    df = pd.DataFrame({"tid": [0, 1, 2, 3], "v": pd.array([2, None, 5, 2], dtype="Int64"), "w": ["a", "b", None, "a"]})
+    cells = pd.DataFrame({"tid": [0, 1, 2], "attribute": ["v", "v", "w"]})
+    em = ErrorModel("tid", [], 80, [], cells, {})
+    got, _, _, _ = em.detect(df, ["v"])
+    assert dict(zip(zip(got["tid"], got["attribute"]), got["current_value"])) == {(0, "v"): "2", (1, "v"): None, (2, "w"): None}
+
+
+def test_gpu_device_option_reaches_the_estimator():
+    from repair.train import fixed_params
+    from repair.gbm import RepairGBMClassifier
+    p = fixed_params({"model.gpu.device_id": "3"}, True, 4, -1)
+    assert p["device_id"] == 3 and RepairGBMClassifier(**p).device_id == 3
+    assert fixed_params({}, False, 0, -1)["device_id"] == 0
+    with pytest.raises(ValueError, match="should be non-negative"):
+        fixed_params({"model.gpu.device_id": "-1"}, True, 4, -1)

@@ -109,8 +109,10 @@ def test_bagging_and_feature_fraction_paths_run():
     assert m.info()["n_iter"] == 10 and (m.predict(X).argmax(1) == y).mean() > 0.5
 
 
-def test_agrees_with_sklearn_hist_gradient_boosting():
-    """Independent LightGBM-family implementation present in the image: agreement in accuracy, not bits."""
+def test_multiclass_accuracy_next_to_sklearn_hist_gradient_boosting():
+    """Sanity of the multiclass / class-weight path next to an independent implementation (accuracy only: sklearn's softmax
+    gradients are float32 and its class trees use a different hessian factor, so trees cannot be compared node by node here).
+    The node-by-node pin of the tree growth lives in tests/test_oracle_split_pin.py."""
     from sklearn.ensemble import HistGradientBoostingClassifier
     dirty, clean, cards = make_table(8000, 8, seed=8)
     tgt = 5; feats = [c for c in range(8) if c != tgt]

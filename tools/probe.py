@@ -12,10 +12,16 @@ ap.add_argument("--cols", type=int, default=16)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--targets", type=str, default="0,4,10")
 ap.add_argument("--stats", type=int, default=1)
+ap.add_argument("--sort", type=int, default=0, help="1: cluster the rows on the host first (lexicographic by descending cardinality)")
 a = ap.parse_args()
 t0 = time.time()
 dirty, clean, cards = make_table(a.rows, a.cols, seed=42)
 print("gen %.1fs" % (time.time() - t0), flush=True)
+if a.sort:
+    t0 = time.time()
+    order = np.lexsort([dirty[c] for c in np.argsort(cards, kind="stable")])      # last key = primary = the largest cardinality
+    dirty = np.ascontiguousarray(dirty[:, order])
+    print("host sort %.1fs" % (time.time() - t0), flush=True)
 t0 = time.time(); tab = N.Table(dirty, cards); print("upload %.2fs" % (time.time() - t0), flush=True)
 for t in [int(x) for x in a.targets.split(",")]:
     feats = [c for c in range(a.cols) if c != t]
@@ -25,6 +31,6 @@ for t in [int(x) for x in a.targets.split(",")]:
         m, st = tab.train(t, feats, class_weight=cw, want_stats=bool(a.stats), objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=a.iters)
         dt = time.time() - t0
         ktrees = 1 if K == 2 else K
-        print("target %d K=%d: %.3fs wall, %.1f ms/iter, %.2f ms/tree | hist %.1f ms (%d launches) root %.1f ms | rows %.3g bytes %.3g -> hist %.1f GB/s, root %.1f GB/s" % (
-            t, K, dt, dt * 1e3 / a.iters, dt * 1e3 / a.iters / ktrees, st["hist_ms"], st["hist_launches"], st["root_ms"], st["hist_rows"], st["hist_bytes"],
+        print("target %d K=%d: %.3fs wall, %.1f ms/iter, %.2f ms/tree | hist %.1f ms (%d launches) root %.1f ms route %.1f ms (%d) | rows %.3g bytes %.3g -> hist %.1f GB/s, root %.1f GB/s" % (
+            t, K, dt, dt * 1e3 / a.iters, dt * 1e3 / a.iters / ktrees, st["hist_ms"], st["hist_launches"], st["root_ms"], st.get("route_ms", 0.0), st.get("route_launches", 0), st["hist_rows"], st["hist_bytes"],
             st["hist_bytes"] / max(st["hist_ms"], 1e-9) * 1e-6, st["root_rows"] * (len(feats) + 8) / max(st["root_ms"], 1e-9) * 1e-6), flush=True)
