@@ -362,15 +362,26 @@ typedef struct {
     split_ctx ctx;
 } trainer;
 
+/* Threads of the timing harness (bench.py cpu_baseline): LightGBM's col-wise mode builds the per-feature histograms in
+ * parallel; so does this (features are independent output ranges and the sums are integers: bit-identical for any thread
+ * count).  Default 1: the tests never change it. */
+static int g_threads = 1;
+ORC_API void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
 static void build_hist(const trainer* t, const int32_t* rows, int64_t n, const int32_t* gq, const int32_t* hq,
                        const char* used, int64_t* hg, int64_t* hh) {
     memset(hg, 0, sizeof(int64_t) * t->totbins);
     memset(hh, 0, sizeof(int64_t) * t->totbins);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads) if (g_threads > 1 && n > 4096)
     for (int f = 0; f < t->F; ++f) {
         if (!used[f]) continue;
         const uint8_t* b = t->bins + (size_t)f * t->N;
-        int64_t* g = hg + t->hoff[f]; int64_t* h = hh + t->hoff[f];
-        for (int64_t i = 0; i < n; ++i) { int32_t r = rows[i]; g[b[r]] += gq[r]; h[b[r]] += hq[r]; }
+        /* a private copy per feature: neighbouring features' bins share cache lines (false sharing between threads) */
+        int64_t lg[256], lh[256];
+        memset(lg, 0, sizeof(lg)); memset(lh, 0, sizeof(lh));
+        for (int64_t i = 0; i < n; ++i) { int32_t r = rows[i]; lg[b[r]] += gq[r]; lh[b[r]] += hq[r]; }
+        const int nb = (f + 1 < t->F ? t->hoff[f + 1] : t->totbins) - t->hoff[f];
+        memcpy(hg + t->hoff[f], lg, sizeof(int64_t) * (size_t)nb); memcpy(hh + t->hoff[f], lh, sizeof(int64_t) * (size_t)nb);
     }
 }
 
@@ -661,7 +672,12 @@ ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_c
             bag_cnt = l;
         }
         /* Boosting(): gradients of all classes from the scores at iteration start */
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1 && N > 4096)
+        {
+        double* rec_t = (double*)malloc(sizeof(double) * (K > 0 ? K : 1));   /* per-thread softmax scratch */
+#pragma omp for schedule(static)
         for (int64_t i = 0; i < N; ++i) {
+            double* rec = rec_t;
             double wi = w ? w[i] : 1.0;
             if (obj == 0) {
                 double label = (y_code[i] > 0) ? 1.0 : -1.0;
@@ -696,6 +712,8 @@ ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_c
                 if (b > HQ_MAX) b = HQ_MAX;
                 gq[i] = (int32_t)a; hq[i] = (int32_t)b;
             }
+        }
+        free(rec_t);
         }
         int should_continue = 0;
         for (int k = 0; k < K; ++k) {

@@ -508,7 +508,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout, d_lay_table; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
-    bool split_mode = false; DevBuf<uint32_t> d_list; DevBuf<unsigned int> d_lcnt;
+    bool split_mode = false;
     bool use_reduce = false;   // sum the per-workgroup partials in a separate kernel (many workgroups per class tree, or row-sharded)
     // Experiment (RGBM_LAZY_SCORE=1, off): defer AddScore into the next iteration's gradient kernel so that the scores are touched
     // once per iteration.  Measured on MI355X (K=64, 10M rows): k_level_final 2.48 -> 0.70 ms, but the per-(row, class) gather of
@@ -520,7 +520,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         // workgroups per (class tree, chunk): one 1024-thread workgroup per CU; pick the count that fills whole
         // rounds of 256 CUs best, with <= 2^22 rows per workgroup (32-bit carry words) and >= 1 tile each
         lc.lds_bytes = LV_LDS_BYTES;
-        if (const char* e = getenv("RGBM_LV_LDS")) { int v = atoi(e); if (v >= 16384 && v <= LV_LDS_BYTES) lc.lds_bytes = v; }
+        if (const char* e = getenv("RGBM_LV_LDS")) { int v = atoi(e); if (v >= 65536 && v <= LV_LDS_BYTES) lc.lds_bytes = v; }
         if (const char* e = getenv("RGBM_LV_DRAIN_SHIFT")) { int v = atoi(e); if (v >= 0 && v <= 31) lc.drain_shift = v; }   // testing: force packed-slot drains
         const long long cu_slots = 256ll * std::max(1, std::min(LV_LDS_TOTAL / lc.lds_bytes, 2048 / LV_THREADS));   // resident workgroups
         const long long per = (long long)K * nchunk;
@@ -538,17 +538,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         n_hnodes = (1 << p.max_depth) - 1;
         // Split mode (route + list-accumulate kernels) pays off once a level pass is bound by its traffic / LDS atomics rather
         // than by launch latency; small fits keep the fused pass (one launch fewer per level).  RGBM_LEVEL_SPLIT=0/1 overrides.
-        split_mode = N < (1ll << LV_ROW_BITS) && p.max_depth >= 2 && (long long)K * N >= (1ll << 21);
-        if (const char* e = getenv("RGBM_LEVEL_SPLIT")) split_mode = N < (1ll << LV_ROW_BITS) && p.max_depth >= 2 && atoi(e) != 0;
+        split_mode = p.max_depth >= 2 && (long long)K * N >= (1ll << 21);
+        if (const char* e = getenv("RGBM_LEVEL_SPLIT")) split_mode = p.max_depth >= 2 && atoi(e) != 0;
         lc.split_mode = split_mode ? 1 : 0;
         lc.sib_local = (dp && g_comm.rank == 0) ? 1 : 0;
         d_node_a.alloc((size_t)K * lc.NS);
         if (!split_mode) d_node_b.alloc((size_t)K * lc.NS);            // split mode routes in place
-        if (split_mode) {
-            const long long nwt = (N + RT_WT_ROWS - 1) / RT_WT_ROWS;
-            lc.list_cap = ((nwt + LV_LIST_SHARDS - 1) / LV_LIST_SHARDS) * RT_WT_ROWS;
-            d_list.alloc((size_t)K * LV_LIST_SHARDS * (size_t)lc.list_cap); d_lcnt.alloc((size_t)K * LV_LIST_SHARDS); d_lcnt.zero(s);
-        }
+
         d_plan.alloc(K); d_layout.alloc((size_t)K * nchunk); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
         d_part.alloc((size_t)K * gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
         d_count.alloc((size_t)K * 256); use_reduce = dp || lc.gx > 4;
@@ -583,6 +579,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
@@ -660,10 +657,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         hipEvent_t a = nullptr, b = nullptr;
         if (stats) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
         const dim3 g(route_gx, (K + RT_KS - 1) / RT_KS), blk(RT_THREADS);
-#define RGBM_LAUNCH_ROUTE(B, NC, INBAG) hipLaunchKernelGGL((k_level_route<B, NC>), g, blk, 0, s, d_rec.p, d_node_a.p, (const uint8_t*)(INBAG), d_plan.p, d_list.p, d_lcnt.p, lc)
-        if (use_bagging) { if (nchunk == 1) RGBM_LAUNCH_ROUTE(true, 1, d_inbag.p); else if (nchunk == 2) RGBM_LAUNCH_ROUTE(true, 2, d_inbag.p); else RGBM_LAUNCH_ROUTE(true, 0, d_inbag.p); }
-        else { if (nchunk == 1) RGBM_LAUNCH_ROUTE(false, 1, nullptr); else if (nchunk == 2) RGBM_LAUNCH_ROUTE(false, 2, nullptr); else RGBM_LAUNCH_ROUTE(false, 0, nullptr); }
-#undef RGBM_LAUNCH_ROUTE
+        if (nchunk == 1) hipLaunchKernelGGL((k_level_route<1>), g, blk, 0, s, d_rec.p, d_node_a.p, d_plan.p, lc);
+        else if (nchunk == 2) hipLaunchKernelGGL((k_level_route<2>), g, blk, 0, s, d_rec.p, d_node_a.p, d_plan.p, lc);
+        else hipLaunchKernelGGL((k_level_route<0>), g, blk, 0, s, d_rec.p, d_node_a.p, d_plan.p, lc);
         if (stats) { HIPCHK(hipEventRecord(b, s)); route_ev.emplace_back(a, b); }
     };
     auto launch_pass = [&](bool root, int with_hist, int gz) {
@@ -671,17 +667,23 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const bool timed = stats && with_hist;
         if (split_mode && !root) launch_route();
         if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
-#define RGBM_LAUNCH_PASS(R, B, M, INBAG)                                                                                                        \
-        hipLaunchKernelGGL((k_level_pass<R, B, M>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, node_b_p, \
+#define RGBM_LAUNCH_PASS2(R, B, M, S, INBAG)                                                                                                    \
+        hipLaunchKernelGGL((k_level_pass<R, B, M, S>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, node_b_p, \
                            (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc)
+#define RGBM_LAUNCH_PASS(R, B, M, INBAG) RGBM_LAUNCH_PASS2(R, B, M, false, INBAG)
         // chunk layout: 0 = one 16-feature chunk, 2 = exactly two (both records prefetched), 3 = more
         if (root) { RGBM_LAUNCH_PASS(true, false, 0, nullptr); }
-        else if (split_mode)
-            hipLaunchKernelGGL((k_level_pass<false, false, 0, true>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, node_b_p,
-                               (const uint8_t*)nullptr, d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc, d_list.p, d_lcnt.p);
+        else if (split_mode) {
+            if (use_bagging) RGBM_LAUNCH_PASS2(false, true, 0, true, d_inbag.p); else RGBM_LAUNCH_PASS2(false, false, 0, true, nullptr);
+            if (const char* e = getenv("RGBM_DBG_STREAM")) {   // timing experiment: throw-away launches of the stream pass without batches (1) / without ring appends (2)
+                for (int mode = 1; mode <= atoi(e); ++mode) { lc.pad0 = mode; RGBM_LAUNCH_PASS2(false, false, 0, true, nullptr); }
+                lc.pad0 = 0;
+            }
+        }
         else if (use_bagging) { if (nchunk == 1) RGBM_LAUNCH_PASS(false, true, 0, d_inbag.p); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, true, 2, d_inbag.p); else RGBM_LAUNCH_PASS(false, true, 3, d_inbag.p); }
         else { if (nchunk == 1) RGBM_LAUNCH_PASS(false, false, 0, nullptr); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, false, 2, nullptr); else RGBM_LAUNCH_PASS(false, false, 3, nullptr); }
 #undef RGBM_LAUNCH_PASS
+#undef RGBM_LAUNCH_PASS2
         if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
 
@@ -710,14 +712,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                                    d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             for (int level = 1; level < p.max_depth; ++level) {
-                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc, split_mode ? d_lcnt.p : (unsigned int*)nullptr);
+                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
                 launch_pass(false, 1, nchunk * lv_groups[level]);
                 auto ex = exchange(false, 1 << (level - 1));
                 hipLaunchKernelGGL(k_level_split<false>, dim3((F + 1) / 2, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
                                    cntg, d_count.p, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
-            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc, (unsigned int*)nullptr);
+            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
             if (lazy_score) hipLaunchKernelGGL(k_level_final<false>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, node_b_p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
@@ -845,8 +847,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const int64_t rows_acc = dp ? (int64_t)(h_statrows / (unsigned long long)g_comm.nranks) : (int64_t)h_statrows;
             if (dp) root_rows /= g_comm.nranks;
             stats->hist_rows = rows_acc; stats->root_rows = root_rows;
-            // algorithmic bytes: F bin bytes + 8 B (g,h) per accumulated row, + 4 B where the row is reached through an index list
-            stats->hist_bytes = rows_acc * ((int64_t)F + 8) + (split_mode ? (rows_acc - root_rows) * 4 : 0);
+            // algorithmic bytes: F bin bytes + 8 B (g,h) per accumulated row
+            stats->hist_bytes = rows_acc * ((int64_t)F + 8);
             for (auto& ev : route_ev) {
                 float m2 = 0.f; HIPCHK(hipEventElapsedTime(&m2, ev.first, ev.second));
                 stats->route_ms += m2; stats->route_launches += 1;

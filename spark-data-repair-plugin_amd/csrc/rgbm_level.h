@@ -51,10 +51,9 @@ constexpr int LV_LDS_BYTES = (LV_LDS_TOTAL / LV_BLOCKS_PER_CU) & ~1023;
 constexpr int LV_CARRY_SHIFT = 11;
 constexpr int LV_MAX_DEPTH = 7;
 constexpr int LV_MAX_LEAVES = 128;
-// split mode (k_level_route + k_level_pass<LIST>): built-row lists
-constexpr int LV_LIST_SHARDS = 8;                       // per class tree: one append counter + region per (wave tile mod 8)
-constexpr int LV_ROW_BITS = 27;                         // list entry = row | built slot << 27  (N < 2^27 rows)
-constexpr uint32_t LV_ROW_MASK = (1u << LV_ROW_BITS) - 1u;
+// split mode (k_level_route + k_level_pass<STREAM>)
+constexpr int LV_SRING = 192;                           // entries of a wave's built-row ring (k_level_pass<STREAM>): <= 64 pending + 128 appended per tile
+constexpr int LV_SRING_BYTES = (LV_THREADS / 64) * LV_SRING * 12;   // entry = g, h, row (4 B each)
 constexpr int RT_KS = 32;                               // class trees per route workgroup (LDS route tables: 512 B each)
 constexpr int RT_THREADS = 256;
 constexpr int RT_WT_ROWS = 256;                         // rows of one wave tile: 4 consecutive rows per lane
@@ -94,10 +93,9 @@ struct LvLayout {   // per (class tree, chunk): packed-slot layout of the coming
 struct LevelConst {
     int32_t gx, max_built, nchunk, K, F, totbins, num_leaves, max_depth, min_data_in_leaf, lds_bytes;
     int32_t drain_shift, pad0;   // testing: the per-lane drain budgets are shifted right by this much (0 in production), which forces drains on small inputs
-    int32_t split_mode;          // 1: route + list-accumulate kernels (k_level_route / k_level_pass<LIST>); sibling counts are parent - built
+    int32_t split_mode;          // 1: route + stream-accumulate kernels (k_level_route / k_level_pass<STREAM>); sibling counts are parent - built
     int32_t sib_local;           // split mode: k_level_split also writes the derived sibling count into the LOCAL count array (row-sharded: rank 0 only)
     long long N, NS;   // rows; row stride of the node-id arrays (multiple of 16)
-    long long list_cap;          // split mode: entries per (class tree, shard) region of the built-row lists
 };
 
 __device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
@@ -129,7 +127,7 @@ __host__ __device__ inline long long lv_layout_bytes(const FeatMeta* fm, const C
 __host__ __device__ inline long long lv_fixed_bytes(const ChunkMeta& cm, int n_exp, const FeatMeta* fm) {
     // route tables + child counters + (wide->slot, wide->hoff) tables + alignment slack (the slot->wide map is charged to the layout: lv_layout_bytes)
     (void)fm;
-    return 2048 + 16 + LV_LIST_BYTES + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + 64;
+    return 2048 + 16 + LV_LIST_BYTES + LV_SRING_BYTES + 256 + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + 64;
 }
 
 // Packed-slot layout of one chunk for `nodes` built nodes inside `avail` bytes: the largest uniform replication 2^s (s <= 5,
@@ -179,27 +177,28 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
 // Algorithmic bytes per accumulated row: F bin bytes + 8 B (g,h); the pass also streams the node
 // ids (1 B in, 1 B out) and the records of rows it only routes.
 // ------------------------------------------------------------------------------------------------
-//   LIST (split mode): no routing at all -- the rows that feed a histogram were listed by k_level_route
-//         (entry = row | built slot << 27); every lane of every wave holds a built row, so the packed atomics
-//         run on full waves only.  The workgroup takes an equal slice of each of the class tree's list shards,
-//         gathers record + (g,h) of the listed rows and counts the rows per built child (the sibling's count
-//         is parent - built, k_level_split).
-template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */, bool LIST = false>
+//   STREAM (split mode): no routing -- k_level_route has already moved every row to its child.  The pass streams the node
+//         ids (1 B) and (g,h) (8 B) of every row, fully coalesced, and looks the node id up in an LDS table: rows that sit
+//         in a BUILT child are appended to the wave's LDS ring (g, h, row); whenever 64 of them are waiting, their records
+//         are re-read (L2: the 64 class trees walk the rows in lock step) and the packed atomics run on a FULL wave.  A wave
+//         instruction of LDS atomics costs the same for 6 active lanes as for 64 (profiles/r01_lds_atomic_active_lanes.txt),
+//         and a built child holds ~12 % of the rows: the fused pass pays that instruction for every 64-row step, this one
+//         for every 64 built rows.  Rows per built child are counted here; the sibling is parent - built (k_level_split).
+template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */, bool STREAM = false>
 __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
                                                            uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
                                                            const LvLayout* __restrict__ layout, HistBin* __restrict__ part,
                                                            int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta,
-                                                           const ChunkMeta* __restrict__ cmeta, int with_hist, LevelConst c,
-                                                           const uint32_t* __restrict__ list = nullptr, const unsigned int* __restrict__ lcnt = nullptr) {
+                                                           const ChunkMeta* __restrict__ cmeta, int with_hist, LevelConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int k = blockIdx.y, ch = blockIdx.z % c.nchunk, grp = blockIdx.z / c.nchunk;
     const LvPlan* pp = &plan[k];
     if (pp->done) return;
-    const int n_exp = (ROOT || LIST) ? 0 : pp->n_exp;
+    const int n_exp = (ROOT || STREAM) ? 0 : pp->n_exp;
     const int n_built = with_hist ? pp->n_built : 0;
     const int npg = pp->npg;
-    const bool writer = !ROOT && !LIST && ch == 0 && grp == 0;
+    const bool writer = !ROOT && !STREAM && ch == 0 && grp == 0;
     const int g0 = grp * npg;
     int ng = n_built - g0; if (ng > npg) ng = npg; if (ng < 0) ng = 0;
     if (grp >= pp->n_groups && !writer) return;
@@ -215,8 +214,10 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
     uint2* route = reinterpret_cast<uint2*>(smem);                                      // [256] (w0, w1) of LvPlan::route0/1
     int32_t* drain_flag = reinterpret_cast<int32_t*>(route + 256);                      // [4] (16 B), relaxed atomic accesses
     uint32_t* lst = reinterpret_cast<uint32_t*>(route + 256) + 4 + (tid >> 6) * LV_LIST;   // this wave's ring (LV_RING)
-    int32_t* cnt = reinterpret_cast<int32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4;
-    const int ncnt = LIST ? ng * LV_CNT_REP : 2 * n_exp * LV_CNT_REP;   // LIST: rows per built child of this group
+    uint32_t* sring = reinterpret_cast<uint32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4 + (tid >> 6) * (LV_SRING * 3);   // STREAM: [3][LV_SRING] g | h | row
+    uint8_t* bslot = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4 + LV_SRING_BYTES / 4);   // STREAM: node id -> group-local built slot
+    int32_t* cnt = reinterpret_cast<int32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4 + LV_SRING_BYTES / 4 + 64;
+    const int ncnt = STREAM ? ng * LV_CNT_REP : 2 * n_exp * LV_CNT_REP;   // STREAM: rows per built child of this group
     int32_t* wide_g = cnt + ncnt;
     uint32_t* wide_h = reinterpret_cast<uint32_t*>(wide_g + (size_t)ng * wb);
     uint32_t* w_slot = wide_h + (size_t)ng * wb;          // [wb] first packed slot of the bin | sh << 24
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
     off = (off + 15) & ~(size_t)15;
     unsigned long long* fast = reinterpret_cast<unsigned long long*>(smem + off);
 
-    if (!ROOT && !LIST) for (int i = tid; i < 256; i += LV_THREADS) {
+    if (!ROOT && !STREAM) for (int i = tid; i < 256; i += LV_THREADS) {
         // LDS copy of the route table, specialised for this block: built slots become group-local (0xFF = the child's
         // histogram is not this block's business) and an unexpanded node routes to itself, so the row loop needs no selects
         const uint32_t w0 = pp->route0[i]; uint32_t w1 = pp->route1[i];
@@ -239,6 +240,17 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
         route[i] = make_uint2(w0, w1);
     }
     if (tid < 4) drain_flag[tid] = 0;
+    if (STREAM) {   // k_level_plan numbers the children of expanded parent ei as child_first + 2 ei (left), + 1 (right); one of them is built
+        for (int i = tid; i < 256; i += LV_THREADS) {
+            const int d = i - pp->child_first;
+            uint8_t v = 0xFF;
+            if (d >= 0 && d < 2 * n_built) {
+                const int ei = d >> 1;
+                if ((pp->built_is_left[ei] ? 0 : 1) == (d & 1) && ei >= g0 && ei - g0 < ng) v = (uint8_t)(ei - g0);
+            }
+            bslot[i] = v;
+        }
+    }
 #define LV_FLAG_LOAD() __hip_atomic_load(drain_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LV_FLAG_STORE(v) __hip_atomic_store(drain_flag, (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
     for (int i = tid; i < ncnt; i += LV_THREADS) cnt[i] = 0;
@@ -357,67 +369,74 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             const unsigned o = (unsigned)(s * LV_THREADS + tid);
             const unsigned oc = o < lim ? o : lim;
             const int nv = nb_[oc];
-            fr[s] = rb_[oc];
-            if (!ROOT && MULTI == 2) fr2[s] = (rec_other + pb)[oc]; else fr2[s] = make_uint4(0, 0, 0, 0);
-            if (ROOT || !LV_RING) fg[s] = gb_[oc]; else fg[s] = make_int2(0, 0);
+            if (!STREAM) fr[s] = rb_[oc]; else fr[s] = make_uint4(0, 0, 0, 0);
+            if (!ROOT && !STREAM && MULTI == 2) fr2[s] = (rec_other + pb)[oc]; else fr2[s] = make_uint4(0, 0, 0, 0);
+            if (ROOT || STREAM || !LV_RING) fg[s] = gb_[oc]; else fg[s] = make_int2(0, 0);
             fib[s] = BAG ? (int)ib_[oc] : 1;
             fn[s] = (tv && o <= lim) ? nv : LV_INACTIVE;
         }
     };
-    if (LIST) {
-        // ---- split mode: this workgroup's equal slice of every list shard of class tree k.  Two-deep software pipeline:
-        // the entries of tile t+2 and the gathered (record, g, h) of tile t+1 are in flight while tile t runs its atomics.
-        // All loads are issued unconditionally on clamped indices (straight-line code keeps the vmcnt bookkeeping exact).
-        const uint32_t* lk = list + (long long)k * LV_LIST_SHARDS * c.list_cap;
-        for (int shd = 0; shd < LV_LIST_SHARDS; ++shd) {
-            const unsigned cnt_s = lcnt[k * LV_LIST_SHARDS + shd];
-            const unsigned lo = (unsigned)((unsigned long long)cnt_s * blockIdx.x / gridDim.x);
-            const unsigned hi = (unsigned)((unsigned long long)cnt_s * (blockIdx.x + 1) / gridDim.x);
-            if (hi <= lo) continue;                                     // uniform
-            const uint32_t* ls = lk + (long long)shd * c.list_cap;
-            const unsigned ntl = (hi - lo + LV_TILE - 1) / LV_TILE;
-            uint32_t ea[RPT], eb[RPT]; bool va[RPT], vb[RPT];
-            auto load_ent = [&](unsigned t, uint32_t (&e)[RPT], bool (&v)[RPT]) __attribute__((always_inline)) {
+    if (STREAM) {
+        // ---- split mode: coalesced stream over (node id, g, h) of every row; built rows go through the wave's LDS ring.
+        // Ring invariant: at most 64 entries wait when a tile starts (<= 128 are appended per tile, LV_SRING = 192).  Whenever
+        // >= 64 wait after a tile, one batch is taken out (its record gather is issued at once and consumed at the START of
+        // the next tile, so an L2 round trip hides behind that tile's loads); more than 128 waiting (a tile of built rows
+        // only: clustered data) are worked off on the spot.
+        uint32_t* ring_g = sring; uint32_t* ring_h = sring + LV_SRING; uint32_t* ring_r = sring + 2 * LV_SRING;
+        int r_head = 0, r_cnt = 0;                       // wave-uniform
+        bool pend = false; uint4 p_rec = make_uint4(0, 0, 0, 0); int2 p_gh = make_int2(0, 0); int p_li = 0;
+        const unsigned long long lane_lt = (1ull << lane) - 1ull;
+        auto take_batch = [&](int nb) __attribute__((always_inline)) {     // nb = min(r_cnt, 64) entries -> p_*, gather issued
+            const bool on = lane < nb;
+            int pos = r_head + lane; if (pos >= LV_SRING) pos -= LV_SRING;
+            const uint32_t row = ring_r[pos], hw = ring_h[pos];             // h < 2^21 (HQ_MAX): the built slot rides in bits 24..31
+            p_gh = make_int2((int)ring_g[pos], (int)(hw & 0xFFFFFFu));
+            p_rec = recc[on ? row : 0u];
+            p_li = on ? (int)(hw >> 24) : -1;
+            r_head += nb; if (r_head >= LV_SRING) r_head -= LV_SRING;
+            r_cnt -= nb; pend = true;
+        };
+        auto run_batch = [&]() __attribute__((always_inline)) {
+            if (ch == 0 && p_li >= 0) atomicAdd(&cnt[p_li * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+            accumulate(p_li >= 0, p_li < 0 ? 0 : p_li, p_rec, p_gh);
+            pend = false;
+        };
+        // the loads of TWO tiles are in flight while a tile is processed (three register sets take turns): with one workgroup
+        // per CU, 9 B per row and ~1.5 us of HBM latency, one tile ahead kept only ~18 KB per CU in flight = 3.7 TB/s
+        auto stream_step = [&](long long t, int (&Cn)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT], int (&Xn)[RPT], uint4 (&Xr)[RPT], uint4 (&Xr2)[RPT], int2 (&Xg)[RPT], int (&Xib)[RPT]) __attribute__((always_inline)) {
+            const long long p0 = t * LV_TILE;
+            if (LV_FLAG_LOAD()) rendezvous();
+            fetch(t + 2 * (long long)gridDim.x, Xn, Xr, Xr2, Xg, Xib);
+            if (pend) run_batch();
 #pragma unroll
-                for (int s = 0; s < RPT; ++s) {
-                    const unsigned long long i = (unsigned long long)lo + (unsigned long long)t * LV_TILE + (unsigned)(s * LV_THREADS + tid);
-                    v[s] = i < hi;
-                    e[s] = ls[v[s] ? i : (unsigned long long)(hi - 1)];
+            for (int s = 0; s < RPT; ++s) {
+                const unsigned o = (unsigned)(s * LV_THREADS + tid);
+                const int n = Cn[s];
+                const uint32_t bs = bslot[n];                                  // inactive rows carry id 255, which never names a child
+                const bool built = bs != 0xFFu && (!BAG || Cib[s] != 0) && c.pad0 != 2;   // (pad0 == 2: timing experiment, nothing is appended)
+                const unsigned long long m = __ballot(built);
+                if (built) {
+                    int pos = r_head + r_cnt + (int)__popcll(m & lane_lt); if (pos >= LV_SRING) pos -= LV_SRING; if (pos >= LV_SRING) pos -= LV_SRING;
+                    ring_g[pos] = (uint32_t)Cg[s].x; ring_h[pos] = (uint32_t)Cg[s].y | (bs << 24); ring_r[pos] = (uint32_t)(p0 + o);
                 }
-            };
-            auto gather = [&](const uint32_t (&e)[RPT], const bool (&v)[RPT], int (&fn)[RPT], uint4 (&fr)[RPT], int2 (&fg)[RPT]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int s = 0; s < RPT; ++s) {
-                    const uint32_t row = e[s] & LV_ROW_MASK;
-                    fr[s] = recc[row]; fg[s] = ghk[row];
-                    const int li = (int)(e[s] >> LV_ROW_BITS) - g0;             // group-local built slot
-                    fn[s] = (v[s] && li >= 0 && li < ng) ? li : -1;
-                }
-            };
-            auto process = [&](const int (&fn)[RPT], const uint4 (&fr)[RPT], const int2 (&fg)[RPT]) __attribute__((always_inline)) {
-                if (LV_FLAG_LOAD()) rendezvous();
-#pragma unroll
-                for (int s = 0; s < RPT; ++s) {
-                    const int li = fn[s];
-                    if (ch == 0 && li >= 0) atomicAdd(&cnt[li * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                    accumulate(li >= 0, li < 0 ? 0 : li, fr[s], fg[s]);
-                }
-            };
-            load_ent(0, ea, va);
-            gather(ea, va, cur_n, cur_r, cur_g);
-            load_ent(1 < ntl ? 1 : 0, eb, vb);
-            unsigned t = 0;
-            while (true) {
-                gather(eb, vb, nxt_n, nxt_r, nxt_g);                     // tile t+1 (a clamped replay of a valid tile past the end)
-                load_ent(t + 2 < ntl ? t + 2 : ntl - 1, ea, va);
-                process(cur_n, cur_r, cur_g);
-                if (++t >= ntl) break;
-                gather(ea, va, cur_n, cur_r, cur_g);
-                load_ent(t + 2 < ntl ? t + 2 : ntl - 1, eb, vb);
-                process(nxt_n, nxt_r, nxt_g);
-                if (++t >= ntl) break;
+                r_cnt += (int)__popcll(m);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // ring entries are read by other lanes of this wave
+            if (c.pad0 != 0) { r_cnt = 0; r_head = 0; }                  // timing experiment (RGBM_DBG_STREAM): the stream + ring without the batches
+            while (r_cnt > 128) { take_batch(64); run_batch(); }
+            if (r_cnt >= 64) take_batch(64);
+        };
+        int thd_n[RPT], thd_ib[RPT]; uint4 thd_r[RPT], thd_r2[RPT]; int2 thd_g[RPT];
+        long long t = blockIdx.x;
+        fetch(t, cur_n, cur_r, cur_r2, cur_g, cur_ib);
+        fetch(t + gridDim.x, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib);
+        while (t < ntiles) {
+            stream_step(t, cur_n, cur_g, cur_ib, thd_n, thd_r, thd_r2, thd_g, thd_ib); t += gridDim.x; if (t >= ntiles) break;
+            stream_step(t, nxt_n, nxt_g, nxt_ib, cur_n, cur_r, cur_r2, cur_g, cur_ib); t += gridDim.x; if (t >= ntiles) break;
+            stream_step(t, thd_n, thd_g, thd_ib, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib); t += gridDim.x;
         }
+        if (pend) run_batch();
+        while (r_cnt > 0) { take_batch(r_cnt < 64 ? r_cnt : 64); run_batch(); }
     } else if (ROOT || !LV_RING) {
         // one tile: prefetch the tile after it into the other register set, then process this one (the two sets swap
         // roles from call to call, so nothing is copied)
@@ -557,6 +576,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
     }
     // epilogue rendezvous: leave only when every wave has finished its rows and no drain is pending
     if (ng > 0) { while (rendezvous()) {} } else __syncthreads();
+    if (STREAM && c.pad0 != 0) return;   // timing experiment: results are discarded
     // ---- flush this workgroup's partial histograms (plain stores: no global atomics, no zeroing)
     for (int li = 0; li < ng; ++li) {
         HistBin* dst = part + (((long long)k * c.gx + blockIdx.x) * c.max_built + (g0 + li)) * c.totbins;
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             if (tot) atomicAdd(&count[(long long)k * 256 + child_first + ci], tot);
         }
     }
-    if (LIST && ch == 0) {   // exact row counts of the built children of this group (k_level_plan numbers the children of parent ei as child_first + 2 ei, + 1)
+    if (STREAM && ch == 0) {   // exact row counts of the built children of this group (k_level_plan numbers the children of parent ei as child_first + 2 ei, + 1)
         for (int ci = tid; ci < ng; ci += LV_THREADS) {
             int tot = 0;
             for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
@@ -596,22 +616,18 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
 // k_level_route (split mode): DataPartition::Split of a whole level for ALL class trees of a row tile.
 // A lane owns 4 consecutive rows: their bin records are loaded ONCE and stay in registers while the
 // lane walks the class trees of its slice -- per class tree it reads one dword of node ids, looks the
-// (at most 64) nodes of the level up in an LDS route table, moves the rows to their children in place
-// (only changed dwords are stored) and appends the rows that fell into a BUILT child to that class
-// tree's list (entry = row | built slot << 27).  No (g,h), no histogram, no counting: the pass costs
-// 1 B per (row, class tree) of HBM traffic instead of 10 B, and k_level_pass<LIST> afterwards runs the
-// packed LDS atomics on full waves of listed rows only.
-// List appends: one returning global atomic per (wave tile, class tree) on one of LV_LIST_SHARDS counters
-// (shard = wave tile mod 8, so a shard region never receives more than ceil(tiles / 8) * 256 entries);
-// the entries of class tree kk are stored while class tree kk+1 is being routed, which hides the atomic's
-// round trip.  Entry order inside a list depends on timing; every sum downstream is an exact integer, so
-// the model does not.
+// (at most 64) nodes of the level up in an LDS route table and moves the rows to their children in place
+// (only changed dwords are stored).  No (g,h), no histogram, no counting: 1-2 B per (row, class tree) of
+// HBM traffic, ~40 VALU instructions per 64 (row, class tree) pairs (the fused pass spends ~100 on the
+// same routing).  k_level_pass<STREAM> then builds the histograms of the built children.
+// (A first cut also appended the built rows to per-class-tree lists here, for a gather-based accumulate:
+// the returning global atomic per (wave tile, class tree) cost 1.9 of its 2.4 ms and the gathers moved as
+// many HBM bytes as a full stream -- profiles/r02b_split_first_cut_profile.txt.)
 // grid (persistent, ceil(K / RT_KS)), block RT_THREADS.
 // ------------------------------------------------------------------------------------------------
-template <bool BAG, int NCH /* 1, 2: the row's one / two 16-byte records live in registers; 0: any number of chunks, the split byte is gathered */>
+template <int NCH /* 1, 2: the row's one / two 16-byte records live in registers; 0: any number of chunks, the split byte is gathered */>
 __global__ __launch_bounds__(RT_THREADS) void k_level_route(const uint4* __restrict__ rec, uint8_t* __restrict__ node /* [K][NS], updated in place */,
-                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
-                                                            uint32_t* __restrict__ list, unsigned int* __restrict__ lcnt, LevelConst c) {
+                                                            const LvPlan* __restrict__ plan, LevelConst c) {
     __shared__ uint2 rt[RT_KS][64];
     __shared__ int s_base[RT_KS], s_live[RT_KS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -632,7 +648,6 @@ __global__ __launch_bounds__(RT_THREADS) void k_level_route(const uint4* __restr
     const long long N = c.N, NS = c.NS;
     const long long nwt = (N + RT_WT_ROWS - 1) / RT_WT_ROWS;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     for (long long wt = (long long)blockIdx.x * (RT_THREADS / 64) + wave; wt < nwt; wt += (long long)gridDim.x * (RT_THREADS / 64)) {
         const long long row0 = wt * RT_WT_ROWS + lane * 4;
         const bool lane_on = row0 < N;
@@ -643,28 +658,11 @@ __global__ __launch_bounds__(RT_THREADS) void k_level_route(const uint4* __restr
             if (NCH >= 1) r[j] = rec[rr]; else r[j] = make_uint4(0, 0, 0, 0);
             if (NCH == 2) r2[j] = rec[N + rr]; else r2[j] = make_uint4(0, 0, 0, 0);
         }
-        uint32_t ib4 = 0x01010101u;
-        if (BAG) { ib4 = 0u; if (lane_on) ib4 = *reinterpret_cast<const uint32_t*>(inbag + row0); }
         // rows past the end of the table never take part (their node bytes are uninitialised)
         uint32_t rowmask = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (row0 + j < N) rowmask |= 0xFFu << (8 * j);
-        ib4 &= rowmask;
-        const unsigned shard = (unsigned)(wt & (LV_LIST_SHARDS - 1));
-        // appends of the previous class tree, still waiting for their list position
-        bool p_any = false; unsigned p_base = 0u; uint32_t p_ent[4] = {0, 0, 0, 0}; unsigned long long p_m[4] = {0, 0, 0, 0}; uint32_t* p_lst = nullptr;
-        auto flush = [&]() __attribute__((always_inline)) {
-            if (p_any) {
-                unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)p_base);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if ((p_m[j] >> lane) & 1ull) p_lst[off + (unsigned)__popcll(p_m[j] & lane_lt)] = p_ent[j];
-                    off += (unsigned)__popcll(p_m[j]);
-                }
-            }
-        };
-        // node ids of the NEXT class tree are requested before this class tree's store / list atomic are issued: vmcnt retires in
-        // order, so waiting for them never waits for the atomic behind them
+        // node ids of the NEXT class tree are requested before this class tree's store is issued
         uint32_t n4_next = 0xFFFFFFFFu;
         if (lane_on) n4_next = *reinterpret_cast<const uint32_t*>(node + (long long)k0 * NS + row0);
         for (int kk = 0; kk < nk; ++kk) {
@@ -681,7 +679,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_level_route(const uint4* __restr
                 any_in |= in[j];
             }
             if (__ballot(any_in) == 0ull) continue;                      // no row of this wave tile sits in a node of the level
-            uint32_t out4 = n4; uint32_t ent[4]; bool built[4];
+            uint32_t out4 = n4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint2 e = rt[kk][idx[j] & 63u];
@@ -699,29 +697,11 @@ __global__ __launch_bounds__(RT_THREADS) void k_level_route(const uint4* __restr
                     bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
                 }
                 const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
-                const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, built slot in bits 16..23 (0xFF: not built)
-                const unsigned li = (sel >> 16) & 0xFFu;
+                const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7
                 if (expd) out4 = (out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j));
-                built[j] = expd && li != 0xFFu && ((ib4 >> (8 * j)) & 0xFFu) != 0u;
-                ent[j] = (uint32_t)(row0 + j) | (li << LV_ROW_BITS);
             }
             if (out4 != n4) *np = out4;
-            unsigned long long m[4]; unsigned total = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { m[j] = __ballot(built[j]); total += (unsigned)__popcll(m[j]); }
-            unsigned my_base = 0u;
-            unsigned int* cp = lcnt + (long long)(k0 + kk) * LV_LIST_SHARDS + shard;
-#ifdef RT_DBG_NO_APPEND
-            total = 0u;
-#endif
-            if (total != 0u && lane == 0) my_base = atomicAdd(cp, total);
-            flush();                                                     // the previous class tree's entries: its atomic has long returned
-            p_any = total != 0u; p_base = my_base;
-            p_lst = list + ((long long)(k0 + kk) * LV_LIST_SHARDS + shard) * c.list_cap;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { p_ent[j] = ent[j]; p_m[j] = m[j]; }
         }
-        flush();
     }
 }
 
@@ -831,7 +811,7 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
     for (int j = 0; j < 4; ++j) { const int b = lane * 4 + j; if (b < fm.nbins) { HistBin v; v.g = ag[j]; v.h = ah[j]; hm[b] = v; } }
     int nl = count[(long long)k * 256 + l], nr = count[(long long)k * 256 + r];
     if (lc.split_mode) {
-        // only the built child was counted (k_level_pass<LIST>); its sibling holds the rest of the parent's rows.  The derived
+        // only the built child was counted (k_level_pass<STREAM>); its sibling holds the rest of the parent's rows.  The derived
         // count is published for the leaf counts; row-sharded training sums the LOCAL arrays, so exactly one rank also
         // stores it there (lc.sib_local).
         const int nb = bl ? nl : nr, ns = P.count - nb;
@@ -860,12 +840,10 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, const LvLayout* __restrict__ lay_table, SNode* __restrict__ nodes,
                                                     const Cand* __restrict__ cand, const FeatMeta* __restrict__ fmeta,
-                                                    const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc,
-                                                    unsigned int* __restrict__ lcnt /* split mode: list append counters [K][LV_LIST_SHARDS], reset here; else null */) {
+                                                    const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc) {
     __shared__ double pm[256];
     const int k = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
     LvPlan* pp = &plan[k];
-    if (lcnt && threadIdx.x < LV_LIST_SHARDS) lcnt[k * LV_LIST_SHARDS + threadIdx.x] = 0u;
     if (pp->done) return;
     SNode* nk = nodes + (long long)k * 256;
     const Cand* ck = cand + (long long)k * 256 * c.F;

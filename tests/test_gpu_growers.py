@@ -232,7 +232,7 @@ class _env:
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("shift,lds", [(5, None), (9, None), (14, None), (9, 40000)])
+@pytest.mark.parametrize("shift,lds", [(5, None), (9, None), (14, None), (9, 80000)])
 def test_forced_packed_slot_drains_stay_bit_exact(shift, lds):
     """The 32+32-bit packed LDS slots are drained into carry words when a lane's |g| / h budget runs out; at test sizes
     that never happens by itself.  RGBM_LV_DRAIN_SHIFT shrinks the budgets (here down to a drain per row step), so the
@@ -256,9 +256,10 @@ def test_forced_packed_slot_drains_stay_bit_exact(shift, lds):
                   dict(objective=2, num_class=2, n_estimators=4, learning_rate=0.2), None, vals))
     for X, nc, y, K, kw, cw, yv in cases:
         mo = O.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
-        with _env(**env):
-            mg = N.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
-        assert mo.save() == mg.save(), "objective %d differs with forced drains" % kw["objective"]
+        for split in (0, 1):                                       # the fused level pass, and the route + stream passes
+            with _env(RGBM_LEVEL_SPLIT=split, **env):
+                mg = N.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
+            assert mo.save() == mg.save(), "objective %d differs with forced drains (split=%d)" % (kw["objective"], split)
 
 
 @pytest.mark.parametrize("tgt", [0, 3])
