@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--no-full-job", action="store_true", help="do not run the 300-iteration job when --steps differs from 300")
     ap.add_argument("--mode", choices=["auto", "targets"], default="auto", help="multi-GPU split: auto = hybrid row/target sharding")
     ap.add_argument("--force-row-sharding", action="store_true", help="testing: run the collective (RCCL) path with a world of one")
+    ap.add_argument("--concurrency", type=int, default=None, help="target models trained at once per rank (default: RGBM_TARGET_CONCURRENCY or 4)")
     ap.add_argument("--train-rows", type=int, default=0,
                     help="train every model on a seeded sample of this many rows (the reference's DEFAULT behaviour is "
                          "model.max_training_row_num = 10000, model.py:755-766); 0 = all rows, which is what BASELINE's metric is quoted on")
@@ -267,7 +268,7 @@ def main():
         rdist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = run_job(eng, train_tab, fresh, cards, targets, label_counts, params, want_stats=True, row_table=row_tab,
-                      force_row_sharding=a.force_row_sharding)
+                      force_row_sharding=a.force_row_sharding, train_concurrency=a.concurrency)
         torch.cuda.synchronize(); rdist.barrier()
         return res, rdist.max_over_ranks(time.perf_counter() - t0)
 

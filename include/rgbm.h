@@ -130,6 +130,11 @@ int rgbm_repair_chain(const rgbm_model* const* models, int32_t T, const int32_t*
  * target cell is non-NULL (model.py:776), all other listed columns being the features. */
 int rgbm_table_create(const int32_t* codes_colmajor, int64_t n, int32_t c, const int32_t* n_codes,
                       int32_t device_id, rgbm_table** out);
+/* Pinned host memory for the code matrix (north_star: "pinned int32 column-major feature matrix"): a block from
+ * rgbm_host_alloc is page-locked, so rgbm_table_create copies it at PCIe DMA speed without staging.  Any other block is
+ * page-locked in place for the duration of the copy (and copied the plain way if that fails). */
+int rgbm_host_alloc(size_t bytes, void** out);
+void rgbm_host_free(void* p);
 void rgbm_table_free(rgbm_table* t);
 int rgbm_table_train(const rgbm_table* t, int32_t target_col, const int32_t* feat_cols, int32_t f,
                      const double* y_value /* regression dictionary or NULL */,
@@ -168,6 +173,10 @@ int rgbm_table_null_cells(rgbm_table* t, const int64_t* rows, const int32_t* col
                           const int32_t* target_cols, int32_t n_targets);
 /* The codes the given cells hold now (cells outside the table read as NULL): the `current_value` of the error cells. */
 int rgbm_table_read_cells(const rgbm_table* t, const int64_t* rows, const int32_t* cols, int64_t n_cells, int32_t* codes_out);
+/* Store codes into the given cells (cells outside the table are ignored).  The chained repair uses it for CONTINUOUS target
+ * attributes: the regressor's prediction (python/repair/model.py:1130-1133, rounded first for integral attributes) is written
+ * back as the code of the nearest dictionary value so that later models of the chain see the repaired cell. */
+int rgbm_table_write_cells(rgbm_table* t, const int64_t* rows, const int32_t* cols, const int32_t* codes, int64_t n_cells);
 /* New resident table made of the given rows (the dirty-row frame the chained repair runs on). */
 int rgbm_table_gather_rows(const rgbm_table* t, const int64_t* rows, int64_t n_rows, rgbm_table** out);
 /* Rows per code of one column (+ NULL count): class weights (train.py:39-40,105), domain statistics. */

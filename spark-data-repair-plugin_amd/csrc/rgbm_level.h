@@ -368,10 +368,13 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
         for (int s = 0; s < RPT; ++s) {
             const unsigned o = (unsigned)(s * LV_THREADS + tid);
             const unsigned oc = o < lim ? o : lim;
-            const int nv = nb_[oc];
+            // STREAM: node ids and (g,h) are use-once data; non-temporal loads leave more of L2 / Infinity Cache to the bin records the
+            // batches re-read (measured: -7 % HBM fetch, -2 % time; profiles/r02_stream_pass_experiments.txt)
+            const int nv = STREAM ? (int)__builtin_nontemporal_load(nb_ + oc) : (int)nb_[oc];
             if (!STREAM) fr[s] = rb_[oc]; else fr[s] = make_uint4(0, 0, 0, 0);
             if (!ROOT && !STREAM && MULTI == 2) fr2[s] = (rec_other + pb)[oc]; else fr2[s] = make_uint4(0, 0, 0, 0);
-            if (ROOT || STREAM || !LV_RING) fg[s] = gb_[oc]; else fg[s] = make_int2(0, 0);
+            if (STREAM) { const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long*>(gb_ + oc)); fg[s] = make_int2((int)(v & 0xFFFFFFFFll), (int)(v >> 32)); }
+            else if (ROOT || STREAM || !LV_RING) fg[s] = gb_[oc]; else fg[s] = make_int2(0, 0);
             fib[s] = BAG ? (int)ib_[oc] : 1;
             fn[s] = (tv && o <= lim) ? nv : LV_INACTIVE;
         }

@@ -199,6 +199,15 @@ __global__ void k_null_cells(int32_t* __restrict__ codes, long long n, int c, co
     codes[(long long)cc * n + r] = -1;
 }
 
+__global__ void k_write_cells(int32_t* __restrict__ codes, long long n, int c, const long long* __restrict__ rows,
+                              const int32_t* __restrict__ cols, const int32_t* __restrict__ vals, long long m) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const long long r = rows[i]; const int cc = cols[i];
+    if (r < 0 || r >= n || cc < 0 || cc >= c) return;
+    codes[(long long)cc * n + r] = vals[i];
+}
+
 __global__ void k_read_cells(const int32_t* __restrict__ codes, long long n, int c, const long long* __restrict__ rows,
                              const int32_t* __restrict__ cols, long long m, int32_t* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,6 +462,24 @@ RGBM_EXPORT int rgbm_table_null_cells(rgbm_table* t, const int64_t* rows, const 
                            (long long)n_cells, d_t);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));      // is_t and the caller's arrays are read by the async copies
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_table_write_cells(rgbm_table* t, const int64_t* rows, const int32_t* cols, const int32_t* codes, int64_t n_cells) {
+    if (!t || n_cells < 0 || (n_cells > 0 && (!rows || !cols || !codes))) return fail(RGBM_ERR_ARG, "rgbm_table_write_cells: bad argument");
+    return guarded([&]() {
+        use_device(t->device);
+        if (n_cells == 0) return RGBM_OK;
+        for (int64_t i = 0; i < n_cells; ++i)
+            if (cols[i] >= 0 && cols[i] < t->c && codes[i] >= t->n_codes[cols[i]]) throw std::invalid_argument("rgbm_table_write_cells: code outside the column's dictionary");
+        hipStream_t s = table_stream(*t);
+        const long long* d_rows = scr_upload<long long>(*t, 7, reinterpret_cast<const long long*>(rows), (size_t)n_cells, s);
+        const int32_t* d_cols = scr_upload<int32_t>(*t, 8, cols, (size_t)n_cells, s);
+        const int32_t* d_vals = scr_upload<int32_t>(*t, 9, codes, (size_t)n_cells, s);
+        hipLaunchKernelGGL(k_write_cells, dim3(nblocks(n_cells, 256)), dim3(256), 0, s, t->codes.p, (long long)t->n, (int)t->c, d_rows, d_cols, d_vals, (long long)n_cells);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
         return RGBM_OK;
     });
 }

@@ -85,6 +85,7 @@ def lib():
         l.rgbm_local_group_free.restype = None
         l.rgbm_table_free.restype = None
         l.rgbm_model_free.restype = None
+        l.rgbm_host_free.restype = None
         _lib = l
     return _lib
 
@@ -97,7 +98,7 @@ EXPORTED_SYMBOLS = [
     "rgbm_local_group_create", "rgbm_local_group_free", "rgbm_comm_init_local",
     "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
     "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict", "rgbm_table_shape",
-    "rgbm_table_repair_pmf", "rgbm_table_read_cells",
+    "rgbm_table_repair_pmf", "rgbm_table_read_cells", "rgbm_table_write_cells", "rgbm_host_alloc", "rgbm_host_free",
 ]
 
 COMM_ID_BYTES = 128
@@ -263,6 +264,28 @@ def repair_chain(models, target_col, feat_cols, class_codes, table, device_id=0)
     return lab, prob
 
 
+class _PinnedBlock:
+    """Owner of a page-locked host block (rgbm_host_alloc); the numpy view keeps it alive through `.base`."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(lib().rgbm_host_alloc(C.c_size_t(nbytes), C.byref(p)), "rgbm_host_alloc")
+        self.p, self.nbytes = p, nbytes
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (p.value, False), "version": 3}
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            lib().rgbm_host_free(self.p)
+            self.p = None
+
+
+def pinned_empty(shape, dtype=np.int32):
+    """Uninitialised numpy array in page-locked host memory: encoders that fill it hand rgbm_table_create a block the copy engine
+    reads directly (no pageable staging)."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    return np.asarray(_PinnedBlock(max(n, 1)))[:n].view(dtype).reshape(shape)
+
+
 class Table:
     """An int32 code table resident in HBM (``rgbm_table``)."""
 
@@ -349,6 +372,10 @@ class Table:
         out = np.zeros(len(r), np.int32)
         _check(lib().rgbm_table_read_cells(self.h, _p(r, C.c_int64), _p(c2, C.c_int32), C.c_int64(len(r)), _p(out, C.c_int32)), "rgbm_table_read_cells")
         return out
+
+    def write_cells(self, rows, cols, codes):
+        r, c2, v = np.ascontiguousarray(rows, np.int64), _i32(cols), _i32(codes)
+        _check(lib().rgbm_table_write_cells(self.h, _p(r, C.c_int64), _p(c2, C.c_int32), _p(v, C.c_int32), C.c_int64(len(r))), "rgbm_table_write_cells")
 
     def gather_rows(self, rows):
         r = np.ascontiguousarray(rows, np.int64)

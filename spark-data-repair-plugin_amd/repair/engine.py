@@ -49,33 +49,109 @@ class HipEngine:
     def load_model(self, blob):
         return _native.Model.load(blob)
 
+    def device_memory_bytes(self):
+        try:
+            import torch
+            return float(torch.cuda.get_device_properties(self.device_id).total_memory)
+        except Exception:  # noqa: BLE001
+            return 256e9
+
     def repair_chain(self, table, models, targets, feats, row_begin, n_rows):
         return table.repair_chain(models, targets, feats, row_begin=row_begin, n_rows=n_rows)
 
 
-def model_params(n_classes, base):
+def model_params(n_classes, base, continuous=False):
+    """objective pick of the reference (train.py:97-100): regression for continuous targets, else binary / multiclass."""
     p = dict(base)
-    p["objective"] = 0 if n_classes <= 2 else 1
+    p["objective"] = 2 if continuous else (0 if n_classes <= 2 else 1)
     p["num_class"] = max(int(n_classes), 2)
     return p
 
 
+def nearest_code(values, v):
+    """Code of the dictionary value nearest to v (ties to the lower one): what repair.encode gives a number it has not seen."""
+    values = np.asarray(values, np.float64)
+    v = np.asarray(v, np.float64)
+    pos = np.clip(np.searchsorted(values, v, side="left"), 0, len(values) - 1)
+    lo = np.clip(pos - 1, 0, len(values) - 1)
+    pick_lo = np.abs(v - values[lo]) <= np.abs(values[pos] - v)
+    return np.where(pick_lo, lo, pos).astype(np.int32)
+
+
+def chained_repair(engine, table, models, targets, feats_l, row_begin, n_rows, y_values, integral):
+    """`_repair` of the reference (model.py:1107-1133) on rows [row_begin, row_begin + n_rows) of a resident table.
+
+    Discrete targets are scored and filled by the device chain (`repair_chain`), run by run.  A CONTINUOUS target is one more
+    model of the same chain: its regressor scores every row, integral attributes are rounded (np.round, half to even,
+    model.py:1131-1132), and the NULL cells of the column receive the code of the nearest dictionary value so that the
+    models behind it see the repaired cell -- as the reference's later models see the predicted number.
+    Returns (labels [T][n] int32 (-1 for continuous targets), probs [T][n] float64, values [T][n] float64 (NaN for discrete))."""
+    T = len(targets)
+    labels = np.full((T, n_rows), -1, np.int32)
+    probs = np.zeros((T, n_rows), np.float64)
+    values = np.full((T, n_rows), np.nan, np.float64)
+    i = 0
+    while i < T:
+        j = i
+        if targets[i] not in y_values:
+            while j < T and targets[j] not in y_values:
+                j += 1
+            lab, prob = engine.repair_chain(table, models[i:j], targets[i:j], feats_l[i:j], row_begin, n_rows)
+            labels[i:j] = lab
+            if prob is not None:
+                probs[i:j] = prob
+        else:
+            j = i + 1
+            t = targets[i]
+            _, pred = engine.repair_chain(table, models[i:j], [t], feats_l[i:j], row_begin, n_rows)
+            v = np.asarray(pred[0], np.float64)
+            if t in integral:
+                v = np.round(v)
+            values[i] = v
+            probs[i] = 1.0
+            col = table.read_column(t)[row_begin:row_begin + n_rows]
+            nul = np.flatnonzero(col < 0)
+            if len(nul):
+                table.write_cells(nul + row_begin, np.full(len(nul), t, np.int32), nearest_code(y_values[t], v[nul]))
+        i = j
+    return labels, probs, values
+
+
+def _train_concurrency(engine, table, costs, requested):
+    """How many target models train at once: `requested` (or RGBM_TARGET_CONCURRENCY, default 4 -- a process has four hardware
+    queues), capped so that the largest `n` models together stay within half of the device memory."""
+    import os
+    n = int(requested if requested is not None else os.environ.get("RGBM_TARGET_CONCURRENCY", "4"))
+    if n <= 1 or getattr(engine, "name", "") != "hip":
+        return 1
+    budget = 0.5 * getattr(engine, "device_memory_bytes", lambda: 256e9)()
+    need = sorted((26.0 * c for _, c in costs), reverse=True)       # cost = class trees x rows
+    while n > 1 and sum(need[:n]) > budget:
+        n -= 1
+    return n
+
+
 def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, base_params, want_stats=False, row_table=None,
-            force_row_sharding=False):
+            force_row_sharding=False, train_concurrency=None, y_values=None, integral=(), train_tables=None):
     """Train + repair, sharded over the ranks of the current torch.distributed group (if any).
 
     train_table / dirty_table : engine tables (all rows with error cells NULLed / the dirty rows)
     label_counts[t]           : per-code row counts of target t over its non-NULL rows (GLOBAL counts)
     row_table                 : this rank's row shard of the training table; when given (and more than one rank),
                                 the expensive targets are trained row-sharded over ALL ranks (dist.split_targets)
-    Returns dict(labels [T][D], probs [T][D], models {target: bytes}, times, stats).
+    y_values[t]               : CONTINUOUS targets only -- the ascending distinct values behind the codes of column t: the target gets
+                                an L2 regressor (train.py:97-100) on those values; `integral` names the ones rounded after prediction
+    Returns dict(labels [T][D], probs [T][D], values [T][D] or None, models {target: bytes}, times, stats).
     """
+    y_values = dict(y_values or {})
+    integral = set(integral)
+    train_tables = dict(train_tables or {})     # {target: table}: that target trains on its own (sampled) table, model.py:755-766
     rank, ws = dist.world()
     n_cols = len(n_codes)
     costs = []
     for t in targets:
         k = int(n_codes[t])
-        costs.append((t, (1 if k <= 2 else k) * float(np.sum(label_counts[t]))))
+        costs.append((t, (1 if (k <= 2 or t in y_values) else k) * float(np.sum(label_counts[t]))))
     big, small = dist.split_targets(costs, ws, row_table is not None, force=force_row_sharding)
     mine = dist.assign_targets(small, ws)[rank]
     t0 = time.perf_counter()
@@ -84,7 +160,8 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     def one(t, table, fn):
         feats = [c for c in range(n_cols) if c != t]
         cw = balanced_class_weight(label_counts[t])
-        res = fn(table, t, feats, cw, model_params(int(n_codes[t]), base_params), want_stats=want_stats)
+        res = fn(table, t, feats, cw, model_params(int(n_codes[t]), base_params, continuous=t in y_values), y_value=y_values.get(t),
+                 want_stats=want_stats)
         if want_stats:
             res, st = res
             st["target"] = t
@@ -93,8 +170,22 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
 
     for t, _ in big:                      # collective: same order on every rank, identical model everywhere
         shared[t] = one(t, row_table, engine.train_row_sharded)
-    for t in mine:
-        blobs[t] = one(t, train_table, engine.train)
+    # This rank's own targets train CONCURRENTLY: every training call owns a HIP stream and ctypes releases the GIL.  A few-class
+    # target is a chain of small dependent kernels (plan / split-find / replay at 10-40 us around 0.1 ms passes) that leaves the
+    # GPU idle two thirds of the time; next to a many-class target those kernels fill the gaps between its passes.  Largest first
+    # (LPT), a bounded number in flight (device memory: ~26 B per row and class tree each).  The models do not depend on it.
+    conc = _train_concurrency(engine, train_table, [c for c in costs if c[0] in set(mine)], train_concurrency)
+    if conc > 1 and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        cost_of = dict(costs)
+        order = sorted(mine, key=lambda t: -cost_of[t])
+        with ThreadPoolExecutor(max_workers=conc) as pool:
+            futs = {t: pool.submit(one, t, train_tables.get(t, train_table), engine.train) for t in order}
+            for t in mine:
+                blobs[t] = futs[t].result()
+    else:
+        for t in mine:
+            blobs[t] = one(t, train_tables.get(t, train_table), engine.train)
     t_train = time.perf_counter() - t0
     # C1: all-gather of the serialised models (Spark broadcast, model.py:1069)
     t0 = time.perf_counter()
@@ -107,12 +198,17 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     D = dirty_table.n
     b, c = dist.shard_rows(D, ws, rank)
     feats_l = [[cc for cc in range(n_cols) if cc != t] for t in targets]
-    lab, prob = engine.repair_chain(dirty_table, models, targets, feats_l, b, c)
+    if y_values:
+        lab, prob, val = chained_repair(engine, dirty_table, models, targets, feats_l, b, c, y_values, integral)
+    else:
+        lab, prob = engine.repair_chain(dirty_table, models, targets, feats_l, b, c)
+        val = None
     t_infer = time.perf_counter() - t0
     # C2: all-gather of the repaired cells
     t0 = time.perf_counter()
     labels = dist.gather_rows(lab, D)
     probs = dist.gather_rows(prob, D) if prob is not None else None
+    values = dist.gather_rows(val, D) if val is not None else None
     t_gather = time.perf_counter() - t0
-    return dict(labels=labels, probs=probs, models=all_blobs, stats=stats, my_targets=mine, row_sharded_targets=[t for t, _ in big],
+    return dict(labels=labels, probs=probs, values=values, models=all_blobs, stats=stats, my_targets=mine, row_sharded_targets=[t for t, _ in big],
                 times=dict(train=t_train, exchange=t_xchg, infer=t_infer, gather=t_gather))

@@ -545,6 +545,102 @@ class RepairModel():
         repaired = error_cells_df[done].assign(repaired=rep[done])
         return error_cells_df[~done], repaired
 
+    # ------------------------------------------------------------------ resident (device) path
+    def _resident_engine(self) -> Any:
+        """The engine of the HBM-resident path, or None: no HIP device, the estimator backend was swapped (CPU tests), or
+        REPAIR_RESIDENT=0.  Tests inject one through `_engine_override`."""
+        import os
+        hook = getattr(self, "_engine_override", None)
+        if hook is not None:
+            return hook
+        if os.environ.get("REPAIR_RESIDENT", "1") == "0":
+            return None
+        from repair import _native, gbm
+        if gbm.get_backend() is not _native:
+            return None
+        try:
+            if _native.device_count() < 1:
+                return None
+            from repair.engine import HipEngine
+            return HipEngine(int(self._get_option_value(*self._opt_gpu_device_id)))
+        except Exception:  # noqa: BLE001 - any doubt: the value-space path
+            return None
+
+    def _resident_plan(self, input_df: DataFrame, target_columns: List[str], continous_columns: List[str], domain_stats: Dict[str, int],
+                       compute_repair_candidate_prob: bool, maximal_likelihood_repair: bool) -> Optional[Dict[str, Any]]:
+        """Decides whether this run can take the HBM-resident pipeline (repair.pipeline) and with which parameters.
+
+        It can when everything between error detection and the result frame is the per-attribute model loop itself:
+        no rule-based repairs, no functional-dependency rule models, no rebalancing, no cost function, plain repair output
+        (cells or repaired data), one hyper-parameter evaluation (`model.hp.max_evals=1`: the searched parameters keep their
+        LightGBM defaults, train.py:148-156), no feature selection, and every discrete target has at least two classes.
+        Otherwise the value-space path (pandas + one estimator per attribute) below handles the run."""
+        if compute_repair_candidate_prob or maximal_likelihood_repair or self.repair_by_rules or self.cf is not None:
+            return None
+        if self.training_data_rebalancing_enabled:
+            return None
+        from repair.train import (_opt_learning_rate, _opt_max_bin, _opt_max_depth, _opt_max_evals, _opt_min_split_gain,
+                                  _opt_n_estimators, _opt_reg_alpha, _opt_boosting_type, _opt_class_weight)
+        g = lambda o: get_option_value(self.opts, *o)  # noqa: E731
+        if int(g(_opt_max_evals)) != 1 or g(_opt_boosting_type) != "gbdt" or g(_opt_class_weight) != "balanced":
+            return None
+        features = len(input_df.columns) - 2
+        if int(self._get_option_value(*self._opt_max_training_column_num)) < features:
+            return None
+        if self._repair_by_functional_deps_enabled and self._get_functional_deps(target_columns):
+            return None
+        for y in target_columns:
+            if y not in continous_columns and int(domain_stats.get(y, 0)) < 2:
+                return None
+        max_depth = int(g(_opt_max_depth))
+        if not 1 <= max_depth:
+            return None
+        engine = self._resident_engine()
+        if engine is None:
+            return None
+        params = dict(n_estimators=int(g(_opt_n_estimators)), learning_rate=float(g(_opt_learning_rate)), max_depth=max_depth,
+                      max_bin=int(g(_opt_max_bin)), lambda_l1=float(g(_opt_reg_alpha)), min_gain_to_split=float(g(_opt_min_split_gain)),
+                      num_leaves=31, min_data_in_leaf=20, min_sum_hessian_in_leaf=1e-3, lambda_l2=0.0, bagging_fraction=1.0, bagging_freq=0,
+                      feature_fraction=1.0, seed=42)
+        return dict(engine=engine, params=params)
+
+    def _run_resident(self, plan: Dict[str, Any], input_df: DataFrame, error_cells_df: DataFrame, target_columns: List[str],
+                      continous_columns: List[str], repair_data: bool) -> DataFrame:
+        """Steps 2 and 3 of `_run` on the device: the table is encoded once (Arrow dictionaries -> codes, on the device), error
+        cells are NULLed, the dirty rows split off, one model per target attribute trained and the chained repair run without
+        the table leaving HBM (repair.pipeline.repair_frame); the host only shapes the (small) list of repaired cells."""
+        from repair.pipeline import repair_frame
+        rid = self._row_id
+        max_rows = int(self._get_option_value(*self._opt_max_training_row_num))
+
+        def sample(_attr: str, rows: np.ndarray) -> Optional[np.ndarray]:
+            # `_sample_training_data_from`: the same seeded sample as DataFrame.sample(n, random_state=42) on the attribute's non-NULL rows
+            if len(rows) <= max_rows:
+                return None
+            _logger.info("To reduce training data, extracts %s%% samples from %d rows" % (100.0 * max_rows / len(rows), len(rows)))
+            return rows[np.random.RandomState(42).choice(len(rows), max_rows, replace=False)]
+
+        _logger.info("[Repair Model Training Phase] Building %d models on the HBM-resident table to repair the cells in %s" % (
+            len(target_columns), to_list_str(target_columns)))
+        frame, info = repair_frame(plan["engine"], input_df, rid, targets=target_columns, base_params=plan["params"],
+                                   error_cells=error_cells_df[[rid, "attribute"]], detect_nulls=False,
+                                   continuous_columns=[c for c in continous_columns if c in target_columns], train_rows=sample,
+                                   want_details=True)
+        self._last_resident_info = info
+        rep = pd.Series(frame["repaired"].to_numpy(dtype=object),
+                        index=pd.MultiIndex.from_arrays([frame[rid].to_numpy(), frame["attribute"].to_numpy()]))
+        key = pd.MultiIndex.from_arrays([error_cells_df[rid].to_numpy(), error_cells_df["attribute"].to_numpy()])
+        values = rep.reindex(key).to_numpy(dtype=object)
+        if repair_data:
+            base = self._prepare_repair_base_cells(input_df, error_cells_df, target_columns)
+            is_dirty = base[rid].isin(set(error_cells_df[rid].tolist())).to_numpy()
+            upd = error_cells_df[[rid, "attribute"]].assign(repaired=[None if v is None or (isinstance(v, float) and np.isnan(v)) else _to_str(v) for v in values])
+            dirty = self._repair_attrs(upd, base[is_dirty].reset_index(drop=True))
+            return pd.concat([base[~is_dirty], dirty], ignore_index=True)
+        cand = error_cells_df.assign(repaired=[None if v is None or (isinstance(v, float) and np.isnan(v)) else _to_str(v) for v in values])
+        keep = cand["repaired"].isna() | ~((cand["current_value"] == cand["repaired"]) | (cand["current_value"].isna() & cand["repaired"].isna()))
+        return cand[keep.to_numpy()].reset_index(drop=True)
+
     # ------------------------------------------------------------------ pipeline
     @elapsed_time  # type: ignore
     def _run(self, input_df: DataFrame, continous_columns: List[str], detect_errors_only: bool,
@@ -562,6 +658,12 @@ class RepairModel():
         if len(target_columns) == 0:
             raise ValueError("At least one valid discretizable feature is needed to repair error cells, but no such feature found")
         error_cells_df = error_cells_df[error_cells_df["attribute"].isin(target_columns)].reset_index(drop=True)
+
+        # 2. + 3. on the HBM-resident table when the run is the plain per-attribute model loop (the hot path of this engine)
+        plan = self._resident_plan(input_df, target_columns, continous_columns, domain_stats, compute_repair_candidate_prob,
+                                   maximal_likelihood_repair)
+        if plan is not None:
+            return self._run_resident(plan, input_df, error_cells_df, target_columns, continous_columns, repair_data)
 
         # 2. Repair Model Training Phase
         repair_base_df = self._prepare_repair_base_cells(input_df, error_cells_df, target_columns)

@@ -52,12 +52,19 @@ def detect_error_cells(table, targets, constraints=(), detect_nulls=True, error_
 
 
 def repair_table(engine, table, targets, base_params, constraints=(), detect_nulls=True, error_cells=None,
-                 want_pmf=False, top_k=32, threshold=0.0, want_stats=False):
+                 want_pmf=False, top_k=32, threshold=0.0, want_stats=False, continuous=None, train_rows=None):
     """Detect, NULL out, split, train, repair, shape.  ``table`` is modified in place (error cells become NULL).
 
-    Returns dict(rows, cols, current, repaired, prob[, pmf_class, pmf_prob, current_prob], dirty_rows, models, times, stats):
-    one entry per error cell, ordered by (column, row).
+    continuous : {column: (ascending distinct values, is_integral)} -- CONTINUOUS target attributes (byte/short/int/long/float/
+                 double in the reference, RepairBase.scala:41-44): repaired by an L2 regressor on the values behind their codes
+                 (train.py:97-100), integral ones rounded (model.py:1130-1132); `repaired_value` carries the prediction.
+    train_rows : {target: row positions} or a callable (target, positions of its non-NULL rows) -> positions -- train that
+                 target's model on these rows only (model.max_training_row_num sampling, model.py:755-766); default: every row
+                 whose target cell is not NULL.
+    Returns dict(rows, cols, current, repaired, repaired_value, prob[, pmf_class, pmf_prob, current_prob], dirty_rows, models,
+    times, stats): one entry per error cell, ordered by (column, row).
     """
+    continuous = dict(continuous or {})
     t0 = time.perf_counter()
     targets = [int(t) for t in targets]
     n_codes = np.asarray(table.n_codes, np.int32)
@@ -69,19 +76,38 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
     dirty_rows = table.rows_of_cells(rows)                      # model.py:549-553
     out = dict(rows=rows, cols=cols, current=current, dirty_rows=dirty_rows, models={}, stats=[])
     if len(rows) == 0:
-        out.update(repaired=np.zeros(0, np.int32), prob=np.zeros(0, np.float64), times=dict(detect=t_detect, prepare=time.perf_counter() - t0))
+        out.update(repaired=np.zeros(0, np.int32), repaired_value=np.zeros(0, np.float64), prob=np.zeros(0, np.float64),
+                   times=dict(detect=t_detect, prepare=time.perf_counter() - t0))
         return out
     dirty_tab = table.gather_rows(dirty_rows)
     pmf_tab = table.gather_rows(dirty_rows) if want_pmf else None      # stays un-repaired: pmf mode does not chain
     label_counts = {}
     for t in targets:
         cnt, _ = table.count_codes(t)
-        if int((cnt > 0).sum()) < 2:
+        if t in continuous:
+            if int((cnt > 0).sum()) < 1:
+                raise ValueError("continuous target column %d has no non-NULL row to learn from" % t)
+        elif int((cnt > 0).sum()) < 2:
             raise ValueError("target column %d has fewer than two classes among its non-NULL rows; the reference short-cuts such "
                              "attributes with a constant model (model.py:1008-1017) -- drop it from `targets`" % t)
         label_counts[t] = cnt
     t_prep = time.perf_counter() - t0
-    res = run_job(engine, table, dirty_tab, n_codes, targets, label_counts, base_params, want_stats=want_stats)
+    y_values = {t: np.asarray(continuous[t][0], np.float64) for t in targets if t in continuous}
+    integral = {t for t in targets if t in continuous and continuous[t][1]}
+    train_tables = {}
+    if callable(train_rows):
+        picked = {}
+        for t in targets:
+            r = train_rows(t, np.flatnonzero(table.read_column(t) >= 0))
+            if r is not None:
+                picked[t] = r
+        train_rows = picked
+    if train_rows:
+        for t, r in train_rows.items():
+            train_tables[t] = table.gather_rows(np.sort(np.asarray(r, np.int64)))
+            label_counts[t] = train_tables[t].count_codes(t)[0]
+    res = run_job(engine, table, dirty_tab, n_codes, targets, label_counts, base_params, want_stats=want_stats,
+                  y_values=y_values, integral=integral, train_tables=train_tables)
     # flatten + join with the error cells (RepairMiscApi.scala:41-49, model.py:1398-1401)
     t0 = time.perf_counter()
     tpos = np.full(table.c, -1, np.int64)
@@ -89,14 +115,15 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
     pos = np.searchsorted(dirty_rows, rows)
     repaired = res["labels"][tpos[cols], pos].astype(np.int32)
     prob = res["probs"][tpos[cols], pos] if res["probs"] is not None else None
-    out.update(repaired=repaired, prob=prob, models=res["models"], stats=res["stats"])
+    repaired_value = res["values"][tpos[cols], pos] if res.get("values") is not None else np.full(len(rows), np.nan)
+    out.update(repaired=repaired, repaired_value=repaired_value, prob=prob, models=res["models"], stats=res["stats"])
     if want_pmf:
         pc = np.full((len(rows), top_k), -1, np.int32)
         pp = np.zeros((len(rows), top_k), np.float64)
         cp = np.zeros(len(rows), np.float64)
         for t in targets:
             sel = np.flatnonzero(cols == t)
-            if len(sel) == 0:
+            if len(sel) == 0 or t in continuous:       # continuous attributes have no pmf (model.py:1215-1222: the value with prob 1.0)
                 continue
             feats = [c for c in range(table.c) if c != t]
             model = engine.load_model(res["models"][t])
@@ -140,13 +167,14 @@ def encode_frame(df, columns):
 
 
 def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=None, want_pmf=False, top_k=32, threshold=0.0,
-                 error_cells=None, detect_nulls=True):
+                 error_cells=None, detect_nulls=True, continuous_columns=(), train_rows=None, want_details=False):
     """DataFrame in, the reference's result frame out: (row_id, attribute, current_value, repaired, prob[, pmf]) -- the
     shape of `RepairModel.run()` / `run(compute_repair_candidate_prob=True)` (python/repair/model.py:1398-1419).
 
-    Every column is treated as discrete (one class per distinct value); `constraints` are `X1,..,Xm -> Y` dependencies
-    given as ([x names], y name); `error_cells` is a frame with `row_id` and `attribute` columns (RepairModel.setErrorCells).
-    Continuous targets, regex / outlier detectors, rule-based repairs and cost functions stay with
+    Columns are discrete (one class per distinct value) unless named in `continuous_columns` (numeric columns; those targets
+    get regressors and `repaired` is the predicted number, rounded for integer columns); `constraints` are `X1,..,Xm -> Y`
+    dependencies given as ([x names], y name); `error_cells` is a frame with `row_id` and `attribute` columns
+    (RepairModel.setErrorCells).  Regex / outlier detectors, rule-based repairs and cost functions stay with
     `repair.model.RepairModel` (the value-space API)."""
     import pandas as pd
     cols = [c for c in df.columns if c != row_id]
@@ -166,8 +194,13 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
         cpos = np.array([pos.get(a, -1) for a in error_cells["attribute"]], np.int64)
         ok = ~np.isnan(rpos) & (cpos >= 0)                      # cells of unknown rows / attributes drop out (join semantics)
         cells = (rpos[ok].astype(np.int64), cpos[ok].astype(np.int32))
+    cont = {}
+    for c in continuous_columns:
+        if c in pos and c in targets:
+            cont[pos[c]] = (np.asarray(dicts[pos[c]], np.float64), pd.api.types.is_integer_dtype(df[c]))
     res = repair_table(engine, table, [pos[t] for t in targets], dict(base_params or {}), constraints=cons, detect_nulls=detect_nulls,
-                       error_cells=cells, want_pmf=want_pmf, top_k=top_k, threshold=threshold)
+                       error_cells=cells, want_pmf=want_pmf, top_k=top_k, threshold=threshold, continuous=cont,
+                       train_rows=(lambda t, r: train_rows(cols[t], r)) if callable(train_rows) else train_rows)
     rows, ccols = res["rows"], res["cols"]
 
     def decode(codes, col_idx):
@@ -183,8 +216,13 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
             out[sel] = v
         return out
 
+    repaired = decode(res["repaired"], ccols)
+    for j, (_, is_int) in cont.items():                       # continuous attributes: the regressor's value, not a dictionary entry
+        sel = ccols == j
+        v = res["repaired_value"][sel]
+        repaired[sel] = [int(x) for x in v] if is_int else [float(x) for x in v]
     frame = pd.DataFrame({row_id: df[row_id].to_numpy()[rows], "attribute": np.asarray(cols, object)[ccols],
-                          "current_value": decode(res["current"], ccols), "repaired": decode(res["repaired"], ccols)})
+                          "current_value": decode(res["current"], ccols), "repaired": repaired})
     if res.get("prob") is not None:
         frame["prob"] = res["prob"]
     if want_pmf and len(rows):
@@ -195,6 +233,8 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
             pmf.append([{"class": d[k], "prob": float(p)} for k, p in zip(pc[i], pp[i]) if k >= 0])
         frame["pmf"] = pmf
         frame["current_prob"] = res["current_prob"]
+    if want_details:
+        return frame, dict(times=res.get("times", {}), stats=res.get("stats", []), models=res.get("models", {}), columns=cols)
     return frame
 
 

@@ -80,6 +80,12 @@ class OracleEngine:
         def read_cells(self, rows, cols):
             return self.codes[np.asarray(cols, np.int64), np.asarray(rows, np.int64)].astype(np.int32)
 
+        def write_cells(self, rows, cols, codes):
+            self.codes[np.asarray(cols, np.int64), np.asarray(rows, np.int64)] = np.asarray(codes, np.int32)
+
+        def read_column(self, col):
+            return self.codes[col].copy()
+
         def null_cells(self, rows, cols, target_cols):
             from oracle import prep as P
             self.codes = P.null_cells(self.codes, rows, cols, target_cols)
@@ -148,6 +154,8 @@ class OracleEngine:
     def repair_chain(self, table, models, targets, feats, row_begin, n_rows):
         from oracle import oracle as O
         sub = np.ascontiguousarray(table.codes[:, row_begin:row_begin + n_rows])
-        lab, prob = O.repair_chain(models, targets, feats, [list(range(int(table.n_codes[t]))) for t in targets], sub)
+        # an empty class list marks a regression model (its column is left untouched by the chain, like the C-ABI's)
+        lab, prob = O.repair_chain(models, targets, feats, [list(range(int(table.n_codes[t]))) if m.info()["objective"] != 2 else []
+                                                            for t, m in zip(targets, models)], sub)
         table.codes[:, row_begin:row_begin + n_rows] = sub
         return lab, prob

@@ -116,3 +116,79 @@ def test_row_sharded_rejects_bagging_and_leafwise():
             tab.train(1, [0, 2, 3, 4], objective=1, num_class=int(cards[1]), n_estimators=2, max_depth=-1, row_sharded=True)
     finally:
         N.comm_finalize()
+
+
+# ---- real multi-process RCCL (needs two GPUs: skipped on the one-GPU test box, run by whoever has the 8-GPU node) ------------
+def _rccl_rank(rank, world, uid, q, fail_rank, timeout_s):
+    """One process per GPU.  Trains target 4 row-sharded; `fail_rank` leaves before its first collective (a dead peer)."""
+    import os
+    import sys
+    os.environ["RGBM_COMM_TIMEOUT_S"] = str(timeout_s)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "spark-data-repair-plugin_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from repair import _native as N
+    from tests.synth import make_table, balanced_weights
+    try:
+        dirty, clean, cards = make_table(60000, 8, seed=71, null_ratio=0.02)
+        feats = [c for c in range(8) if c != 4]
+        K = int(cards[4])
+        kw = dict(objective=1, num_class=K, n_estimators=6, learning_rate=0.2, device_id=rank)
+        N.comm_init(uid, rank, world, rank)
+        if rank == fail_rank:
+            q.put((rank, "left", None))
+            return                                       # never joins the collectives: the peers must not hang
+        b0, b1 = rank * 60000 // world, (rank + 1) * 60000 // world
+        tab = N.Table(np.ascontiguousarray(dirty[:, b0:b1]), cards, device_id=rank)
+        blob = tab.train(4, feats, class_weight=balanced_weights(dirty[4], K), row_sharded=True, **kw).save()
+        single = None
+        if rank == 0:
+            N.comm_finalize()
+            single = N.Table(dirty, cards, device_id=0).train(4, feats, class_weight=balanced_weights(dirty[4], K), **kw).save()
+        q.put((rank, "ok", (blob, single)))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "error", "%s: %s" % (type(e).__name__, e)))
+
+
+def _run_ranks(world, fail_rank=-1, timeout_s=120):
+    import multiprocessing as mp
+    from repair import _native as N
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = N.comm_unique_id()
+    ps = [ctx.Process(target=_rccl_rank, args=(r, world, uid, q, fail_rank, timeout_s)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = {}
+    for _ in range(world):
+        r, status, payload = q.get(timeout=600)
+        out[r] = (status, payload)
+    for p in ps:
+        p.join(timeout=60)
+    return out
+
+
+def _two_gpus():
+    from repair import _native as N
+    return N.device_count() >= 2
+
+
+def test_rccl_two_processes_give_the_single_device_model(level_pass_kind):
+    if not _two_gpus():
+        pytest.skip("needs two HIP devices (one process per GPU over RCCL)")
+    out = _run_ranks(2)
+    assert all(s == "ok" for s, _ in out.values()), out
+    single = out[0][1][1]
+    assert out[0][1][0] == single and out[1][1][0] == single
+
+
+def test_rccl_dead_peer_raises_instead_of_hanging(level_pass_kind):
+    """A rank that never enters the collectives: the surviving rank's watchdog (RGBM_COMM_TIMEOUT_S) aborts its communicator and
+    the training call fails with an error instead of blocking in ncclAllReduce for ever."""
+    if not _two_gpus():
+        pytest.skip("needs two HIP devices (one process per GPU over RCCL)")
+    out = _run_ranks(2, fail_rank=1, timeout_s=8)
+    assert out[1][0] == "left"
+    assert out[0][0] == "error" and ("collective" in out[0][1] or "RCCL" in out[0][1]), out
