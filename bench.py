@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--no-full-job", action="store_true", help="do not run the 300-iteration job when --steps differs from 300")
     ap.add_argument("--mode", choices=["auto", "targets"], default="auto", help="multi-GPU split: auto = hybrid row/target sharding")
     ap.add_argument("--force-row-sharding", action="store_true", help="testing: run the collective (RCCL) path with a world of one")
+    ap.add_argument("--roofline-steps", type=int, default=20, help="boosting iterations of the sequential pass that measures the kernel roofline")
     ap.add_argument("--concurrency", type=int, default=None, help="target models trained at once per rank (default: RGBM_TARGET_CONCURRENCY or 4)")
     ap.add_argument("--train-rows", type=int, default=0,
                     help="train every model on a seeded sample of this many rows (the reference's DEFAULT behaviour is "
@@ -258,17 +259,15 @@ def main():
                 row_tab = None
                 row_sharding_note = "disabled: the row-sharded warm-up model differed from the single-device one (or failed)"
 
-    def timed_job(n_estimators):
+    def timed_job(n_estimators, want_stats=False, concurrency=None):
         """One complete job of `n_estimators` boosting iterations per target model, bracketed as the contract says."""
         params = dict(BASE_PARAMS, n_estimators=n_estimators)
-        if n_estimators != a.steps:                       # the chained repair rewrites the dirty table in place: start from the NULLs again
-            fresh = eng.upload(dirty_rows, cards)
-        else:
-            fresh = dirty_tab
+        concurrency = a.concurrency if concurrency is None else concurrency
+        fresh = eng.upload(dirty_rows, cards)            # the chained repair rewrites the dirty table in place: every job starts from the NULLs
         rdist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = run_job(eng, train_tab, fresh, cards, targets, label_counts, params, want_stats=True, row_table=row_tab,
-                      force_row_sharding=a.force_row_sharding, train_concurrency=a.concurrency)
+        res = run_job(eng, train_tab, fresh, cards, targets, label_counts, params, want_stats=want_stats, row_table=row_tab,
+                      force_row_sharding=a.force_row_sharding, train_concurrency=concurrency)
         torch.cuda.synchronize(); rdist.barrier()
         return res, rdist.max_over_ranks(time.perf_counter() - t0)
 
@@ -279,12 +278,17 @@ def main():
     res, elapsed = timed_job(REF_N_ESTIMATORS) if run_full else (res_k, elapsed_k)
     job_steps = REF_N_ESTIMATORS if run_full else a.steps
 
-    # ---- roofline inputs: hist_build algorithmic bytes / its summed launch time (HIP events on the launch stream)
-    def agg(key, r=res):
+    # ---- roofline inputs: hist_build algorithmic bytes / its summed launch time.  Every launch is bracketed by HIP events on the
+    # stream it is launched on (rgbm_train_stats); with several training streams in flight a bracket also spans the other streams'
+    # kernels, so the kernel figures come from a dedicated pass of the SAME job with ONE target at a time (not part of `value`).
+    roof_steps = max(1, min(a.steps, a.roofline_steps))
+    res_roof, elapsed_roof = timed_job(roof_steps, want_stats=True, concurrency=1)
+
+    def agg(key, r=res_roof):
         return rdist.sum_over_ranks(sum(s.get(key, 0) for s in r["stats"]))
     hist_ms_all, hist_bytes_all, launches_all = agg("hist_ms"), agg("hist_bytes"), agg("hist_launches")
     route_ms_all, route_launches_all = agg("route_ms"), agg("route_launches")
-    root_ms = sum(s["root_ms"] for s in res["stats"]); root_bytes = sum(s["root_rows"] * (cols - 1 + 8) for s in res["stats"])
+    root_ms = sum(s["root_ms"] for s in res_roof["stats"]); root_bytes = sum(s["root_rows"] * (cols - 1 + 8) for s in res_roof["stats"])
     train_s = rdist.max_over_ranks(res["times"]["train"]); infer_s = rdist.max_over_ranks(res["times"]["infer"])
 
     out = None
@@ -321,6 +325,7 @@ def main():
                          "kernel": "rg::k_level_pass<ROOT> + rg::k_level_pass<STREAM> (histogram build of the level grower; rg::k_hist for the leaf-wise grower)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                         "measured_on": "sequential pass (one target model at a time) of %d boosting iterations of the same job, %.2f s; HIP events per launch" % (roof_steps, elapsed_roof),
                          "launches": int(launches_all), "avg_launch_us": hist_ms_all * 1e3 / max(launches_all, 1),
                          "alg_bytes_per_launch": hist_bytes_all / max(launches_all, 1),
                          "root_scan_GBps_rank0": root_bytes / max(root_ms, 1e-9) * 1e-6,

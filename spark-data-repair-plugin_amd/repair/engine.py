@@ -132,7 +132,7 @@ def _train_concurrency(engine, table, costs, requested):
 
 
 def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, base_params, want_stats=False, row_table=None,
-            force_row_sharding=False, train_concurrency=None, y_values=None, integral=(), train_tables=None):
+            force_row_sharding=False, train_concurrency=None, y_values=None, integral=(), train_tables=None, param_search=None):
     """Train + repair, sharded over the ranks of the current torch.distributed group (if any).
 
     train_table / dirty_table : engine tables (all rows with error cells NULLed / the dirty rows)
@@ -146,6 +146,8 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     y_values = dict(y_values or {})
     integral = set(integral)
     train_tables = dict(train_tables or {})     # {target: table}: that target trains on its own (sampled) table, model.py:755-766
+    # param_search(target, table) -> {LightGBM core parameter: value} found by the hyper-parameter search for that target (train.py:133-209),
+    # run by the rank that owns the target right before its final fit; None = the fixed parameters
     rank, ws = dist.world()
     n_cols = len(n_codes)
     costs = []
@@ -160,7 +162,10 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     def one(t, table, fn):
         feats = [c for c in range(n_cols) if c != t]
         cw = balanced_class_weight(label_counts[t])
-        res = fn(table, t, feats, cw, model_params(int(n_codes[t]), base_params, continuous=t in y_values), y_value=y_values.get(t),
+        base = dict(base_params)
+        if param_search is not None and fn == engine.train:
+            base.update(param_search(t, table) or {})
+        res = fn(table, t, feats, cw, model_params(int(n_codes[t]), base, continuous=t in y_values), y_value=y_values.get(t),
                  want_stats=want_stats)
         if want_stats:
             res, st = res

@@ -572,8 +572,8 @@ class RepairModel():
 
         It can when everything between error detection and the result frame is the per-attribute model loop itself:
         no rule-based repairs, no functional-dependency rule models, no rebalancing, no cost function, plain repair output
-        (cells or repaired data), one hyper-parameter evaluation (`model.hp.max_evals=1`: the searched parameters keep their
-        LightGBM defaults, train.py:148-156), no feature selection, and every discrete target has at least two classes.
+        (cells or repaired data), no feature selection, and every discrete target has at least two classes.  The
+        hyper-parameter search (`model.hp.max_evals` > 1) runs on the resident tables too (pipeline.search_on_table).
         Otherwise the value-space path (pandas + one estimator per attribute) below handles the run."""
         if compute_repair_candidate_prob or maximal_likelihood_repair or self.repair_by_rules or self.cf is not None:
             return None
@@ -582,7 +582,7 @@ class RepairModel():
         from repair.train import (_opt_learning_rate, _opt_max_bin, _opt_max_depth, _opt_max_evals, _opt_min_split_gain,
                                   _opt_n_estimators, _opt_reg_alpha, _opt_boosting_type, _opt_class_weight)
         g = lambda o: get_option_value(self.opts, *o)  # noqa: E731
-        if int(g(_opt_max_evals)) != 1 or g(_opt_boosting_type) != "gbdt" or g(_opt_class_weight) != "balanced":
+        if g(_opt_boosting_type) != "gbdt" or g(_opt_class_weight) != "balanced":
             return None
         features = len(input_df.columns) - 2
         if int(self._get_option_value(*self._opt_max_training_column_num)) < features:
@@ -602,7 +602,7 @@ class RepairModel():
                       max_bin=int(g(_opt_max_bin)), lambda_l1=float(g(_opt_reg_alpha)), min_gain_to_split=float(g(_opt_min_split_gain)),
                       num_leaves=31, min_data_in_leaf=20, min_sum_hessian_in_leaf=1e-3, lambda_l2=0.0, bagging_fraction=1.0, bagging_freq=0,
                       feature_fraction=1.0, seed=42)
-        return dict(engine=engine, params=params)
+        return dict(engine=engine, params=params, search=int(g(_opt_max_evals)) > 1)
 
     def _run_resident(self, plan: Dict[str, Any], input_df: DataFrame, error_cells_df: DataFrame, target_columns: List[str],
                       continous_columns: List[str], repair_data: bool) -> DataFrame:
@@ -625,7 +625,7 @@ class RepairModel():
         frame, info = repair_frame(plan["engine"], input_df, rid, targets=target_columns, base_params=plan["params"],
                                    error_cells=error_cells_df[[rid, "attribute"]], detect_nulls=False,
                                    continuous_columns=[c for c in continous_columns if c in target_columns], train_rows=sample,
-                                   want_details=True)
+                                   want_details=True, check_unseen=True, search_opts=dict(self.opts) if plan.get("search") else None)
         self._last_resident_info = info
         rep = pd.Series(frame["repaired"].to_numpy(dtype=object),
                         index=pd.MultiIndex.from_arrays([frame[rid].to_numpy(), frame["attribute"].to_numpy()]))
@@ -663,7 +663,13 @@ class RepairModel():
         plan = self._resident_plan(input_df, target_columns, continous_columns, domain_stats, compute_repair_candidate_prob,
                                    maximal_likelihood_repair)
         if plan is not None:
-            return self._run_resident(plan, input_df, error_cells_df, target_columns, continous_columns, repair_data)
+            from repair.pipeline import UnseenCategories
+            try:
+                return self._run_resident(plan, input_df, error_cells_df, target_columns, continous_columns, repair_data)
+            except UnseenCategories as e:
+                # a dirty row carries a categorical value that the target's training rows never show: per-model dictionaries (the
+                # value-space path) treat it as missing, the table-wide dictionary would not -- keep the reference behaviour
+                _logger.info("resident path not taken: %s" % e)
 
         # 2. Repair Model Training Phase
         repair_base_df = self._prepare_repair_base_cells(input_df, error_cells_df, target_columns)

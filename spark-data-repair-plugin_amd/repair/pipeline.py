@@ -51,13 +51,99 @@ def detect_error_cells(table, targets, constraints=(), detect_nulls=True, error_
     return _merge_cells(table.n, parts)
 
 
+# searched parameter (sklearn alias, train.py:148-156) -> LightGBM core name of rgbm_params
+_POINT_TO_CORE = dict(num_leaves="num_leaves", subsample="bagging_fraction", subsample_freq="bagging_freq", colsample_bytree="feature_fraction",
+                      min_child_samples="min_data_in_leaf", min_child_weight="min_sum_hessian_in_leaf", reg_lambda="lambda_l2")
+
+
+def search_on_table(engine, table, t, n_codes, base_params, opts, y_value=None, rows=None):
+    """The hyper-parameter search of one target (train.py:133-209) on RESIDENT tables: every CV fold is a pair of device row gathers
+    of the training table (no pandas slicing, no re-encoding, no upload per fit -- the value-space search pays all three for each
+    of its >= 150 fits), trained and scored through the table API; the folds of `model.hp.batch_size` evaluations are in flight
+    together, one HIP stream per fit.  Same points (RandomState(42)), same folds (StratifiedKFold / KFold shuffled with the
+    evaluation index) and same stopping rule as repair.train.run_search -- it IS that loop.  Returns core parameters of the best point."""
+    from sklearn.metrics import f1_score, mean_squared_error
+    from sklearn.model_selection import KFold, StratifiedKFold
+    from repair.engine import balanced_class_weight, model_params
+    from repair.train import _opt_n_splits, run_search
+    from repair.utils import get_option_value
+    col = table.read_column(t)
+    rows = np.flatnonzero(col >= 0) if rows is None else np.asarray(rows, np.int64)
+    y = col[rows]
+    feats = [c for c in range(table.c) if c != t]
+    discrete = y_value is None
+    n_splits = int(get_option_value(opts, *_opt_n_splits))
+
+    def folds(seed):
+        cv = StratifiedKFold(n_splits=n_splits, shuffle=True, random_state=seed) if discrete else KFold(n_splits=n_splits, shuffle=True, random_state=seed)
+        return list(cv.split(np.zeros(len(rows)), y))
+
+    def core(point):
+        p = dict(base_params)
+        for k, v in point.items():
+            p[_POINT_TO_CORE[k]] = int(v) if k in ("num_leaves", "subsample_freq", "min_child_samples") else float(v)
+        return p
+
+    def fold_score(point, fold):
+        tr, va = fold
+        ttab, vtab = table.gather_rows(np.sort(rows[tr])), table.gather_rows(np.sort(rows[va]))
+        cnt = ttab.count_codes(t)[0]
+        m = engine.train(ttab, t, feats, balanced_class_weight(cnt), model_params(int(n_codes[t]), core(point), continuous=not discrete), y_value=y_value)
+        lab, pr = engine.repair_chain(vtab, [m], [t], [feats], 0, vtab.n)
+        truth = vtab.read_column(t)
+        if discrete:
+            return float(f1_score(truth, lab[0], average="macro"))
+        return -float(mean_squared_error(np.asarray(y_value, np.float64)[truth], pr[0]))
+
+    point, _, _ = run_search(opts, folds, fold_score)
+    return {_POINT_TO_CORE[k]: (int(v) if k in ("num_leaves", "subsample_freq", "min_child_samples") else float(v)) for k, v in point.items()}
+
+
+class UnseenCategories(ValueError):
+    """A dirty row holds a categorical feature value that none of the target's training rows has (see `unseen_categories`)."""
+
+
+def unseen_categories(table, dirty_tab, targets, ordered_cols=(), train_tables=None):
+    """[(target, feature, codes)]: categorical feature codes that occur in the rows a target model has to repair but in none of the
+    rows it trains on.  The value-space path gives such a value the code -1 (the model's own dictionary does not hold it: it is
+    MISSING for that model); the resident table codes it like any other value and the trees would bin it next to its dictionary
+    neighbours.  Callers that promise the value-space result (RepairModel.run) check this and fall back."""
+    C = table.c
+    d = np.stack([dirty_tab.read_column(c) for c in range(C)])
+    total = [table.count_codes(c)[0] for c in range(C)]
+    out = []
+    for t in targets:
+        need = d[t] < 0                                   # the rows this model's prediction is used for; all of them are dirty rows
+        if not need.any():
+            continue
+        for f in range(C):
+            if f == t or f in ordered_cols:
+                continue
+            v = d[f][need]
+            v = v[v >= 0]
+            if len(v) == 0:
+                continue
+            held = np.bincount(v, minlength=len(total[f]))   # rows with this code whose target cell is NULL: not training rows
+            if train_tables and t in train_tables:            # the model trains on a row sample (its target cells are all non-NULL)
+                seen = train_tables[t].count_codes(f)[0]
+            else:
+                seen = total[f] - held
+            gone = np.flatnonzero((held > 0) & (seen <= 0))
+            if len(gone):
+                out.append((t, f, gone))
+    return out
+
+
 def repair_table(engine, table, targets, base_params, constraints=(), detect_nulls=True, error_cells=None,
-                 want_pmf=False, top_k=32, threshold=0.0, want_stats=False, continuous=None, train_rows=None):
+                 want_pmf=False, top_k=32, threshold=0.0, want_stats=False, continuous=None, train_rows=None,
+                 check_unseen=False, search_opts=None):
     """Detect, NULL out, split, train, repair, shape.  ``table`` is modified in place (error cells become NULL).
 
     continuous : {column: (ascending distinct values, is_integral)} -- CONTINUOUS target attributes (byte/short/int/long/float/
                  double in the reference, RepairBase.scala:41-44): repaired by an L2 regressor on the values behind their codes
                  (train.py:97-100), integral ones rounded (model.py:1130-1132); `repaired_value` carries the prediction.
+    search_opts: reference option dict (model.hp.*, model.cv.n_splits): run the hyper-parameter search of every target on the
+                 resident tables before its final fit (`search_on_table`); None = the fixed parameters.
     train_rows : {target: row positions} or a callable (target, positions of its non-NULL rows) -> positions -- train that
                  target's model on these rows only (model.max_training_row_num sampling, model.py:755-766); default: every row
                  whose target cell is not NULL.
@@ -106,8 +192,17 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
         for t, r in train_rows.items():
             train_tables[t] = table.gather_rows(np.sort(np.asarray(r, np.int64)))
             label_counts[t] = train_tables[t].count_codes(t)[0]
+    if check_unseen:
+        gone = unseen_categories(table, dirty_tab, targets, train_tables=train_tables, ordered_cols=set(continuous) | set(check_unseen if not isinstance(check_unseen, bool) else ()))
+        if gone:
+            raise UnseenCategories("%d (target, feature) pairs hold categories no training row has, e.g. target column %d / feature column %d"
+                                   % (len(gone), gone[0][0], gone[0][1]))
+    search = None
+    if search_opts is not None:
+        def search(t, tab):
+            return search_on_table(engine, tab, t, n_codes, base_params, search_opts, y_value=y_values.get(t))
     res = run_job(engine, table, dirty_tab, n_codes, targets, label_counts, base_params, want_stats=want_stats,
-                  y_values=y_values, integral=integral, train_tables=train_tables)
+                  y_values=y_values, integral=integral, train_tables=train_tables, param_search=search)
     # flatten + join with the error cells (RepairMiscApi.scala:41-49, model.py:1398-1401)
     t0 = time.perf_counter()
     tpos = np.full(table.c, -1, np.int64)
@@ -167,7 +262,8 @@ def encode_frame(df, columns):
 
 
 def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=None, want_pmf=False, top_k=32, threshold=0.0,
-                 error_cells=None, detect_nulls=True, continuous_columns=(), train_rows=None, want_details=False):
+                 error_cells=None, detect_nulls=True, continuous_columns=(), train_rows=None, want_details=False,
+                 check_unseen=False, search_opts=None):
     """DataFrame in, the reference's result frame out: (row_id, attribute, current_value, repaired, prob[, pmf]) -- the
     shape of `RepairModel.run()` / `run(compute_repair_candidate_prob=True)` (python/repair/model.py:1398-1419).
 
@@ -199,7 +295,8 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
         if c in pos and c in targets:
             cont[pos[c]] = (np.asarray(dicts[pos[c]], np.float64), pd.api.types.is_integer_dtype(df[c]))
     res = repair_table(engine, table, [pos[t] for t in targets], dict(base_params or {}), constraints=cons, detect_nulls=detect_nulls,
-                       error_cells=cells, want_pmf=want_pmf, top_k=top_k, threshold=threshold, continuous=cont,
+                       error_cells=cells, want_pmf=want_pmf, top_k=top_k, threshold=threshold, continuous=cont, search_opts=search_opts,
+                       check_unseen=([pos[c] for c in cols if pd.api.types.is_numeric_dtype(df[c]) and not pd.api.types.is_bool_dtype(df[c])] or True) if check_unseen else False,
                        train_rows=(lambda t, r: train_rows(cols[t], r)) if callable(train_rows) else train_rows)
     rows, ccols = res["rows"], res["cols"]
 

@@ -99,6 +99,64 @@ def _cv_loss(model: Any, X: pd.DataFrame, y: pd.Series, is_discrete: bool, n_spl
     return -float(np.mean(scores))
 
 
+def run_search(opts: Dict[str, str], n_folds_of: Any, fold_score: Any) -> Tuple[Dict[str, Any], float, int]:
+    """The hyper-parameter search loop of train.py:133-209, independent of WHERE a fit runs.
+
+    n_folds_of(seed) -> the CV folds of one evaluation (a list; shuffled with `seed`, train.py:158-173)
+    fold_score(point, fold) -> the score of one fit (macro-F1 / -MSE) -- called from a thread pool, several at a time
+    Returns (best point, best score, evaluations).  Evaluation #0 is LightGBM's defaults for the searched parameters; the folds of
+    `model.hp.batch_size` consecutive evaluations are in flight together (every fit owns a HIP stream); the no-progress / timeout
+    rule is applied to the losses in trial order, so the outcome equals the sequential search."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = lambda o: get_option_value(opts, *o)  # noqa: E731
+    n_splits = int(g(_opt_n_splits))
+    max_evals = int(g(_opt_max_evals))
+    patience = int(g(_opt_no_progress_loss))
+    timeout = int(g(_opt_timeout))
+    batch = max(1, int(g(_opt_batch_size)))
+    rs = np.random.RandomState(42)
+    trials: List[Tuple[float, Dict[str, Any]]] = []
+    best_loss, since_best, start = None, 0, time.time()
+    stop = False
+    with ThreadPoolExecutor(max_workers=batch * n_splits) as pool:
+        while len(trials) < max_evals and not stop:
+            # draw the next `batch` points (same RandomState stream as a sequential search) ...
+            nb = min(batch, max_evals - len(trials))
+            points = [dict(_DEFAULT_POINT) if (not trials and i == 0) else _sample_point(rs) for i in range(nb)]
+            futs: List[Any] = []
+            if max_evals > 1:   # a single evaluation decides nothing: skip the CV fits
+                # ... train every CV fold of every point of the batch concurrently (one HIP stream per fit) ...
+                for i, point in enumerate(points):
+                    try:
+                        futs.append([pool.submit(fold_score, point, fold) for fold in n_folds_of(len(trials) + i)])
+                    except Exception as e:   # noqa: BLE001
+                        futs.append(e)
+            # ... and account for the losses in trial order, exactly like the sequential loop
+            for i, point in enumerate(points):
+                if max_evals == 1:
+                    loss = 0.0
+                else:
+                    try:
+                        if isinstance(futs[i], Exception):
+                            raise futs[i]
+                        loss = -float(np.mean([f.result() for f in futs[i]]))
+                    except Exception as e:   # e.g. a fold misses a label (train.py:175-179)
+                        _logger.warning("%s: %s" % (e.__class__, e))
+                        loss = 0.0
+                if stop:
+                    continue   # evaluated in vain: past the stopping point of the sequential search
+                trials.append((loss, point))
+                if best_loss is None or loss < best_loss:
+                    best_loss, since_best = loss, 0
+                else:
+                    since_best += 1
+                if since_best >= patience or (timeout > 0 and time.time() - start > timeout):
+                    stop = True
+    _logger.info("hyperopt: #eval=%d/%d" % (len(trials), max_evals))
+    best = min(trials, key=lambda t: t[0])
+    return best[1], -best[0], len(trials)
+
+
 @elapsed_time  # type: ignore
 def _build_gbm_model(X: pd.DataFrame, y: pd.Series, is_discrete: bool, num_class: int, n_jobs: int,
                      opts: Dict[str, str]) -> Tuple[Any, float]:
@@ -116,59 +174,14 @@ def _build_gbm_model(X: pd.DataFrame, y: pd.Series, is_discrete: bool, num_class
         return model_class(**p)
 
     n_splits = int(g(_opt_n_splits))
-    max_evals = int(g(_opt_max_evals))
-    patience = int(g(_opt_no_progress_loss))
-    timeout = int(g(_opt_timeout))
-    batch = max(1, int(g(_opt_batch_size)))
     try:
-        from concurrent.futures import ThreadPoolExecutor
-        rs = np.random.RandomState(42)
-        trials: List[Tuple[float, Dict[str, Any]]] = []
-        best_loss, since_best, start = None, 0, time.time()
-        stop = False
-        with ThreadPoolExecutor(max_workers=batch * n_splits) as pool:
-            while len(trials) < max_evals and not stop:
-                # draw the next `batch` points (same RandomState stream as a sequential search) ...
-                nb = min(batch, max_evals - len(trials))
-                points = [dict(_DEFAULT_POINT) if (not trials and i == 0) else _sample_point(rs) for i in range(nb)]
-                futs: List[Any] = []
-                if max_evals > 1:   # a single evaluation decides nothing: skip the CV fits
-                    # ... train every CV fold of every point of the batch concurrently (one HIP stream per fit) ...
-                    for i, point in enumerate(points):
-                        try:
-                            model = _create_model(point)
-                            folds = _cv_folds(X, y, is_discrete, n_splits, seed=len(trials) + i)
-                            futs.append([pool.submit(_fold_score, model, X, y, is_discrete, tr, va) for tr, va in folds])
-                        except Exception as e:   # noqa: BLE001
-                            futs.append(e)
-                # ... and account for the losses in trial order, exactly like the sequential loop
-                for i, point in enumerate(points):
-                    if max_evals == 1:
-                        loss = 0.0
-                    else:
-                        try:
-                            if isinstance(futs[i], Exception):
-                                raise futs[i]
-                            loss = -float(np.mean([f.result() for f in futs[i]]))
-                        except Exception as e:   # e.g. a fold misses a label (train.py:175-179)
-                            _logger.warning("%s: %s" % (e.__class__, e))
-                            loss = 0.0
-                    if stop:
-                        continue   # evaluated in vain: past the stopping point of the sequential search
-                    trials.append((loss, point))
-                    if best_loss is None or loss < best_loss:
-                        best_loss, since_best = loss, 0
-                    else:
-                        since_best += 1
-                    if since_best >= patience or (timeout > 0 and time.time() - start > timeout):
-                        stop = True
-        _logger.info("hyperopt: #eval=%d/%d" % (len(trials), max_evals))
-        best = min(trials, key=lambda t: t[0])
-        model = _create_model(best[1])
+        point, score, _ = run_search(opts, lambda seed: _cv_folds(X, y, is_discrete, n_splits, seed=seed),
+                                     lambda point, fold: _fold_score(_create_model(point), X, y, is_discrete, fold[0], fold[1]))
+        model = _create_model(point)
         model.fit(X, y)
         imp = sorted(((n, v) for n, v in zip(model.feature_name_, model.feature_importances_) if v > 0.0), key=lambda x: -x[1])
         _logger.debug("repairgbm: feature_importances=%s" % imp)
-        return model, -best[0]
+        return model, score
     except Exception as e:
         _logger.warning("Failed to build a stat model because: %s" % e)
         return None, 0.0

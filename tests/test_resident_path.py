@@ -101,10 +101,19 @@ def test_runs_outside_the_plain_loop_keep_the_value_space_path(oracle_backend):
     m._engine_override = OracleEngine()
     m.run(compute_repair_candidate_prob=True)
     assert getattr(m, "_last_resident_info", None) is None                  # pmf output: value-space path
-    m2 = _model(df, **{"model.hp.max_evals": "2"})
+    m2 = _model(df).setRepairByRules(True)
     m2._engine_override = OracleEngine()
     m2.run()
-    assert getattr(m2, "_last_resident_info", None) is None                 # a hyper-parameter search: value-space path
+    assert getattr(m2, "_last_resident_info", None) is None                 # rule-based repairs: value-space path
+
+
+def test_hyperparameter_search_on_resident_tables_equals_the_value_space_search(oracle_backend):
+    """model.hp.max_evals > 1: the same points, folds and stopping rule, with every CV fit a pair of device row gathers + a table
+    training call.  Same best point per target, hence the same repairs as the value-space search."""
+    df, _, _, _ = _synthetic_frame(1500, 5, seed=19)
+    opts = {"model.hp.max_evals": "4", "model.hp.no_progress_loss": "3", "model.lgb.n_estimators": "8"}
+    a, b = _both_paths(df, OracleEngine(), **opts)
+    pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
 
 
 @pytest.mark.gpu
@@ -154,3 +163,23 @@ def test_gpu_run_takes_the_resident_path_and_matches_both_references():
     assert got == expect                                       # NULL current values: every cell is kept in the result
     device = sum(info["times"].get(k, 0.0) for k in ("train", "infer", "detect", "prepare", "exchange", "gather"))
     print("resident run(): %.2fs wall, %.2fs on the device pipeline, host share %.0f %%" % (wall, device, 100 * (1 - device / wall)))
+
+
+def test_unseen_category_in_a_dirty_row_falls_back(oracle_backend):
+    """A dirty row with a feature value no training row of that target shows: the value-space path treats it as missing (it is not in
+    the model's dictionary); the table-wide dictionary would code it like any value, so the run keeps the value-space path."""
+    df, _, _, _ = _synthetic_frame(1500, 5, seed=17)
+    i = int(np.flatnonzero(df["c3"].isna().to_numpy())[0])
+    df.loc[i, "c1"] = "only-here"
+    a, b = None, None
+    m = _model(df)
+    m._engine_override = OracleEngine()
+    b = m.run()
+    assert getattr(m, "_last_resident_info", None) is None
+    import os
+    os.environ["REPAIR_RESIDENT"] = "0"
+    try:
+        a = _model(df).run()
+    finally:
+        os.environ.pop("REPAIR_RESIDENT", None)
+    pd.testing.assert_frame_equal(_sorted(a), _sorted(b))

@@ -18,3 +18,17 @@ for bs in ("1", "4", "8", "16"):
     print("batch_size=%s: 16 evaluations x 3 folds + final fit, 300 iterations each: %.2f s  (cv f1=%.4f)" % (bs, dt, score), flush=True)
 assert len(set(res.values())) == 1, "batched search changed the outcome"
 print("identical outcome for every batch size")
+
+# ---- the same search on RESIDENT tables (pipeline.search_on_table): folds are device row gathers, no re-encode / upload per fit
+from repair.engine import HipEngine
+from repair.pipeline import search_on_table, encode_frame
+eng = HipEngine(0)
+df = X.assign(y=y)
+idx, remaps, dicts = encode_frame(df, list(df.columns))
+for bs in ("1", "8", "16"):
+    tab = eng.upload_dictionaries(idx, remaps)
+    t0 = time.perf_counter()
+    best = search_on_table(eng, tab, len(df.columns) - 1, np.asarray(tab.n_codes), dict(n_estimators=300, learning_rate=0.01, max_depth=7, max_bin=255, seed=42),
+                           dict(base, **{"model.hp.batch_size": bs}))
+    dt = time.perf_counter() - t0
+    print("resident tables, batch_size=%s: 16 evaluations x 3 folds (48 fits, 300 iterations each): %.2f s  best=%s" % (bs, dt, best), flush=True)
