@@ -130,6 +130,15 @@ int rgbm_repair_chain(const rgbm_model* const* models, int32_t T, const int32_t*
  * target cell is non-NULL (model.py:776), all other listed columns being the features. */
 int rgbm_table_create(const int32_t* codes_colmajor, int64_t n, int32_t c, const int32_t* n_codes,
                       int32_t device_id, rgbm_table** out);
+/* CATEGORICAL columns (kind 1; default 0 = ordered codes): a model trained from this table records which codes of the column no
+ * training row held, and treats them as MISSING when it predicts -- what the reference's per-model encoders do with a category they
+ * have not seen (python/repair/model.py:701-729: the encoders are fitted on the training frame of each model).  Such models are
+ * serialised as format version 2 (version 1 + one bitmap per feature); row gathers inherit the kinds. */
+int rgbm_table_set_column_kind(rgbm_table* t, int32_t col, int32_t kind);
+/* NUMERIC columns: the ascending distinct values behind the codes 0..n_codes[col]-1 (one per code; n = 0 clears).  The trainer then
+ * places bin bounds at the midpoints of the VALUES, as LightGBM does on raw numbers (bin.cpp GreedyFindBin), instead of at the
+ * midpoints of the rank codes: it only matters for values that no training row of the model holds.  Row gathers inherit it. */
+int rgbm_table_set_column_values(rgbm_table* t, int32_t col, const double* values, int32_t n);
 /* Pinned host memory for the code matrix (north_star: "pinned int32 column-major feature matrix"): a block from
  * rgbm_host_alloc is page-locked, so rgbm_table_create copies it at PCIe DMA speed without staging.  Any other block is
  * page-locked in place for the duration of the copy (and copied the plain way if that fails). */

@@ -50,6 +50,7 @@ def lib():
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.orc_train.restype = C.c_int
+        _lib.orc_train2.restype = C.c_int
         _lib.orc_predict.restype = C.c_int
         _lib.orc_model_save.restype = C.c_int
         _lib.orc_model_load.restype = C.c_int
@@ -106,8 +107,11 @@ class OracleModel:
         return out
 
 
-def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample_weight=None, **params):
-    """X: [F][N] int32 codes column-major; y_code: [N] int32."""
+def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample_weight=None, feature_values=None,
+          categorical=None, **params):
+    """X: [F][N] int32 codes column-major; y_code: [N] int32.  feature_values: {feature index: ascending distinct values} of the
+    NUMERIC features (bin bounds at value midpoints, like Table.set_column_values on the product side); categorical: indices of the
+    CATEGORICAL features (codes no training row holds are missing at prediction time, like Table.set_column_kind)."""
     X = np.ascontiguousarray(X, np.int32)
     F, N = X.shape
     n_codes = np.ascontiguousarray(n_codes, np.int32)
@@ -117,9 +121,21 @@ def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample
     sw = None if sample_weight is None else np.ascontiguousarray(sample_weight, np.float64)
     p = make_params(**params)
     h = C.c_void_p()
-    rc = lib().orc_train(_p(X, C.c_int32), C.c_int64(N), C.c_int32(F), _p(n_codes, C.c_int32),
-                         _p(y_code, C.c_int32), C.c_int32(n_y_codes), _p(yv, C.c_double),
-                         _p(cw, C.c_double), _p(sw, C.c_double), C.byref(p), C.byref(h))
+    fv_arr, keep = None, []
+    if feature_values:
+        fv_arr = (C.POINTER(C.c_double) * F)()
+        for f, v in feature_values.items():
+            a = np.ascontiguousarray(v, np.float64)
+            assert len(a) == int(n_codes[f]), "feature_values[%d] must list every code of the column" % f
+            keep.append(a)
+            fv_arr[f] = a.ctypes.data_as(C.POINTER(C.c_double))
+    kinds = None
+    if categorical:
+        kinds = np.zeros(F, np.int32)
+        kinds[list(categorical)] = 1
+    rc = lib().orc_train2(_p(X, C.c_int32), C.c_int64(N), C.c_int32(F), _p(n_codes, C.c_int32),
+                          _p(y_code, C.c_int32), C.c_int32(n_y_codes), _p(yv, C.c_double),
+                          _p(cw, C.c_double), _p(sw, C.c_double), C.byref(p), fv_arr, _p(kinds, C.c_int32), C.byref(h))
     if rc:
         raise RuntimeError("orc_train failed: %d" % rc)
     return OracleModel(h)

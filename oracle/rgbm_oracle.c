@@ -53,6 +53,9 @@ typedef struct {
     int32_t V;         /* number of value bins */
     int32_t has_nan;   /* 1 => an extra bin (index V) holds NULL rows (LightGBM MissingType::NaN) */
     int32_t* ub;       /* [V] last code that falls into value bin b (last entry INT32_MAX) */
+    uint32_t* unseen;  /* CATEGORICAL features only, or NULL: bit c set => no training row held code c; such a category is MISSING for
+                        * this model at prediction time (it has no place in the order of the codes), like a value outside the dictionary */
+    int32_t n_unseen_words;
 } orc_feat;
 
 typedef struct {
@@ -126,8 +129,20 @@ static double leaf_gain(double G, double H, double l1, double l2) {
 /* GreedyFindBin restated in code space: distinct values are the codes with cnt>0, a bin
  * boundary between consecutive seen codes a<b is floor((a+b)/2) (the integer codes that are
  * <= the LightGBM midpoint).  Returns number of bins, fills ub (last code per bin). */
+/* Bin upper bound between two neighbouring training codes a < b.  Codes of a NUMERIC column are ranks of its distinct values;
+ * LightGBM puts the bound at the midpoint of the VALUES, so a code that lies between a and b (a value that only rows outside the
+ * training set hold) goes left iff its value is <= (val[a] + val[b]) / 2: the bound in code space is the largest such code.
+ * Without a value dictionary (categorical columns, host-array calls) the codes themselves are the scale. */
+static int32_t mid_code(int32_t a, int32_t b, const double* vals) {
+    if (!vals) return (int32_t)(((int64_t)a + (int64_t)b) / 2);
+    const double m = (vals[a] + vals[b]) / 2.0;
+    int32_t lo = a, hi = b - 1;                 /* vals[a] <= m always */
+    while (lo < hi) { int32_t c = lo + (hi - lo + 1) / 2; if (vals[c] <= m) lo = c; else hi = c - 1; }
+    return lo;
+}
+
 static int greedy_find_bin(const int32_t* dv, const int64_t* cnt, int nd, int max_bin,
-                           int64_t total_cnt, int min_data_in_bin, int32_t* ub) {
+                           int64_t total_cnt, int min_data_in_bin, int32_t* ub, const double* vals) {
     int nb = 0;
     if (nd <= 0) return 0;
     if (nd <= max_bin) {
@@ -135,7 +150,7 @@ static int greedy_find_bin(const int32_t* dv, const int64_t* cnt, int nd, int ma
         for (int i = 0; i < nd - 1; ++i) {
             cur += cnt[i];
             if (cur >= min_data_in_bin) {
-                ub[nb++] = (int32_t)(((int64_t)dv[i] + (int64_t)dv[i + 1]) / 2);
+                ub[nb++] = mid_code(dv[i], dv[i + 1], vals);
                 cur = 0;
             }
         }
@@ -176,7 +191,7 @@ static int greedy_find_bin(const int32_t* dv, const int64_t* cnt, int nd, int ma
     }
     ++bin_cnt;
     for (int i = 0; i < bin_cnt - 1; ++i) {
-        int32_t v = (int32_t)(((int64_t)upper[i] + (int64_t)lower[i + 1]) / 2);
+        int32_t v = mid_code(upper[i], lower[i + 1], vals);
         if (nb == 0 || ub[nb - 1] != v) ub[nb++] = v;
     }
     ub[nb++] = INT32_MAX;
@@ -187,7 +202,7 @@ static int greedy_find_bin(const int32_t* dv, const int64_t* cnt, int nd, int ma
 /* FindBin for one feature over the training rows.  All codes are shifted to positive values
  * (OrdinalEncoder emits 1..n), so FindBinWithZeroAsOneBin gives an (always empty) zero bin and
  * max_bin-1 bins to the values; one more bin is reserved when NULLs are present. */
-static void find_bin(const int32_t* col, int64_t n, int32_t n_codes, const orc_params* p, orc_feat* f) {
+static void find_bin(const int32_t* col, int64_t n, int32_t n_codes, const orc_params* p, orc_feat* f, const double* vals, int categorical) {
     int64_t* cnt = (int64_t*)calloc((size_t)(n_codes > 0 ? n_codes : 1), sizeof(int64_t));
     int64_t na = 0;
     for (int64_t i = 0; i < n; ++i) { int32_t c = col[i]; if (c < 0 || c >= n_codes) ++na; else ++cnt[c]; }
@@ -203,12 +218,19 @@ static void find_bin(const int32_t* col, int64_t n, int32_t n_codes, const orc_p
     f->n_codes = n_codes;
     f->has_nan = na > 0 ? 1 : 0;
     f->ub = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nd > 0 ? (nd < mb + 1 ? nd + 1 : mb + 1) : 1));
-    f->V = greedy_find_bin(dv, dc, nd, mb, n - na, p->min_data_in_bin, f->ub);
+    f->V = greedy_find_bin(dv, dc, nd, mb, n - na, p->min_data_in_bin, f->ub, vals);
+    f->unseen = NULL; f->n_unseen_words = 0;
+    if (categorical && nd < n_codes) {
+        f->n_unseen_words = (n_codes + 31) / 32;
+        f->unseen = (uint32_t*)calloc((size_t)f->n_unseen_words, sizeof(uint32_t));
+        for (int32_t c = 0; c < n_codes; ++c) if (cnt[c] == 0) f->unseen[c >> 5] |= 1u << (c & 31);
+    }
     free(cnt); free(dv); free(dc);
 }
 
 static inline int code_to_bin(const orc_feat* f, int32_t c) {
     if (c < 0 || c >= f->n_codes) return -1;   /* missing */
+    if (f->unseen && ((f->unseen[c >> 5] >> (c & 31)) & 1u)) return -1;
     int lo = 0, hi = f->V - 1;                 /* first b with c <= ub[b] */
     while (lo < hi) { int mid = (lo + hi) >> 1; if (c <= f->ub[mid]) hi = mid; else lo = mid + 1; }
     return lo;
@@ -521,10 +543,26 @@ static int frexp_exp(double v) { int ex; (void)frexp(v, &ex); return ex; }   /* 
 ORC_API void orc_model_free(orc_model* m);
 
 /* ------------------------------------------------------------------ GBDT::Train */
+ORC_API int orc_train2(const int32_t* X, int64_t N, int32_t F, const int32_t* n_codes,
+                       const int32_t* y_code, int32_t n_y_codes, const double* y_value,
+                       const double* class_weight, const double* sample_weight,
+                       const orc_params* p, const double* const* feat_values, const int32_t* feat_kinds, orc_model** out);
+
 ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_codes,
                       const int32_t* y_code, int32_t n_y_codes, const double* y_value,
                       const double* class_weight, const double* sample_weight,
                       const orc_params* p, orc_model** out) {
+    return orc_train2(X, N, F, n_codes, y_code, n_y_codes, y_value, class_weight, sample_weight, p, NULL, NULL, out);
+}
+
+/* feat_values[f] (may be NULL, as may the whole array): the ascending distinct values behind the codes of NUMERIC feature f
+ * (rgbm_table_set_column_values on the product side) -- bin bounds are then value midpoints (mid_code).
+ * feat_kinds[f] == 1 (array may be NULL): CATEGORICAL feature (rgbm_table_set_column_kind) -- codes no training row holds are
+ * recorded in the model and are MISSING at prediction time. */
+ORC_API int orc_train2(const int32_t* X, int64_t N, int32_t F, const int32_t* n_codes,
+                       const int32_t* y_code, int32_t n_y_codes, const double* y_value,
+                       const double* class_weight, const double* sample_weight,
+                       const orc_params* p, const double* const* feat_values, const int32_t* feat_kinds, orc_model** out) {
     if (N <= 0 || F <= 0 || !X || !y_code || !p || !out) return -1;
     if (p->max_bin < 2 || p->max_bin > 255 || p->num_leaves < 2) return -2;
     const int obj = p->objective;
@@ -542,7 +580,7 @@ ORC_API int orc_train(const int32_t* X, int64_t N, int32_t F, const int32_t* n_c
     t.hoff[0] = 0;
     for (int f = 0; f < F; ++f) {
         const int32_t* col = X + (size_t)f * N;
-        find_bin(col, N, n_codes[f], p, &t.feats[f]);
+        find_bin(col, N, n_codes[f], p, &t.feats[f], feat_values ? feat_values[f] : NULL, feat_kinds ? feat_kinds[f] == 1 : 0);
         const orc_feat* ft = &t.feats[f];
         uint8_t* b = t.bins + (size_t)f * N;
         for (int64_t i = 0; i < N; ++i) { int bin = code_to_bin(ft, col[i]); b[i] = (uint8_t)(bin < 0 ? ft->V : bin); }
@@ -818,12 +856,20 @@ static void put(uint8_t** p, const void* src, size_t n, int write) { if (write) 
 static size_t serialise(const orc_model* m, uint8_t* buf) {
     int write = buf != NULL; uint8_t* p = buf ? buf : (uint8_t*)0;
     uint8_t* start = p;
-    int32_t hdr[7] = {0x4D424752, 1, m->objective, m->num_class, m->K, m->n_iter, m->F};
+    /* version 2 = version 1 + the unseen-category bitmap of every feature; written only when a feature has one */
+    int ver = 1;
+    for (int f = 0; f < m->F; ++f) if (m->feats[f].unseen) ver = 2;
+    int32_t hdr[7] = {0x4D424752, ver, m->objective, m->num_class, m->K, m->n_iter, m->F};
     put(&p, hdr, sizeof(hdr), write);
     for (int f = 0; f < m->F; ++f) {
         int32_t h3[3] = {m->feats[f].n_codes, m->feats[f].V, m->feats[f].has_nan};
         put(&p, h3, sizeof(h3), write);
         put(&p, m->feats[f].ub, sizeof(int32_t) * m->feats[f].V, write);
+        if (ver == 2) {
+            int32_t nw = m->feats[f].unseen ? m->feats[f].n_unseen_words : 0;
+            put(&p, &nw, 4, write);
+            if (nw) put(&p, m->feats[f].unseen, 4 * (size_t)nw, write);
+        }
     }
     for (int i = 0; i < m->n_iter * m->K; ++i) {
         const orc_tree* t = &m->trees[i]; int n = t->L - 1;
@@ -845,7 +891,7 @@ ORC_API int orc_model_load(const void* buf, size_t len, orc_model** out) {
     const uint8_t* p = (const uint8_t*)buf; const uint8_t* end = p + len;
     if (len < 28) return -1;
     int32_t hdr[7]; memcpy(hdr, p, 28); p += 28;
-    if (hdr[0] != 0x4D424752 || hdr[1] != 1) return -1;
+    if (hdr[0] != 0x4D424752 || (hdr[1] != 1 && hdr[1] != 2)) return -1;
     orc_model* m = (orc_model*)calloc(1, sizeof(orc_model));
     m->objective = hdr[2]; m->num_class = hdr[3]; m->K = hdr[4]; m->n_iter = hdr[5]; m->F = hdr[6];
     m->feats = (orc_feat*)calloc(m->F > 0 ? m->F : 1, sizeof(orc_feat));
@@ -855,6 +901,12 @@ ORC_API int orc_model_load(const void* buf, size_t len, orc_model** out) {
         m->feats[f].n_codes = h3[0]; m->feats[f].V = h3[1]; m->feats[f].has_nan = h3[2];
         if (h3[1] < 0 || p + 4 * (size_t)h3[1] > end) { orc_model_free(m); return -1; }
         m->feats[f].ub = (int32_t*)malloc(4 * (size_t)(h3[1] > 0 ? h3[1] : 1)); memcpy(m->feats[f].ub, p, 4 * (size_t)h3[1]); p += 4 * (size_t)h3[1];
+        if (hdr[1] == 2) {
+            int32_t nw; if (p + 4 > end) { orc_model_free(m); return -1; }
+            memcpy(&nw, p, 4); p += 4;
+            if (nw < 0 || (nw != 0 && nw != (h3[0] + 31) / 32) || p + 4 * (size_t)nw > end) { orc_model_free(m); return -1; }
+            if (nw) { m->feats[f].unseen = (uint32_t*)malloc(4 * (size_t)nw); memcpy(m->feats[f].unseen, p, 4 * (size_t)nw); m->feats[f].n_unseen_words = nw; p += 4 * (size_t)nw; }
+        }
     }
     int nt = m->n_iter * m->K;
     m->trees = (orc_tree*)calloc(nt > 0 ? nt : 1, sizeof(orc_tree));
@@ -875,7 +927,7 @@ ORC_API int orc_model_load(const void* buf, size_t len, orc_model** out) {
 }
 ORC_API void orc_model_free(orc_model* m) {
     if (!m) return;
-    if (m->feats) { for (int f = 0; f < m->F; ++f) free(m->feats[f].ub); free(m->feats); }
+    if (m->feats) { for (int f = 0; f < m->F; ++f) { free(m->feats[f].ub); free(m->feats[f].unseen); } free(m->feats); }
     if (m->trees) {
         for (int i = 0; i < m->n_iter * m->K; ++i) {
             orc_tree* t = &m->trees[i];
@@ -930,6 +982,6 @@ ORC_API int orc_repair_chain(const orc_model* const* models, int32_t T, const in
 
 ORC_API double orc_exp(double x) { return rg_exp(x); }
 ORC_API int orc_find_bin(const int32_t* col, int64_t n, int32_t n_codes, const orc_params* p, int32_t* V, int32_t* has_nan, int32_t* ub /*cap max_bin*/) {
-    orc_feat f; find_bin(col, n, n_codes, p, &f); *V = f.V; *has_nan = f.has_nan;
+    orc_feat f; find_bin(col, n, n_codes, p, &f, NULL, 0); *V = f.V; *has_nan = f.has_nan;
     memcpy(ub, f.ub, sizeof(int32_t) * f.V); free(f.ub); return 0;
 }

@@ -223,7 +223,13 @@ void all_reduce(void* buf, size_t count, int type, hipStream_t s) {
     g->barrier();
 }
 
-struct Feat { int32_t n_codes = 0, V = 0, has_nan = 0; std::vector<int32_t> ub; };
+struct Feat {
+    int32_t n_codes = 0, V = 0, has_nan = 0; std::vector<int32_t> ub;
+    // CATEGORICAL features only (else empty): bit c set => no training row held code c.  Such a category is MISSING for this model at
+    // prediction time (it has no place in the order of the codes) -- what a per-model dictionary does with a value it does not hold.
+    std::vector<uint32_t> unseen;
+    bool is_unseen(int32_t c) const { return !unseen.empty() && ((unseen[(size_t)c >> 5] >> (c & 31)) & 1u); }
+};
 struct Tree {
     int32_t L = 1;
     std::vector<int32_t> feat, theta, dleft, left, right;
@@ -255,8 +261,20 @@ namespace {
 // Host logic: bin finding (LightGBM bin.cpp GreedyFindBin / FindBinWithZeroAsOneBin restated in
 // code space; see DESIGN.md "Binning").  Input: counts per code over the training rows.
 // ---------------------------------------------------------------------------------------------
+// Bin upper bound between two neighbouring training codes a < b.  Codes of a NUMERIC column are ranks of its distinct values and
+// LightGBM puts the bound at the midpoint of the VALUES: with the column's value dictionary (rgbm_table_set_column_values) the bound
+// in code space is the largest code whose value is <= (val[a] + val[b]) / 2, so a value that only rows outside the training set
+// hold falls on the side LightGBM would send it to.  Without one (categorical columns, host-array calls) the codes are the scale.
+int32_t mid_code(int32_t a, int32_t b, const double* vals) {
+    if (!vals) return (int32_t)(((int64_t)a + (int64_t)b) / 2);
+    const double m = (vals[a] + vals[b]) / 2.0;
+    int32_t lo = a, hi = b - 1;
+    while (lo < hi) { const int32_t c = lo + (hi - lo + 1) / 2; if (vals[c] <= m) lo = c; else hi = c - 1; }
+    return lo;
+}
+
 int greedy_find_bin(const std::vector<int32_t>& dv, const std::vector<int64_t>& cnt, int max_bin, int64_t total_cnt,
-                    int min_data_in_bin, std::vector<int32_t>& ub) {
+                    int min_data_in_bin, std::vector<int32_t>& ub, const double* vals) {
     const int nd = (int)dv.size();
     ub.clear();
     if (nd <= 0) return 0;
@@ -264,7 +282,7 @@ int greedy_find_bin(const std::vector<int32_t>& dv, const std::vector<int64_t>& 
         int64_t cur = 0;
         for (int i = 0; i + 1 < nd; ++i) {
             cur += cnt[i];
-            if (cur >= min_data_in_bin) { ub.push_back((int32_t)(((int64_t)dv[i] + (int64_t)dv[i + 1]) / 2)); cur = 0; }
+            if (cur >= min_data_in_bin) { ub.push_back(mid_code(dv[i], dv[i + 1], vals)); cur = 0; }
         }
         ub.push_back(INT32_MAX);
         return (int)ub.size();
@@ -300,14 +318,14 @@ int greedy_find_bin(const std::vector<int32_t>& dv, const std::vector<int64_t>& 
     }
     ++bin_cnt;
     for (int i = 0; i + 1 < bin_cnt; ++i) {
-        int32_t v = (int32_t)(((int64_t)upper[i] + (int64_t)lower[i + 1]) / 2);
+        int32_t v = mid_code(upper[i], lower[i + 1], vals);
         if (ub.empty() || ub.back() != v) ub.push_back(v);
     }
     ub.push_back(INT32_MAX);
     return (int)ub.size();
 }
 
-void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const rgbm_params& p, Feat& f) {
+void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const rgbm_params& p, Feat& f, const double* vals) {
     std::vector<int32_t> dv; std::vector<int64_t> dc;
     int64_t seen = 0;
     for (int32_t c = 0; c < n_codes; ++c) if (cnt[c]) { dv.push_back(c); dc.push_back(cnt[c]); seen += cnt[c]; }
@@ -315,7 +333,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
     int mb = p.max_bin - (na > 0 ? 1 : 0) - 1;   // NaN bin, zero bin (FindBinWithZeroAsOneBin)
     if (mb < 1) mb = 1;
     f.n_codes = n_codes; f.has_nan = na > 0 ? 1 : 0;
-    f.V = greedy_find_bin(dv, dc, mb, seen, p.min_data_in_bin, f.ub);
+    f.V = greedy_find_bin(dv, dc, mb, seen, p.min_data_in_bin, f.ub, vals);
 }
 
 
@@ -427,7 +445,17 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     int totbins = 0;
     for (int f = 0; f < F; ++f) {
         Feat& ft = model->feats[f];
-        find_bin(cnt.data() + cnt_off[f], ncod[f], n_train, p, ft);
+        const std::vector<double>* cv = (size_t)cols[f] < tab.col_values.size() ? &tab.col_values[cols[f]] : nullptr;
+        find_bin(cnt.data() + cnt_off[f], ncod[f], n_train, p, ft, (cv && (int32_t)cv->size() == ncod[f] && ncod[f] > 0) ? cv->data() : nullptr);
+        if ((size_t)cols[f] < tab.col_kind.size() && tab.col_kind[cols[f]] == 1) {
+            const unsigned int* cf = cnt.data() + cnt_off[f];
+            bool any = false;
+            for (int32_t c = 0; c < ncod[f]; ++c) any |= cf[c] == 0;
+            if (any) {
+                ft.unseen.assign((size_t)(ncod[f] + 31) / 32, 0u);
+                for (int32_t c = 0; c < ncod[f]; ++c) if (cf[c] == 0) ft.unseen[(size_t)c >> 5] |= 1u << (c & 31);
+            }
+        }
         fmeta[f].V = ft.V; fmeta[f].has_nan = ft.has_nan; fmeta[f].nbins = std::max(ft.V + ft.has_nan, 1); fmeta[f].hoff = totbins;
         totbins += fmeta[f].nbins;
         trivial[f] = (ft.V + ft.has_nan <= 1) || ft.V == 0;
@@ -967,7 +995,7 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
     std::vector<uint8_t> lut(lut_off[F]);
     for (int f = 0; f < F; ++f) {
         const Feat& ft = m->feats[f]; int b = 0;
-        for (int c = 0; c < ncod[f]; ++c) { while (b < ft.V - 1 && c > ft.ub[b]) ++b; lut[lut_off[f] + c] = (uint8_t)(ft.V > 0 ? b : 0); }
+        for (int c = 0; c < ncod[f]; ++c) { while (b < ft.V - 1 && c > ft.ub[b]) ++b; lut[lut_off[f] + c] = ft.is_unseen(c) ? (uint8_t)255 : (uint8_t)(ft.V > 0 ? b : 0); }
     }
     dm->nodes.alloc(nodes.size()); dm->nodes.upload(nodes.data(), nodes.size(), s);
     dm->leaf_value.alloc(lv.size()); dm->leaf_value.upload(lv.data(), lv.size(), s);
@@ -1014,9 +1042,15 @@ void put(std::vector<uint8_t>& b, const void* p, size_t n) { const uint8_t* c = 
 
 std::vector<uint8_t> serialise(const rgbm_model& m) {
     std::vector<uint8_t> b;
-    int32_t hdr[7] = {0x4D424752, 1, m.objective, m.num_class, m.K, m.n_iter, m.F};
+    // version 2 = version 1 + the unseen-category bitmap of every feature; written only when a feature has one
+    int32_t ver = 1;
+    for (const Feat& f : m.feats) if (!f.unseen.empty()) ver = 2;
+    int32_t hdr[7] = {0x4D424752, ver, m.objective, m.num_class, m.K, m.n_iter, m.F};
     put(b, hdr, sizeof(hdr));
-    for (const Feat& f : m.feats) { int32_t h3[3] = {f.n_codes, f.V, f.has_nan}; put(b, h3, sizeof(h3)); put(b, f.ub.data(), 4 * (size_t)f.V); }
+    for (const Feat& f : m.feats) {
+        int32_t h3[3] = {f.n_codes, f.V, f.has_nan}; put(b, h3, sizeof(h3)); put(b, f.ub.data(), 4 * (size_t)f.V);
+        if (ver == 2) { int32_t nw = (int32_t)f.unseen.size(); put(b, &nw, 4); put(b, f.unseen.data(), 4 * (size_t)nw); }
+    }
     for (const Tree& t : m.trees) {
         const size_t n = (size_t)t.L - 1;
         put(b, &t.L, 4);
@@ -1128,6 +1162,24 @@ RGBM_EXPORT int rgbm_host_alloc(size_t bytes, void** out) {
 }
 
 RGBM_EXPORT void rgbm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+RGBM_EXPORT int rgbm_table_set_column_kind(rgbm_table* t, int32_t col, int32_t kind) {
+    if (!t || col < 0 || col >= t->c || kind < 0 || kind > 1) return fail(RGBM_ERR_ARG, "rgbm_table_set_column_kind: bad argument");
+    if (t->col_kind.size() < (size_t)t->c) t->col_kind.resize(t->c, 0);
+    t->col_kind[col] = (uint8_t)kind;
+    return RGBM_OK;
+}
+
+RGBM_EXPORT int rgbm_table_set_column_values(rgbm_table* t, int32_t col, const double* values, int32_t n) {
+    if (!t || col < 0 || col >= t->c || n < 0 || (n > 0 && !values)) return fail(RGBM_ERR_ARG, "rgbm_table_set_column_values: bad argument");
+    return guarded([&]() {
+        if (n != 0 && n != t->n_codes[col]) throw std::invalid_argument("rgbm_table_set_column_values: one value per code of the column is needed");
+        for (int i = 1; i < n; ++i) if (!(values[i - 1] < values[i])) throw std::invalid_argument("rgbm_table_set_column_values: values must be strictly ascending");
+        if (t->col_values.size() < (size_t)t->c) t->col_values.resize(t->c);
+        t->col_values[col].assign(values, values + n);
+        return RGBM_OK;
+    });
+}
 
 RGBM_EXPORT void rgbm_table_free(rgbm_table* t) { if (t) { (void)hipSetDevice(t->device); delete t; } }
 
@@ -1278,7 +1330,7 @@ RGBM_EXPORT int rgbm_model_load(const void* buf, size_t len, rgbm_model** out) {
         auto need = [&](size_t n) { if ((size_t)(end - p) < n) throw std::length_error("truncated model"); };
         try {
             need(28); int32_t hdr[7]; memcpy(hdr, p, 28); p += 28;
-            if (hdr[0] != 0x4D424752 || hdr[1] != 1) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad magic/version");
+            if (hdr[0] != 0x4D424752 || (hdr[1] != 1 && hdr[1] != 2)) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad magic/version");
             std::unique_ptr<rgbm_model> m(new rgbm_model());
             m->objective = hdr[2]; m->num_class = hdr[3]; m->K = hdr[4]; m->n_iter = hdr[5]; m->F = hdr[6];
             if (m->F < 0 || m->K < 1 || m->n_iter < 0 || m->F > 65535) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad header");
@@ -1294,6 +1346,11 @@ RGBM_EXPORT int rgbm_model_load(const void* buf, size_t len, rgbm_model** out) {
                 f.n_codes = h3[0]; f.V = h3[1]; f.has_nan = h3[2];
                 if (f.V < 0 || f.V > 255) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad bin count");
                 need(4 * (size_t)f.V); f.ub.resize(f.V); memcpy(f.ub.data(), p, 4 * (size_t)f.V); p += 4 * (size_t)f.V;
+                if (hdr[1] == 2) {
+                    need(4); int32_t nw; memcpy(&nw, p, 4); p += 4;
+                    if (nw < 0 || (nw != 0 && (f.n_codes < 0 || nw != (f.n_codes + 31) / 32))) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad unseen-category bitmap");
+                    need(4 * (size_t)nw); f.unseen.resize(nw); memcpy(f.unseen.data(), p, 4 * (size_t)nw); p += 4 * (size_t)nw;
+                }
             }
             m->trees.resize((size_t)m->n_iter * m->K);
             for (Tree& t : m->trees) {

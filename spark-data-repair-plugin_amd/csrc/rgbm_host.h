@@ -92,6 +92,8 @@ void model_shape(const rgbm_model* m, int32_t* objective, int32_t* num_class, in
 struct rgbm_table {
     int device = 0; int64_t n = 0; int32_t c = 0;
     std::vector<int32_t> n_codes;
+    std::vector<std::vector<double>> col_values;   // NUMERIC columns: the ascending distinct values behind the codes (rgbm_table_set_column_values)
+    std::vector<uint8_t> col_kind;                 // 1 = CATEGORICAL column (rgbm_table_set_column_kind): unseen categories are missing for a model
     rgh::DevBuf<int32_t> codes;
     // result of the last rgbm_table_detect_* call (rgbm_prep.hip): cells (row, column), device resident
     rgh::DevBuf<long long> cell_rows; rgh::DevBuf<int32_t> cell_cols; int64_t n_cells = 0;

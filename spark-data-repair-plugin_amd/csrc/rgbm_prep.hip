@@ -509,7 +509,7 @@ RGBM_EXPORT int rgbm_table_gather_rows(const rgbm_table* t, const int64_t* rows,
         for (int64_t i = 0; i < n_rows; ++i) if (rows[i] < 0 || rows[i] >= t->n) throw std::invalid_argument("rgbm_table_gather_rows: row position out of range");
         hipStream_t s = table_stream(*t);
         std::unique_ptr<rgbm_table> o(new rgbm_table());
-        o->device = t->device; o->n = n_rows; o->c = t->c; o->n_codes = t->n_codes;
+        o->device = t->device; o->n = n_rows; o->c = t->c; o->n_codes = t->n_codes; o->col_values = t->col_values; o->col_kind = t->col_kind;
         o->codes.alloc((size_t)n_rows * t->c);
         const long long* d_rows = scr_upload<long long>(*t, 7, reinterpret_cast<const long long*>(rows), (size_t)n_rows, s);
         hipLaunchKernelGGL(k_gather_rows, dim3(nblocks(n_rows, 256), (unsigned)t->c), dim3(256), 0, s, t->codes.p, (long long)t->n, o->codes.p,

@@ -99,6 +99,7 @@ EXPORTED_SYMBOLS = [
     "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
     "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict", "rgbm_table_shape",
     "rgbm_table_repair_pmf", "rgbm_table_read_cells", "rgbm_table_write_cells", "rgbm_host_alloc", "rgbm_host_free",
+    "rgbm_table_set_column_values", "rgbm_table_set_column_kind",
 ]
 
 COMM_ID_BYTES = 128
@@ -372,6 +373,15 @@ class Table:
         out = np.zeros(len(r), np.int32)
         _check(lib().rgbm_table_read_cells(self.h, _p(r, C.c_int64), _p(c2, C.c_int32), C.c_int64(len(r)), _p(out, C.c_int32)), "rgbm_table_read_cells")
         return out
+
+    def set_column_kind(self, col, categorical=True):
+        """CATEGORICAL column: codes that no training row of a model holds are missing for that model (per-model dictionaries)."""
+        _check(lib().rgbm_table_set_column_kind(self.h, C.c_int32(col), C.c_int32(1 if categorical else 0)), "rgbm_table_set_column_kind")
+
+    def set_column_values(self, col, values):
+        """NUMERIC column: the ascending distinct values behind its codes (bin bounds at value midpoints)."""
+        v = np.ascontiguousarray(values, np.float64)
+        _check(lib().rgbm_table_set_column_values(self.h, C.c_int32(col), _p(v, C.c_double), C.c_int32(len(v))), "rgbm_table_set_column_values")
 
     def write_cells(self, rows, cols, codes):
         r, c2, v = np.ascontiguousarray(rows, np.int64), _i32(cols), _i32(codes)

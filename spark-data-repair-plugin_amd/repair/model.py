@@ -625,7 +625,7 @@ class RepairModel():
         frame, info = repair_frame(plan["engine"], input_df, rid, targets=target_columns, base_params=plan["params"],
                                    error_cells=error_cells_df[[rid, "attribute"]], detect_nulls=False,
                                    continuous_columns=[c for c in continous_columns if c in target_columns], train_rows=sample,
-                                   want_details=True, check_unseen=True, search_opts=dict(self.opts) if plan.get("search") else None)
+                                   want_details=True, search_opts=dict(self.opts) if plan.get("search") else None)
         self._last_resident_info = info
         rep = pd.Series(frame["repaired"].to_numpy(dtype=object),
                         index=pd.MultiIndex.from_arrays([frame[rid].to_numpy(), frame["attribute"].to_numpy()]))

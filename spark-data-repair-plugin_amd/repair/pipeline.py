@@ -279,10 +279,8 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
     if unknown:
         raise ValueError("Target attributes not found in the input: %s" % ",".join(unknown))
     indices, remaps, dicts = encode_frame(df, cols)
-    table = engine.upload_dictionaries(indices, remaps)
     pos = {c: i for i, c in enumerate(cols)}
-    cons = [([pos[x] for x in xs], pos[y]) for xs, y in constraints]
-    cells = None
+    cells, given_current = None, None
     if error_cells is not None:
         if row_id not in error_cells.columns or "attribute" not in error_cells.columns:
             raise ValueError("Error cells should have `%s` and `attribute` in columns" % row_id)
@@ -290,6 +288,37 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
         cpos = np.array([pos.get(a, -1) for a in error_cells["attribute"]], np.int64)
         ok = ~np.isnan(rpos) & (cpos >= 0)                      # cells of unknown rows / attributes drop out (join semantics)
         cells = (rpos[ok].astype(np.int64), cpos[ok].astype(np.int32))
+        # The cells are known before the table exists, so they are NULLed here already and values that ONLY they held leave the
+        # dictionaries: the reference counts a target's classes over the frame with the error cells removed (model.py:1005,
+        # count(distinct y)), and num_class enters the softmax hessian factor K / (K - 1) -- a dead class would change every tree.
+        tset = {pos[t] for t in targets}
+        sel = np.isin(cells[1], list(tset))
+        gr, gc = cells[0][sel], cells[1][sel]
+        gv = np.empty(len(gr), object)                          # the values the cells hold now: `current_value` of the result
+        for j in np.unique(gc):
+            m = gc == j
+            idx = indices[j, gr[m]]
+            v = np.empty(int(m.sum()), object)
+            v[idx >= 0] = dicts[j][remaps[j][idx[idx >= 0]]]
+            v[idx < 0] = None
+            gv[m] = v
+        given_current = (gc.astype(np.int64) * len(df) + gr, gv)
+        indices[gc, gr] = -1
+        for j in sorted(tset):
+            live = np.bincount(indices[j][indices[j] >= 0], minlength=len(remaps[j])) > 0
+            if not live.all():
+                live_codes = np.sort(remaps[j][live])                     # surviving old codes, ascending
+                new = np.zeros(len(remaps[j]), np.int32)
+                new[live] = np.searchsorted(live_codes, remaps[j][live]).astype(np.int32)
+                dicts[j] = dicts[j][live_codes]
+                remaps[j] = new
+    table = engine.upload_dictionaries(indices, remaps)
+    for j, c in enumerate(cols):               # numeric columns: bin bounds at the midpoints of the values, like LightGBM on raw numbers
+        if dicts[j].dtype != object and len(dicts[j]) > 0:
+            table.set_column_values(j, dicts[j])
+        elif dicts[j].dtype == object:
+            table.set_column_kind(j, True)     # categories a model's training rows do not show are missing for that model
+    cons = [([pos[x] for x in xs], pos[y]) for xs, y in constraints]
     cont = {}
     for c in continuous_columns:
         if c in pos and c in targets:
@@ -318,8 +347,16 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
         sel = ccols == j
         v = res["repaired_value"][sel]
         repaired[sel] = [int(x) for x in v] if is_int else [float(x) for x in v]
+    current = decode(res["current"], ccols)
+    if given_current is not None and len(rows):
+        key = ccols.astype(np.int64) * len(df) + rows
+        order = np.argsort(given_current[0], kind="stable")
+        at = np.searchsorted(given_current[0][order], key)
+        at = np.clip(at, 0, max(len(order) - 1, 0))
+        hit = given_current[0][order][at] == key if len(order) else np.zeros(len(key), bool)
+        current[hit] = given_current[1][order][at[hit]]
     frame = pd.DataFrame({row_id: df[row_id].to_numpy()[rows], "attribute": np.asarray(cols, object)[ccols],
-                          "current_value": decode(res["current"], ccols), "repaired": repaired})
+                          "current_value": current, "repaired": repaired})
     if res.get("prob") is not None:
         frame["prob"] = res["prob"]
     if want_pmf and len(rows):

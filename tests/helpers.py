@@ -62,10 +62,18 @@ class OracleEngine:
     name = "oracle"
 
     class _Table:
-        def __init__(self, codes, n_codes):
+        def __init__(self, codes, n_codes, values=None, kinds=None):
             self.codes = np.ascontiguousarray(codes, np.int32).copy()
             self.n_codes = np.asarray(n_codes, np.int32)
             self.c, self.n = self.codes.shape
+            self.values = dict(values or {})        # numeric columns: value dictionaries (set_column_values)
+            self.kinds = set(kinds or ())           # categorical columns (set_column_kind)
+
+        def set_column_kind(self, col, categorical=True):
+            (self.kinds.add if categorical else self.kinds.discard)(int(col))
+
+        def set_column_values(self, col, values):
+            self.values[int(col)] = np.asarray(values, np.float64)
 
         # the relational steps of repair.pipeline, restated by oracle/prep.py (same method names as repair._native.Table)
         def detect_nulls(self, cols):
@@ -95,7 +103,7 @@ class OracleEngine:
             return P.rows_of_cells(self.n, rows)
 
         def gather_rows(self, rows):
-            return OracleEngine._Table(self.codes[:, np.asarray(rows, np.int64)], self.n_codes)
+            return OracleEngine._Table(self.codes[:, np.asarray(rows, np.int64)], self.n_codes, self.values, self.kinds)
 
         def count_codes(self, col):
             from oracle import prep as P
@@ -125,8 +133,10 @@ class OracleEngine:
         from oracle import oracle as O
         rows = table.codes[target] >= 0
         p = {k: v for k, v in params.items() if k != "device_id"}
+        fv = {i: table.values[f] for i, f in enumerate(feats) if f in table.values}
         m = O.train(np.ascontiguousarray(table.codes[feats][:, rows]), table.n_codes[feats], table.codes[target][rows],
-                    int(table.n_codes[target]), y_value=y_value, class_weight=class_weight, **p)
+                    int(table.n_codes[target]), y_value=y_value, class_weight=class_weight, feature_values=fv or None,
+                    categorical=[i for i, f in enumerate(feats) if f in table.kinds] or None, **p)
         return (m, {"hist_ms": 0.0, "hist_bytes": 0, "hist_launches": 0, "root_ms": 0.0, "root_rows": 0}) if want_stats else m
 
     def train_row_sharded(self, shard_table, target, feats, class_weight, params, y_value=None, want_stats=False):

@@ -206,3 +206,69 @@ def test_build_model_hp_search_runs_on_gpu_and_matches_oracle_backend():
     assert mg is not None and mo is not None and sg == so
     assert mg.booster_bytes_ == mo.booster_bytes_
     assert np.array_equal(mg.predict_proba(X), mo.predict_proba(X))
+
+
+def test_numeric_columns_bin_at_value_midpoints_like_the_oracle():
+    """rgbm_table_set_column_values: with the value dictionary of a numeric column the bin bounds sit at the midpoints of the VALUES
+    (LightGBM on raw numbers), which only shows for codes that no training row holds.  HIP == oracle, and the bounds differ from the
+    code-midpoint ones exactly where the values are unevenly spaced."""
+    from oracle import oracle as O
+    from repair import _native as N
+    rng = np.random.default_rng(211)
+    n = 30000
+    vals0 = np.cumsum(rng.exponential(1.0, 40) ** 3 + 0.01)            # very unevenly spaced
+    x0 = rng.integers(0, 40, n).astype(np.int32)
+    x0[x0 % 3 == 1] = (x0[x0 % 3 == 1] + 1) % 40                       # codes = 1 mod 3 never occur among the training rows
+    x1 = rng.integers(0, 6, n).astype(np.int32)
+    y = ((vals0[x0] > np.median(vals0)).astype(np.int32) + x1) % 3
+    tab = np.ascontiguousarray(np.stack([x0, x1, y.astype(np.int32)]))
+    cards = np.asarray([40, 6, 3], np.int32)
+    kw = dict(objective=1, num_class=3, n_estimators=6, learning_rate=0.3, min_data_in_leaf=5)
+    cw = np.ones(3)
+    t = N.Table(tab, cards)
+    plain = t.train(2, [0, 1], class_weight=cw, **kw).save()
+    t.set_column_values(0, vals0)
+    withv = t.train(2, [0, 1], class_weight=cw, **kw).save()
+    mo = O.train(tab[:2], cards[:2], tab[2], 3, class_weight=cw, feature_values={0: vals0}, **kw).save()
+    assert withv == mo
+    assert plain == O.train(tab[:2], cards[:2], tab[2], 3, class_weight=cw, **kw).save()
+    assert withv != plain
+    g = t.gather_rows(np.arange(0, n, 2))                               # row gathers inherit the dictionary
+    assert g.train(2, [0, 1], class_weight=cw, **kw).save() == O.train(np.ascontiguousarray(tab[:2, ::2]), cards[:2], tab[2, ::2], 3, class_weight=cw,
+                                                                         feature_values={0: vals0}, **kw).save()
+
+
+def test_categorical_columns_record_unseen_codes_like_the_oracle():
+    """rgbm_table_set_column_kind: a model trained from a table whose column is CATEGORICAL records the codes none of its training rows
+    held (format version 2) and scores them as missing.  Same bytes and same predictions as the oracle; without the marking the
+    model is version 1 and bins the unseen code next to its neighbours."""
+    import struct
+    from oracle import oracle as O
+    from repair import _native as N
+    rng = np.random.default_rng(223)
+    n = 20000
+    x0 = rng.integers(0, 12, n).astype(np.int32)
+    x1 = rng.integers(0, 5, n).astype(np.int32)
+    y = ((x0 // 3) + x1) % 4
+    y = y.astype(np.int32)
+    hold = (x0 == 7) | (x0 == 2)                                 # rows holding codes 2 / 7 of x0 lose their label: not training rows
+    ytab = np.where(hold, -1, y).astype(np.int32)
+    tab = np.ascontiguousarray(np.stack([x0, x1, ytab]))
+    cards = np.asarray([12, 5, 4], np.int32)
+    kw = dict(objective=1, num_class=4, n_estimators=5, learning_rate=0.3, min_data_in_leaf=5)
+    cw = np.ones(4)
+    t = N.Table(tab, cards)
+    plain = t.train(2, [0, 1], class_weight=cw, **kw)
+    t.set_column_kind(0, True)
+    cat = t.train(2, [0, 1], class_weight=cw, **kw)
+    rows = ~hold
+    mo = O.train(np.ascontiguousarray(tab[:2][:, rows]), cards[:2], tab[2][rows], 4, class_weight=cw, categorical=[0], **kw)
+    assert cat.save() == mo.save()
+    assert struct.unpack_from("2i", cat.save(), 0)[1] == 2 and struct.unpack_from("2i", plain.save(), 0)[1] == 1
+    X = np.ascontiguousarray(tab[:2])
+    pg, po = cat.predict(X), mo.predict(X)
+    assert np.array_equal(pg, po)
+    Xm = X.copy(); Xm[0][hold] = -1                              # an unseen category scores exactly like a missing value
+    assert np.array_equal(pg, cat.predict(Xm))
+    assert not np.array_equal(pg[hold], plain.predict(X)[hold])
+    assert N.Model.load(cat.save()).save() == cat.save()

@@ -79,20 +79,11 @@ def test_continuous_and_integral_targets_boston(oracle_backend):
     df = frame(g["input"])
     a, b = _both_paths(df, OracleEngine(), **{"model.lgb.n_estimators": "20"})
     assert set(a["attribute"]) >= {"CRIM", "RAD"} and len(a) > 20
-    a, b = _sorted(a), _sorted(b)
-    pd.testing.assert_frame_equal(a.drop(columns=["repaired"]), b.drop(columns=["repaired"]))
-    # The two paths build different dictionaries for CONTINUOUS FEATURES: the value-space path one per model (the distinct values of
-    # that model's training rows, an unseen number goes to its nearest entry), the resident table one per column (every row).  A
-    # dirty row whose feature value occurs nowhere else (CRIM is nearly unique per row) is therefore binned by the nearest-value
-    # rule on one side and by the code midpoint on the other, and a few percent of the predictions move to the neighbouring leaf.
-    # Discrete attributes and the bulk of the continuous ones must agree exactly; the rest must stay close.
-    va, vb = a["repaired"].astype(float).to_numpy(), b["repaired"].astype(float).to_numpy()
-    same = va == vb
-    assert same.mean() >= 0.9
-    for attr in set(a["attribute"]):
-        sel = (a["attribute"] == attr).to_numpy()
-        scale = float(pd.to_numeric(df[attr], errors="coerce").std())
-        assert np.abs(va[sel] - vb[sel]).max() <= 0.25 * scale, attr
+    # Numeric FEATURES: the value-space path builds one dictionary per model (the distinct values of its training rows; a number it has
+    # not seen goes to the nearest entry), the resident table one per column.  A dirty row whose CRIM occurs nowhere else is then a code
+    # BETWEEN two training codes; the trainer puts its bin bounds at the midpoints of the values (rgbm_table_set_column_values), which
+    # is the nearest-entry rule -- so both paths give the same numbers, not merely close ones.
+    pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
 
 
 def test_runs_outside_the_plain_loop_keep_the_value_space_path(oracle_backend):
@@ -165,21 +156,39 @@ def test_gpu_run_takes_the_resident_path_and_matches_both_references():
     print("resident run(): %.2fs wall, %.2fs on the device pipeline, host share %.0f %%" % (wall, device, 100 * (1 - device / wall)))
 
 
-def test_unseen_category_in_a_dirty_row_falls_back(oracle_backend):
-    """A dirty row with a feature value no training row of that target shows: the value-space path treats it as missing (it is not in
-    the model's dictionary); the table-wide dictionary would code it like any value, so the run keeps the value-space path."""
+def test_unseen_category_in_a_dirty_row_is_missing_for_the_model(oracle_backend):
+    """A dirty row with a feature value no training row of that target shows.  The value-space path treats it as missing (it is not in
+    the model's dictionary).  The table-wide dictionary does hold it, so the column is marked CATEGORICAL (rgbm_table_set_column_kind)
+    and the model records the codes its training rows never showed: same prediction on both paths, through the resident one."""
     df, _, _, _ = _synthetic_frame(1500, 5, seed=17)
-    i = int(np.flatnonzero(df["c3"].isna().to_numpy())[0])
-    df.loc[i, "c1"] = "only-here"
-    a, b = None, None
-    m = _model(df)
-    m._engine_override = OracleEngine()
-    b = m.run()
-    assert getattr(m, "_last_resident_info", None) is None
+    for k, i in enumerate(np.flatnonzero(df["c3"].isna().to_numpy())[:12]):
+        df.loc[int(i), "c1"] = "only-here-%d" % (k % 3)
+    a, b = _both_paths(df, OracleEngine())
+    pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
+    # ... and the guard that callers without categorical marking can use still sees them
+    from repair.pipeline import UnseenCategories, repair_frame
+    with pytest.raises(UnseenCategories):
+        repair_frame(OracleEngine(), df, "tid", targets=["c3"], base_params=dict(n_estimators=2), check_unseen=True)
+
+
+def test_hospital_config1_through_the_resident_path(oracle_backend):
+    """configs[1]: 1000 rows of typos.  Dirty rows carry categories their target's training rows never show (missing for that model:
+    unseen-category bitmap), and erroneous values that only the error cells held must not count as classes (the dictionaries are built
+    with the given cells already NULLed: num_class enters the softmax hessian factor).  177 repairs, identical on both paths."""
     import os
+    import tests.test_quality as Q
+    from repair.model import RepairModel
     os.environ["REPAIR_RESIDENT"] = "0"
     try:
-        a = _model(df).run()
+        a, _ = Q._run_hospital()
     finally:
         os.environ.pop("REPAIR_RESIDENT", None)
+    prev = RepairModel._resident_engine
+    taken = []
+    RepairModel._resident_engine = lambda self: (taken.append(1), OracleEngine())[1]
+    try:
+        b, _ = Q._run_hospital()
+    finally:
+        RepairModel._resident_engine = prev
+    assert taken and len(a) == len(b) > 150
     pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
