@@ -281,6 +281,26 @@ typedef struct {
 
 static inline int64_t round_int(double x) { return (int64_t)(x + 0.5); }
 
+/* Numerics v1.02 (csrc/rgbm_numerics.h h_from_g): the quantised hessian is a function of the QUANTISED gradient, the row's label
+ * and weight -- the level passes of the product carry g only and recompute h.  obj 0: g = response * w, h = |response|(1 - |response|) w;
+ * obj 1: g = (p - [y is this class]) w, h = factor p (1 - p) w;  obj 2: h = w. */
+#define GQ_MAX_ ((1 << 20) - 1)
+#define HQ_MAX_ ((1 << 21) - 1)
+static int32_t h_from_g(int32_t gq, int is_label_class, double w, int obj, double inv_sg, double sh, double factor) {
+    double h;
+    if (obj == 2) h = w;
+    else {
+        const double inv_w = w > 0.0 ? 1.0 / w : 0.0;          /* the product takes this reciprocal once per label / row */
+        const double a = ((double)gq * inv_sg) * inv_w;
+        if (obj == 0) { const double r = fabs(a); h = r * (1.0 - r) * w; }
+        else { const double p = is_label_class ? a + 1.0 : a; h = factor * p * (1.0 - p) * w; }
+        if (!(h > 0.0)) h = 0.0;
+    }
+    double b = rint(h * sh);
+    if (b > HQ_MAX_) b = HQ_MAX_;
+    return (int32_t)b;
+}
+
 /* FeatureHistogram::FindBestThresholdSequentially, both instantiations used by
  * FuncForNumricalL3 for MissingType::NaN / None, restated over exact integer bin sums.
  * hg/hh: [V + has_nan] bin sums; value bins 0..V-1, NaN bin at V. theta=-1 => only NULLs left. */
@@ -721,12 +741,12 @@ ORC_API int orc_train2(const int32_t* X, int64_t N, int32_t F, const int32_t* n_
                 double label = (y_code[i] > 0) ? 1.0 : -1.0;
                 double response = -label / (1.0 + rg_exp(label * score[i]));
                 double abs_r = fabs(response);
-                double g = response * wi, h = abs_r * (1.0 - abs_r) * wi;
-                double a = rint(g * sg), b = rint(h * sh);
+                (void)abs_r;
+                double g = response * wi;
+                double a = rint(g * sg);
                 if (a > GQ_MAX) a = GQ_MAX;
                 if (a < -GQ_MAX) a = -GQ_MAX;
-                if (b > HQ_MAX) b = HQ_MAX;
-                gq[i] = (int32_t)a; hq[i] = (int32_t)b;
+                gq[i] = (int32_t)a; hq[i] = h_from_g((int32_t)a, 0, wi, 0, t.ctx.inv_sg, sh, factor);
             } else if (obj == 1) {
                 double wmax = score[i];
                 for (int k = 1; k < K; ++k) { double s = score[(size_t)k * N + i]; if (s > wmax) wmax = s; }
@@ -735,12 +755,11 @@ ORC_API int orc_train2(const int32_t* X, int64_t N, int32_t F, const int32_t* n_
                 for (int k = 0; k < K; ++k) {
                     double pk = rec[k] / wsum;
                     double g = ((y_code[i] == k) ? (pk - 1.0) : pk) * wi;
-                    double h = factor * pk * (1.0 - pk) * wi;
-                    double a = rint(g * sg), b = rint(h * sh);
+                    double a = rint(g * sg);
                     if (a > GQ_MAX) a = GQ_MAX;
                     if (a < -GQ_MAX) a = -GQ_MAX;
-                    if (b > HQ_MAX) b = HQ_MAX;
-                    gq[(size_t)k * N + i] = (int32_t)a; hq[(size_t)k * N + i] = (int32_t)b;
+                    gq[(size_t)k * N + i] = (int32_t)a;
+                    hq[(size_t)k * N + i] = h_from_g((int32_t)a, y_code[i] == k, wi, 1, t.ctx.inv_sg, sh, factor);
                 }
             } else {
                 double g = (score[i] - y_value[y_code[i]]) * wi, h = wi;

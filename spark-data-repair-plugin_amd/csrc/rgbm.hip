@@ -31,7 +31,7 @@
 #include "rgbm_kernels.h"
 #include "rgbm_level.h"
 
-#define RGBM_VERSION 101   // numerics spec v1.01 (hessian scale: exact when the bound is a power of two)
+#define RGBM_VERSION 102   // numerics spec v1.02 (v1.01: hessian scale exact for power-of-two bounds; v1.02: h derived from the quantised g)
 
 namespace {
 
@@ -555,7 +555,23 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         d_base.alloc(n_train);
         hipLaunchKernelGGL(k_iota_train, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, (long long)N, d_base.p, d_counter.p);
     }
-    DevBuf<int2> d_gh((size_t)K * N); d_gh.zero(s);
+    // Split mode decision (needed here: it picks the layout of the gradient buffer).  Split mode (route + stream kernels) pays off once a
+    // level pass is bound by its traffic / LDS atomics rather than by launch latency; small fits keep the fused pass (one launch fewer
+    // per level).  RGBM_LEVEL_SPLIT=0/1 overrides.
+    bool split_mode = level_mode && p.max_depth >= 2 && (long long)K * N >= (1ll << 21);
+    if (const char* e = getenv("RGBM_LEVEL_SPLIT")) split_mode = level_mode && p.max_depth >= 2 && atoi(e) != 0;
+    // g-only gradient buffer (numerics v1.02: h is a function of the quantised g, the label and its weight): the level passes of split
+    // mode then stream 4 B instead of 8 per (row, class tree).  Needs byte labels and per-label weights (<= 128 labels) only.  RGBM_G_ONLY=0 disables it.
+    // (regression + bagging keeps (g,h): an out-of-bag row has g = 0 like an in-bag row with a zero residual, but must not add its h = w)
+    bool g_only = split_mode && !sample_weight_host && n_y <= 128 && !(obj == 2 && use_bagging);
+    if (const char* e = getenv("RGBM_G_ONLY")) g_only = g_only && atoi(e) != 0;
+    tc.g_only = g_only ? 1 : 0;
+    DevBuf<int2> d_gh(g_only ? ((size_t)K * N + 1) / 2 : (size_t)K * N); d_gh.zero(s);
+    DevBuf<uint8_t> d_ylab; DevBuf<double> d_cw32;
+    if (g_only) {
+        d_ylab.alloc(N);
+        hipLaunchKernelGGL(k_ylab, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, (long long)N, d_ylab.p);
+    }
     DevBuf<double> d_score((size_t)K * N), d_init(K);
     d_init.upload(init.data(), K, s);
     hipLaunchKernelGGL(k_init_score, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_score.p, (long long)N, K, d_init.p);
@@ -572,7 +588,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout, d_lay_table; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
-    bool split_mode = false;
     bool use_reduce = false;   // sum the per-workgroup partials in a separate kernel (many workgroups per class tree, or row-sharded)
     // Experiment (RGBM_LAZY_SCORE=1, off): defer AddScore into the next iteration's gradient kernel so that the scores are touched
     // once per iteration.  Measured on MI355X (K=64, 10M rows): k_level_final 2.48 -> 0.70 ms, but the per-(row, class) gather of
@@ -600,17 +615,33 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         lc.gx = (int)gx; lc.max_built = 1 << std::max(0, p.max_depth - 2); lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
         lc.num_leaves = NL; lc.max_depth = p.max_depth; lc.min_data_in_leaf = p.min_data_in_leaf; lc.N = N; lc.NS = (N + 15) & ~15ll;
         n_hnodes = (1 << p.max_depth) - 1;
-        // Split mode (route + list-accumulate kernels) pays off once a level pass is bound by its traffic / LDS atomics rather
-        // than by launch latency; small fits keep the fused pass (one launch fewer per level).  RGBM_LEVEL_SPLIT=0/1 overrides.
-        split_mode = p.max_depth >= 2 && (long long)K * N >= (1ll << 21);
-        if (const char* e = getenv("RGBM_LEVEL_SPLIT")) split_mode = p.max_depth >= 2 && atoi(e) != 0;
         lc.split_mode = split_mode ? 1 : 0;
+        lc.inv_sg = tc.inv_sg; lc.sh = tc.sh; lc.factor = tc.factor; lc.objective = obj; lc.n_labels = n_y;
+        if (split_mode) {
+            // Row blocks instead of strided tiles (k_level_pass): a multiple of 8 blocks per class tree (one XCD each).  Every block costs
+            // a workgroup's set-up, pipeline ramp and flush (~10-20 us), every round of 256 workgroups ends with a tail; measured at
+            // K = 64 (10M rows): 8 blocks 23.0, 16 blocks 21.0, 40 blocks 23.2 ms per iteration.  So: about four rounds when the class
+            // trees alone nearly fill the chip (>= 16 of them), else the fewest blocks that fill one round; the multiple of 8 with the
+            // best last-round occupancy, the smallest among equals.  RGBM_LV_BLOCKS overrides.
+            auto eff_of = [&](long long g) { const long long tot = g * per, rounds = (tot + cu_slots - 1) / cu_slots; return (double)tot / (double)(rounds * cu_slots); };
+            const long long gfloor = std::max<long long>(8, (gmin + 7) / 8 * 8), gcap = std::max<long long>(gfloor, std::min<long long>(512, (ntiles + 7) / 8 * 8));
+            long long g2 = gfloor; double best2 = -1.0;
+            for (long long g = gfloor; g <= gcap; g += 8) {
+                if (per >= 16 && (g * per < 3 * cu_slots || g * per > 5 * cu_slots)) continue;
+                const double e = eff_of(g);
+                if (e > best2 + 1e-9) { best2 = e; g2 = g; }
+                if (e >= 0.99) break;
+            }
+            if (best2 < 0.0) for (long long g = gfloor; g <= gcap; g += 8) { const double e = eff_of(g); if (e > best2 + 1e-9) { best2 = e; g2 = g; } if (e >= 0.99) break; }
+            if (const char* e = getenv("RGBM_LV_BLOCKS")) { long long v = atoll(e); if (v >= 1) g2 = (v + 7) / 8 * 8; }
+            lc.gx = (int)g2;
+        }
         lc.sib_local = (dp && g_comm.rank == 0) ? 1 : 0;
         d_node_a.alloc((size_t)K * lc.NS);
         if (!split_mode) d_node_b.alloc((size_t)K * lc.NS);            // split mode routes in place
 
         d_plan.alloc(K); d_layout.alloc((size_t)K * nchunk); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
-        d_part.alloc((size_t)K * gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
+        d_part.alloc((size_t)K * lc.gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
         d_count.alloc((size_t)K * 256); use_reduce = dp || lc.gx > 4;
         if (dp) d_count_g.alloc((size_t)K * 256);
         if (use_reduce) { d_part_red.alloc((size_t)K * lc.max_built * tc.totbins + (size_t)K * 128 /* K*256 int64 counts */); }
@@ -644,6 +675,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
@@ -652,6 +686,12 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     TreeOut to{t_L.p, t_feat.p, t_theta.p, t_dleft.p, t_left.p, t_right.p, t_gain.p, t_val.p, t_cnt.p};
     DevBuf<double> d_cw, d_yv, d_sw;
     if (class_weight) { d_cw.alloc(n_y); d_cw.upload(class_weight, n_y, s); }
+    std::vector<double> cw32h;
+    if (g_only && class_weight) {   // the weight a row of label c carries: float32-rounded, as the gradient kernels round it
+        cw32h.resize(n_y); for (int c = 0; c < n_y; ++c) cw32h[c] = (double)(float)class_weight[c];
+        d_cw32.alloc(n_y); d_cw32.upload(cw32h.data(), n_y, s);
+        HIPCHK(hipStreamSynchronize(s));
+    }
     if (y_value) { d_yv.alloc(n_y); d_yv.upload(y_value, n_y, s); }
     if (sample_weight_host) { d_sw.alloc(N); d_sw.upload(sample_weight_host, N, s); }
 
@@ -731,15 +771,19 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const bool timed = stats && with_hist;
         if (split_mode && !root) launch_route();
         if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
-#define RGBM_LAUNCH_PASS2(R, B, M, S, INBAG)                                                                                                    \
-        hipLaunchKernelGGL((k_level_pass<R, B, M, S>), dim3(lc.gx, K, gz), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, node_b_p, \
-                           (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc)
+        const dim3 pass_grid = split_mode ? dim3((unsigned)lc.gx * (unsigned)K, 1, gz) : dim3(lc.gx, K, gz);
+#define RGBM_LAUNCH_PASS3(R, B, M, S, G, INBAG)                                                                                                 \
+        hipLaunchKernelGGL((k_level_pass<R, B, M, S, G>), pass_grid, dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, node_b_p, \
+                           (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc,          \
+                           (const uint8_t*)d_ylab.p, (const double*)(d_cw32.n ? d_cw32.p : nullptr))
+#define RGBM_LAUNCH_PASS2(R, B, M, S, INBAG) RGBM_LAUNCH_PASS3(R, B, M, S, false, INBAG)
 #define RGBM_LAUNCH_PASS(R, B, M, INBAG) RGBM_LAUNCH_PASS2(R, B, M, false, INBAG)
         // chunk layout: 0 = one 16-feature chunk, 2 = exactly two (both records prefetched), 3 = more
-        if (root) { RGBM_LAUNCH_PASS(true, false, 0, nullptr); }
+        if (root) { if (g_only) RGBM_LAUNCH_PASS3(true, false, 0, false, true, nullptr); else RGBM_LAUNCH_PASS(true, false, 0, nullptr); }
         else if (split_mode) {
-            if (use_bagging) RGBM_LAUNCH_PASS2(false, true, 0, true, d_inbag.p); else RGBM_LAUNCH_PASS2(false, false, 0, true, nullptr);
-            if (const char* e = getenv("RGBM_DBG_STREAM")) {   // timing experiment: throw-away launches of the stream pass without batches (1) / without ring appends (2)
+            if (g_only) { if (use_bagging) RGBM_LAUNCH_PASS3(false, true, 0, true, true, d_inbag.p); else RGBM_LAUNCH_PASS3(false, false, 0, true, true, nullptr); }
+            else if (use_bagging) RGBM_LAUNCH_PASS2(false, true, 0, true, d_inbag.p); else RGBM_LAUNCH_PASS2(false, false, 0, true, nullptr);
+            if (const char* e = g_only ? nullptr : getenv("RGBM_DBG_STREAM")) {   // timing experiment: throw-away launches of the stream pass without batches (1) / without ring appends (2)
                 for (int mode = 1; mode <= atoi(e); ++mode) { lc.pad0 = mode; RGBM_LAUNCH_PASS2(false, false, 0, true, nullptr); }
                 lc.pad0 = 0;
             }
@@ -748,6 +792,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         else { if (nchunk == 1) RGBM_LAUNCH_PASS(false, false, 0, nullptr); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, false, 2, nullptr); else RGBM_LAUNCH_PASS(false, false, 3, nullptr); }
 #undef RGBM_LAUNCH_PASS
 #undef RGBM_LAUNCH_PASS2
+#undef RGBM_LAUNCH_PASS3
         if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
 

@@ -59,6 +59,7 @@ struct TrainConst {
     double l1, l2, min_gain_to_split, min_sum_hessian, learning_rate, factor;
     int32_t min_data_in_leaf, max_depth, num_leaves, F, K, totbins, nchunk, objective;
     long long N, n_train;
+    int32_t g_only, pad_;    // 1: the gradient kernels store the quantised gradient only (int32 [K][N]); the level passes recompute h (h_from_g)
 };
 
 // packed tree node for the predictor: one 8-byte load per visit

@@ -23,6 +23,11 @@ namespace rg {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// (g, h) of one (row, class tree): int2 [K][N], or -- TrainConst::g_only -- the gradient alone as int32 [K][N] in the same buffer
+__device__ __forceinline__ void store_gh(int2* gh, long long idx, int gq, int hq, int g_only) {
+    if (g_only) reinterpret_cast<int32_t*>(gh)[idx] = gq; else gh[idx] = make_int2(gq, hq);
+}
+
 struct TreeOut {   // flat device arrays of every tree of the model, [(it*K+k)] major
     int32_t* L; int32_t* feat; int32_t* theta; int32_t* dleft; int32_t* left; int32_t* right; double* gain;
     double* leaf_value; int32_t* leaf_count;
@@ -80,6 +85,12 @@ __global__ __launch_bounds__(256) void k_pack_bins(const int32_t* __restrict__ c
     }
 }
 
+// labels as bytes for the g-only level passes: 255 = not a training row
+__global__ __launch_bounds__(256) void k_ylab(const int32_t* __restrict__ ycol, long long N, uint8_t* __restrict__ ylab) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) { const int y = ycol[i]; ylab[i] = (y < 0 || y > 254) ? (uint8_t)255 : (uint8_t)y; }
+}
+
 __global__ void k_iota_train(const int32_t* __restrict__ ycol, long long N, int32_t* __restrict__ out, unsigned int* __restrict__ counter) {
     // unstable compaction of training rows (order is irrelevant: every sum downstream is an exact integer)
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,21 +129,23 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
         if (y < 0) continue;   // not a training row: its gh stays 0 for ever
         if (row_in_bag && !row_in_bag[i]) {   // out of bag this round: contributes nothing to any histogram
             const int K = (OBJ == 1) ? c.K : 1;
-            for (int k = 0; k < K; ++k) gh[(long long)k * N + i] = make_int2(0, 0);
+            for (int k = 0; k < K; ++k) store_gh(gh, (long long)k * N + i, 0, 0, c.g_only);
             continue;
         }
         double wi = class_w ? class_w[y] : 1.0;
         if (sample_w) wi = wi * sample_w[i];
         wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
+        const double inv_wi = rg_inv_weight(wi); (void)inv_wi;
         if (OBJ == 0) {
             double label = (y > 0) ? 1.0 : -1.0;
             double response = -label / (1.0 + rg_exp(label * score[i]));
             double abs_r = fabs(response);
-            double g = response * wi, h = abs_r * (1.0 - abs_r) * wi;
-            gh[i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+            (void)abs_r;
+            const int gq = quant_g(response * wi, c.sg);
+            store_gh(gh, i, gq, c.g_only ? 0 : h_from_g(gq, false, wi, rg_inv_weight(wi), 0, c.inv_sg, c.sh, c.factor), c.g_only);
         } else if (OBJ == 2) {
             double g = (score[i] - y_value[y]) * wi, h = wi;
-            gh[i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+            store_gh(gh, i, quant_g(g, c.sg), quant_h(h, c.sh), c.g_only);
         } else {
             const int K = c.K;
             double wmax = score[i];
@@ -141,9 +154,8 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
             for (int k = 0; k < K; ++k) wsum += rg_exp(score[(long long)k * N + i] - wmax);
             for (int k = 0; k < K; ++k) {
                 double pk = rg_exp(score[(long long)k * N + i] - wmax) / wsum;
-                double g = ((y == k) ? (pk - 1.0) : pk) * wi;
-                double h = c.factor * pk * (1.0 - pk) * wi;
-                gh[(long long)k * N + i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+                const int gq = quant_g(((y == k) ? (pk - 1.0) : pk) * wi, c.sg);
+                store_gh(gh, (long long)k * N + i, gq, c.g_only ? 0 : h_from_g(gq, y == k, wi, inv_wi, 1, c.inv_sg, c.sh, c.factor), c.g_only);
             }
         }
     }
@@ -219,16 +231,16 @@ __global__ __launch_bounds__(256) void k_grad_mc(double* __restrict__ score, con
     if (wv == 0) { double wsum = 0.0; for (int k = 0; k < K; ++k) wsum += tile[k * 64 + r]; psum[r] = wsum; }
     __syncthreads();
     if (!valid || y < 0) return;    // not a training row: its gh stays 0 for ever
-    if (out_of_bag) { for (int k = wv; k < K; k += 4) gh[(long long)k * N + i] = make_int2(0, 0); return; }
+    if (out_of_bag) { for (int k = wv; k < K; k += 4) store_gh(gh, (long long)k * N + i, 0, 0, c.g_only); return; }
     double wi = class_w ? class_w[y] : 1.0;
     if (sample_w) wi = wi * sample_w[i];
     wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
+        const double inv_wi = rg_inv_weight(wi); (void)inv_wi;
     const double wsum = psum[r];
     for (int k = wv; k < K; k += 4) {
         const double pk = tile[k * 64 + r] / wsum;
-        const double g = ((y == k) ? (pk - 1.0) : pk) * wi;
-        const double h = c.factor * pk * (1.0 - pk) * wi;
-        gh[(long long)k * N + i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+        const int gq = quant_g(((y == k) ? (pk - 1.0) : pk) * wi, c.sg);
+        store_gh(gh, (long long)k * N + i, gq, c.g_only ? 0 : h_from_g(gq, y == k, wi, inv_wi, 1, c.inv_sg, c.sh, c.factor), c.g_only);
     }
 }
 
@@ -255,17 +267,17 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ s
         for (int kk = 0; kk < K; ++kk) node0[(long long)kk * NS + i] = v;
     }
     if (y < 0) return;
-    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) gh[(long long)kk * N + i] = make_int2(0, 0); return; }
+    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) store_gh(gh, (long long)kk * N + i, 0, 0, c.g_only); return; }
     double wi = class_w ? class_w[y] : 1.0;
     if (sample_w) wi = wi * sample_w[i];
     wi = (double)(float)wi;
+    const double inv_wi = rg_inv_weight(wi);
     double wsum = 0.0;
     for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
     for (int kk = 0; kk < K; ++kk) {
         const double pk = tile[kk * R] / wsum;
-        const double g = ((y == kk) ? (pk - 1.0) : pk) * wi;
-        const double h = c.factor * pk * (1.0 - pk) * wi;
-        gh[(long long)kk * N + i] = make_int2(quant_g(g, c.sg), quant_h(h, c.sh));
+        const int gq = quant_g(((y == kk) ? (pk - 1.0) : pk) * wi, c.sg);
+        store_gh(gh, (long long)kk * N + i, gq, c.g_only ? 0 : h_from_g(gq, y == kk, wi, inv_wi, 1, c.inv_sg, c.sh, c.factor), c.g_only);
     }
 }
 

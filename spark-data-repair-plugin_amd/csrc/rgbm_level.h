@@ -96,6 +96,9 @@ struct LevelConst {
     int32_t split_mode;          // 1: route + stream-accumulate kernels (k_level_route / k_level_pass<STREAM>); sibling counts are parent - built
     int32_t sib_local;           // split mode: k_level_split also writes the derived sibling count into the LOCAL count array (row-sharded: rank 0 only)
     long long N, NS;   // rows; row stride of the node-id arrays (multiple of 16)
+    // GONLY passes (split mode): the gradient buffer holds int32 g only; h = h_from_g(g, label, weight) for the rows that are accumulated
+    double inv_sg, sh, factor;
+    int32_t objective, n_labels;
 };
 
 __device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
@@ -184,15 +187,32 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
 //         instruction of LDS atomics costs the same for 6 active lanes as for 64 (profiles/r01_lds_atomic_active_lanes.txt),
 //         and a built child holds ~12 % of the rows: the fused pass pays that instruction for every 64-row step, this one
 //         for every 64 built rows.  Rows per built child are counted here; the sibling is parent - built (k_level_split).
-template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */, bool STREAM = false>
+//   GONLY: the (g,h) buffer holds the quantised gradient alone (int32 [K][N], TrainConst::g_only): the pass streams 4 B instead of 8 per
+//         (row, class tree) and derives h from g, the row's label (u8 `ylab`) and the label's weight (`cw32`, float32-rounded; LDS copy)
+//         for the rows it accumulates -- numerics v1.02 defines h that way for every path, so the histograms are the same integers.
+template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */, bool STREAM = false, bool GONLY = false>
 __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
                                                            uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
                                                            const LvLayout* __restrict__ layout, HistBin* __restrict__ part,
                                                            int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta,
-                                                           const ChunkMeta* __restrict__ cmeta, int with_hist, LevelConst c) {
+                                                           const ChunkMeta* __restrict__ cmeta, int with_hist, LevelConst c,
+                                                           const uint8_t* __restrict__ ylab = nullptr, const double* __restrict__ cw32 = nullptr) {
+    static_assert(!GONLY || ROOT || STREAM, "g-only buffers exist in split mode only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int k = blockIdx.y, ch = blockIdx.z % c.nchunk, grp = blockIdx.z / c.nchunk;
+    // Block -> (class tree, row block).  Fused mode: grid (gx, K): block x walks the tiles x, x + gx, ... of class tree blockIdx.y.
+    // Split mode: 1-D grid of K * gx blocks (gx a multiple of 8), every block owns a CONTIGUOUS run of tiles, and the decode makes
+    // the launch order walk the table front to back with ALL class trees of a row block on ONE XCD (blocks land on XCD id % 8):
+    //     id -> xl = id % 8,  r = id / 8,  class tree = r % K,  row block = (r / K) * 8 + xl
+    // The class trees re-read the bin records of the rows they accumulate; spread over the chip and drifting apart over a whole
+    // pass they missed L2 half of the time (2-4 GB of a level pass's 8-10 GB).  Now the ~32 workgroups that are resident on an XCD
+    // share one 4 MB slice of records, start together and finish within ~0.2 ms.
+    int k, bx, nbx;
+    if (c.split_mode) {
+        const unsigned id = blockIdx.x, r = id >> 3;
+        k = (int)(r % (unsigned)c.K); bx = (int)(r / (unsigned)c.K) * 8 + (int)(id & 7u); nbx = c.gx;
+    } else { k = blockIdx.y; bx = blockIdx.x; nbx = gridDim.x; }
+    const int ch = blockIdx.z % c.nchunk, grp = blockIdx.z / c.nchunk;
     const LvPlan* pp = &plan[k];
     if (pp->done) return;
     const int n_exp = (ROOT || STREAM) ? 0 : pp->n_exp;
@@ -240,6 +260,8 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
         route[i] = make_uint2(w0, w1);
     }
     if (tid < 4) drain_flag[tid] = 0;
+    double2* wtab = reinterpret_cast<double2*>(route);     // GONLY: (weight, 1 / weight) of every label (<= 128; the route table's 2 KB are free in ROOT / STREAM passes)
+    if (GONLY) for (int i = tid; i < 128; i += LV_THREADS) { const double w = (cw32 && i < c.n_labels) ? cw32[i] : 1.0; wtab[i] = make_double2(w, rg_inv_weight(w)); }
     if (STREAM) {   // k_level_plan numbers the children of expanded parent ei as child_first + 2 ei (left), + 1 (right); one of them is built
         for (int i = tid; i < 256; i += LV_THREADS) {
             const int d = i - pp->child_first;
@@ -277,7 +299,11 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
     const int2* ghk = gh + (long long)k * N;
     const int child_first = pp->child_first;
-    const long long ntiles = (N + LV_TILE - 1) / LV_TILE;
+    const long long ntiles_all = (N + LV_TILE - 1) / LV_TILE;
+    // this block's tiles: t = tbeg, tbeg + tstep, ... < ntiles
+    const long long tbeg = c.split_mode ? ntiles_all * bx / nbx : bx;
+    const long long ntiles = c.split_mode ? ntiles_all * (bx + 1) / nbx : ntiles_all;
+    const long long tstep = c.split_mode ? 1 : nbx;
 
     // Packed-slot overflow control without per-tile barriers.  Every lane keeps the sums of |g| and h it has
     // added since the last drain; a field of any slot is at most 2047 (drain remainder) + the sum over all 1024
@@ -324,7 +350,13 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
     };
 
     // one histogram update of a (row, built node) pair held by this lane: 15-16 packed LDS atomics, 3 instructions each
-    auto accumulate = [&](bool on, int li, const uint4& r, const int2& g) __attribute__((always_inline)) {
+    auto accumulate = [&](bool on, int li, const uint4& r, const int2& g_in) __attribute__((always_inline)) {
+        int2 g = g_in;
+        if (GONLY) {   // g_in = (quantised gradient, label): h is a function of both and of the label's weight (numerics v1.02)
+            const int yl = on ? (g_in.y & 0x7F) : 0;
+            const double2 ww = wtab[yl];
+            g.y = on ? h_from_g(g_in.x, yl == k, ww.x, ww.y, c.objective, c.inv_sg, c.sh, c.factor) : 0;
+        }
         const unsigned long long packed = ((unsigned long long)(long long)g.x << 32) + (unsigned long long)(unsigned int)g.y;
         const bool need = on && packed != 0ull;
         const unsigned ag = (unsigned)(g.x < 0 ? -g.x : g.x), ah = (unsigned)g.y;
@@ -373,7 +405,12 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             const int nv = STREAM ? (int)__builtin_nontemporal_load(nb_ + oc) : (int)nb_[oc];
             if (!STREAM) fr[s] = rb_[oc]; else fr[s] = make_uint4(0, 0, 0, 0);
             if (!ROOT && !STREAM && MULTI == 2) fr2[s] = (rec_other + pb)[oc]; else fr2[s] = make_uint4(0, 0, 0, 0);
-            if (STREAM) { const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long*>(gb_ + oc)); fg[s] = make_int2((int)(v & 0xFFFFFFFFll), (int)(v >> 32)); }
+            if (GONLY) {
+                const int32_t* g32 = reinterpret_cast<const int32_t*>(gh) + (long long)k * N + pb;
+                const int gv = STREAM ? __builtin_nontemporal_load(g32 + oc) : g32[oc];
+                fg[s] = make_int2(gv, ROOT ? (int)ylab[pb + oc] : 0);                 // ROOT: the label rides in the h slot (accumulate)
+            }
+            else if (STREAM) { const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long*>(gb_ + oc)); fg[s] = make_int2((int)(v & 0xFFFFFFFFll), (int)(v >> 32)); }
             else if (ROOT || STREAM || !LV_RING) fg[s] = gb_[oc]; else fg[s] = make_int2(0, 0);
             fib[s] = BAG ? (int)ib_[oc] : 1;
             fn[s] = (tv && o <= lim) ? nv : LV_INACTIVE;
@@ -393,7 +430,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             const bool on = lane < nb;
             int pos = r_head + lane; if (pos >= LV_SRING) pos -= LV_SRING;
             const uint32_t row = ring_r[pos], hw = ring_h[pos];             // h < 2^21 (HQ_MAX): the built slot rides in bits 24..31
-            p_gh = make_int2((int)ring_g[pos], (int)(hw & 0xFFFFFFu));
+            p_gh = make_int2((int)ring_g[pos], GONLY ? (int)ylab[on ? row : 0u] : (int)(hw & 0xFFFFFFu));   // GONLY: (g, label)
             p_rec = recc[on ? row : 0u];
             p_li = on ? (int)(hw >> 24) : -1;
             r_head += nb; if (r_head >= LV_SRING) r_head -= LV_SRING;
@@ -409,7 +446,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
         auto stream_step = [&](long long t, int (&Cn)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT], int (&Xn)[RPT], uint4 (&Xr)[RPT], uint4 (&Xr2)[RPT], int2 (&Xg)[RPT], int (&Xib)[RPT]) __attribute__((always_inline)) {
             const long long p0 = t * LV_TILE;
             if (LV_FLAG_LOAD()) rendezvous();
-            fetch(t + 2 * (long long)gridDim.x, Xn, Xr, Xr2, Xg, Xib);
+            fetch(t + 2 * tstep, Xn, Xr, Xr2, Xg, Xib);
             if (pend) run_batch();
 #pragma unroll
             for (int s = 0; s < RPT; ++s) {
@@ -420,7 +457,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
                 const unsigned long long m = __ballot(built);
                 if (built) {
                     int pos = r_head + r_cnt + (int)__popcll(m & lane_lt); if (pos >= LV_SRING) pos -= LV_SRING; if (pos >= LV_SRING) pos -= LV_SRING;
-                    ring_g[pos] = (uint32_t)Cg[s].x; ring_h[pos] = (uint32_t)Cg[s].y | (bs << 24); ring_r[pos] = (uint32_t)(p0 + o);
+                    ring_g[pos] = (uint32_t)Cg[s].x; ring_h[pos] = (GONLY ? 0u : (uint32_t)Cg[s].y) | (bs << 24); ring_r[pos] = (uint32_t)(p0 + o);
                 }
                 r_cnt += (int)__popcll(m);
             }
@@ -430,13 +467,13 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             if (r_cnt >= 64) take_batch(64);
         };
         int thd_n[RPT], thd_ib[RPT]; uint4 thd_r[RPT], thd_r2[RPT]; int2 thd_g[RPT];
-        long long t = blockIdx.x;
+        long long t = tbeg;
         fetch(t, cur_n, cur_r, cur_r2, cur_g, cur_ib);
-        fetch(t + gridDim.x, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib);
+        fetch(t + tstep, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib);
         while (t < ntiles) {
-            stream_step(t, cur_n, cur_g, cur_ib, thd_n, thd_r, thd_r2, thd_g, thd_ib); t += gridDim.x; if (t >= ntiles) break;
-            stream_step(t, nxt_n, nxt_g, nxt_ib, cur_n, cur_r, cur_r2, cur_g, cur_ib); t += gridDim.x; if (t >= ntiles) break;
-            stream_step(t, thd_n, thd_g, thd_ib, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib); t += gridDim.x;
+            stream_step(t, cur_n, cur_g, cur_ib, thd_n, thd_r, thd_r2, thd_g, thd_ib); t += tstep; if (t >= ntiles) break;
+            stream_step(t, nxt_n, nxt_g, nxt_ib, cur_n, cur_r, cur_r2, cur_g, cur_ib); t += tstep; if (t >= ntiles) break;
+            stream_step(t, thd_n, thd_g, thd_ib, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib); t += tstep;
         }
         if (pend) run_batch();
         while (r_cnt > 0) { take_batch(r_cnt < 64 ? r_cnt : 64); run_batch(); }
@@ -449,7 +486,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
             // one poll of the drain flag per tile, before this tile's atomics are queued: an LDS read returns behind every
             // LDS atomic issued before it, so polling inside the row steps would serialise the atomics of consecutive steps
             if (ng > 0 && LV_FLAG_LOAD()) rendezvous();
-            fetch(t + gridDim.x, Xn, Xr, Xr2, Xg, Xib);
+            fetch(t + tstep, Xn, Xr, Xr2, Xg, Xib);
             uint8_t* ob_ = node_out + p0;
 #pragma unroll
             for (int s = 0; s < RPT; ++s) {
@@ -491,11 +528,11 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
                 if (ng > 0) accumulate(li != 0xFF, li, Cr[s], Cg[s]);
             }
         };
-        long long t = blockIdx.x;
+        long long t = tbeg;
         fetch(t, cur_n, cur_r, cur_r2, cur_g, cur_ib);
         while (t < ntiles) {
-            tile_step(t, cur_n, cur_r, cur_r2, cur_g, cur_ib, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib); t += gridDim.x; if (t >= ntiles) break;
-            tile_step(t, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib, cur_n, cur_r, cur_r2, cur_g, cur_ib); t += gridDim.x;
+            tile_step(t, cur_n, cur_r, cur_r2, cur_g, cur_ib, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib); t += tstep; if (t >= ntiles) break;
+            tile_step(t, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib, cur_n, cur_r, cur_r2, cur_g, cur_ib); t += tstep;
         }
     } else {
         // ---- level pass with compaction.  Phase 1 (every row): route, count, store the new node id; rows that feed a
@@ -582,7 +619,7 @@ __global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(con
     if (STREAM && c.pad0 != 0) return;   // timing experiment: results are discarded
     // ---- flush this workgroup's partial histograms (plain stores: no global atomics, no zeroing)
     for (int li = 0; li < ng; ++li) {
-        HistBin* dst = part + (((long long)k * c.gx + blockIdx.x) * c.max_built + (g0 + li)) * c.totbins;
+        HistBin* dst = part + (((long long)k * c.gx + bx) * c.max_built + (g0 + li)) * c.totbins;
         for (int b = tid; b < wb; b += LV_THREADS) {
             const uint32_t ws = w_slot[b];
             const int sh = (int)(ws >> 24), s0 = (int)(ws & 0xFFFFFFu);

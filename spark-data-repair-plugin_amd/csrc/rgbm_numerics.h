@@ -84,4 +84,21 @@ RG_HD int quant_h(double h, double sh) {
 }
 RG_HD long long round_int(double x) { return (long long)(x + 0.5); }
 
+// Numerics v1.02: the quantised hessian is a FUNCTION of the quantised gradient (and of the row's label and weight), not of
+// the unrounded probability.  For the binary / softmax objectives g = (p - [y is this class]) * w and h = factor * p * (1 - p) * w, so
+// p -- and with it h -- is recovered from g to within the gradient's own resolution (2^-20 of its bound, the same order as the
+// rounding of h itself).  This is what lets the level passes stream 4 bytes per (row, class tree) instead of 8: they carry g only
+// and recompute h for the rows they accumulate.  Regression: h = w, independent of g.
+//   obj 0: g = response * w, h = |response| (1 - |response|) w;  obj 1: as above;  obj 2: h = w.
+RG_HD int h_from_g(int gq, bool is_label_class, double w, double inv_w /* 1.0 / w, or 0 for w = 0 */, int obj, double inv_sg, double sh, double factor) {
+    if (obj == 2) return quant_h(w, sh);
+    const double a = ((double)gq * inv_sg) * inv_w;      // the reciprocal is taken once per label / row: no division per (row, class tree)
+    double h;
+    if (obj == 0) { const double r = fabs(a); h = r * (1.0 - r) * w; }
+    else { const double p = is_label_class ? a + 1.0 : a; h = factor * p * (1.0 - p) * w; }
+    if (!(h > 0.0)) h = 0.0;       // p rounded a hair outside [0, 1]; w = 0
+    return quant_h(h, sh);
+}
+RG_HD double rg_inv_weight(double w) { return w > 0.0 ? 1.0 / w : 0.0; }
+
 }  // namespace rg

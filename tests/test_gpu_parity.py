@@ -197,12 +197,22 @@ def test_build_model_hp_search_runs_on_gpu_and_matches_oracle_backend():
     X = pd.DataFrame({"a": rng.choice(list("xyz"), 600), "b": rng.choice(list("pqrs"), 600), "c": rng.integers(0, 6, 600)})
     y = pd.Series(np.where(X.a == "x", "A", np.where(X.b == "p", "B", "C")))
     opts = {"model.hp.max_evals": "4", "model.lgb.n_estimators": "25", "model.lgb.learning_rate": "0.2", "model.hp.no_progress_loss": "3"}
-    (mg, sg), _ = build_model(X, y, True, 3, n_jobs=-1, opts=opts)
+    import faulthandler
+    import sys
+    import time
+    t0 = time.perf_counter()
+    faulthandler.dump_traceback_later(20, repeat=False, file=sys.stderr)     # a search that takes longer than 20 s shows where its threads sit
+    try:
+        (mg, sg), _ = build_model(X, y, True, 3, n_jobs=-1, opts=opts)
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+    t1 = time.perf_counter()
     prev = gbm.set_backend(OracleBackend)
     try:
         (mo, so), _ = build_model(X, y, True, 3, n_jobs=-1, opts=opts)
     finally:
         gbm.set_backend(prev)
+    print("hp search: HIP backend %.2fs, oracle backend %.2fs" % (t1 - t0, time.perf_counter() - t1))
     assert mg is not None and mo is not None and sg == so
     assert mg.booster_bytes_ == mo.booster_bytes_
     assert np.array_equal(mg.predict_proba(X), mo.predict_proba(X))
