@@ -860,32 +860,18 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (timing) HIPCHK(hipStreamSynchronize(s));
     const double t_setup = now();
     // ---- 5. boosting iterations: everything below is enqueue-only.
-    // Without bagging / row sharding / per-launch timing one iteration of the level grower is the same launch sequence
-    // every time (the iteration counter lives on the device), so it CAN be captured once into a hipGraph and replayed
-    // (RGBM_GRAPH=1).  It is off by default: measured on MI355X / ROCm 7.2 a 10 000-row fit is bound by the GPU-side
-    // latency of its ~27 small dependent kernels per iteration, not by the host launches (134.7 ms either way), and
-    // graphs replayed from several host threads at once (the batched hp search) gave 2 wrong models in 72.
-    const char* genv_graph = getenv("RGBM_GRAPH");
-    const bool graph_mode = level_mode && !use_bagging && !dp && !stats && genv_graph && genv_graph[0] == '1';
-    if (graph_mode) {
-        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        enqueue_grad();
-        enqueue_level_growth();
-        hipLaunchKernelGGL(k_next_iteration, dim3(1), dim3(1), 0, s, d_it.p);
-        HIPCHK(hipStreamEndCapture(s, &graph));
-        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        for (int it = 0; it < NE; ++it) HIPCHK(hipGraphLaunch(exec, s));
-        HIPCHK(hipStreamSynchronize(s));
-        (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
-    }
-    for (int it = graph_mode ? NE : 0; it < NE; ++it) {
-        if (use_bagging && it % p.bagging_freq == 0) {
-            const long long nrb = (n_train + 1023) / 1024;
-            d_bagcnt.zero(s);
-            hipLaunchKernelGGL(k_bagging, dim3((unsigned)((nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, (long long)n_train, p.bagging_fraction, d_sorted_rows.p, d_inbag.p);
-            hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((n_train + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, (long long)n_train, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
-        }
+    // hipGraph replay of an iteration was built and measured twice (rounds 1 and 2, MI355X / ROCm 7.2) and removed: a 10 000-row fit
+    // takes the same time either way (the chain of ~30 small dependent kernels per iteration is bound by GPU-side latency, not by
+    // the host launches), 24 concurrent host threads gain nothing (8.8 vs 9.2 ms per 60-iteration fit), and captures made while
+    // other threads train fail or replay wrongly (20 bad models in 150) even with every graph call behind one mutex.
+    auto enqueue_bagging = [&]() {
+        const long long nrb = (n_train + 1023) / 1024;
+        d_bagcnt.zero(s);
+        hipLaunchKernelGGL(k_bagging, dim3((unsigned)((nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, (long long)n_train, p.bagging_fraction, d_sorted_rows.p, d_inbag.p);
+        hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((n_train + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, (long long)n_train, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
+    };
+    for (int it = 0; it < NE; ++it) {
+        if (use_bagging && it % p.bagging_freq == 0) enqueue_bagging();
         enqueue_grad();
         const uint8_t* usedp = d_used.p + (size_t)it * K * F;
         if (level_mode) {

@@ -499,20 +499,12 @@ __device__ void scan_child(const long long (&bg)[4], const long long (&bh)[4], c
     }
 }
 
-__global__ __launch_bounds__(256) void k_split_find(HistBin* __restrict__ pool, const TreeState* __restrict__ state,
-                                                    Leaf* __restrict__ leaves, const FeatMeta* __restrict__ fmeta,
-                                                    const uint8_t* __restrict__ used /* [K][F] */, Cand* __restrict__ cand /* [K][2][F] */,
-                                                    TrainConst c) {
-    const int k = blockIdx.y;
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= c.F) return;
-    const TreeState st = state[k];
-    if (!st.do_hist) return;
+// one wave: feature f of the leaf / the two leaves searched in this step (pk = the class tree's histogram pool, lk its leaves,
+// used_k its feature mask, ck its [2][F] candidates; lk / ck may live in LDS)
+__device__ __forceinline__ void split_find_body(HistBin* __restrict__ pk, const TreeState& st, Leaf* lk, const FeatMeta* __restrict__ fmeta,
+                                                const uint8_t* __restrict__ used_k, Cand* ck, int f, const TrainConst& c) {
     const int lane = lane_id();
-    Cand* ck = cand + (long long)k * 2 * c.F;
     const FeatMeta fm = fmeta[f];
-    HistBin* pk = pool + (long long)k * c.num_leaves * c.totbins;
-    Leaf* lk = leaves + (long long)k * c.num_leaves;
     long long ag[4], ah[4], bgv[4], bhv[4];
     if (st.hist_is_root) {
         const HistBin* h0 = pk + fm.hoff;
@@ -527,7 +519,7 @@ __global__ __launch_bounds__(256) void k_split_find(HistBin* __restrict__ pool, 
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { sg_ += __shfl_xor(sg_, off); sh_ += __shfl_xor(sh_, off); }
         if (f == 0 && lane == 0) { lk[0].Gq = sg_; lk[0].Hq = sh_; }
-        if (!used[(long long)k * c.F + f]) { if (lane == 0) ck[f].gain = -INFINITY; return; }
+        if (!used_k[f]) { if (lane == 0) ck[f].gain = -INFINITY; return; }
         scan_child(ag, ah, fm, sg_, sh_, (long long)lk[0].count, c, &ck[f]);
         return;
     }
@@ -547,10 +539,23 @@ __global__ __launch_bounds__(256) void k_split_find(HistBin* __restrict__ pool, 
             ag[j] = l.g; ah[j] = l.h; bgv[j] = r.g; bhv[j] = r.h;
         } else { ag[j] = ah[j] = bgv[j] = bhv[j] = 0; }
     }
-    if (!used[(long long)k * c.F + f]) { if (lane == 0) { ck[f].gain = -INFINITY; ck[c.F + f].gain = -INFINITY; } return; }
+    if (!used_k[f]) { if (lane == 0) { ck[f].gain = -INFINITY; ck[c.F + f].gain = -INFINITY; } return; }
     const Leaf L = lk[st.split_leaf], R = lk[st.right_leaf];
     scan_child(ag, ah, fm, L.Gq, L.Hq, (long long)L.count, c, &ck[f]);
     scan_child(bgv, bhv, fm, R.Gq, R.Hq, (long long)R.count, c, &ck[c.F + f]);
+}
+
+__global__ __launch_bounds__(256) void k_split_find(HistBin* __restrict__ pool, const TreeState* __restrict__ state,
+                                                    Leaf* __restrict__ leaves, const FeatMeta* __restrict__ fmeta,
+                                                    const uint8_t* __restrict__ used /* [K][F] */, Cand* __restrict__ cand /* [K][2][F] */,
+                                                    TrainConst c) {
+    const int k = blockIdx.y;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= c.F) return;
+    const TreeState st = state[k];
+    if (!st.do_hist) return;
+    split_find_body(pool + (long long)k * c.num_leaves * c.totbins, st, leaves + (long long)k * c.num_leaves, fmeta, used + (long long)k * c.F,
+                    cand + (long long)k * 2 * c.F, f, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -584,18 +589,12 @@ __device__ void reduce_leaf_best(const Cand* cf, int F, Leaf* leaf) {
     }
 }
 
-__global__ __launch_bounds__(64) void k_tree_step(TreeState* __restrict__ state, Leaf* __restrict__ leaves, const Cand* __restrict__ cand,
-                                                  HistBin* __restrict__ pool, const FeatMeta* __restrict__ fmeta, TreeOut out, int it, TrainConst c) {
-    const int k = blockIdx.x, lane = lane_id();
-    TreeState* st = &state[k];
-    if (st->done) return;
-    Leaf* lk = leaves + (long long)k * c.num_leaves;
-    const Cand* ck = cand + (long long)k * 2 * c.F;
-    if (st->do_hist) {
-        if (st->hist_is_root) reduce_leaf_best(ck, c.F, &lk[0]);
-        else { reduce_leaf_best(ck, c.F, &lk[st->split_leaf]); reduce_leaf_best(ck + c.F, c.F, &lk[st->right_leaf]); }
-    }
-    __syncthreads();
+// Steps (2) and (3) for one class tree, run by ONE wave after the candidates of the freshly searched leaves are reduced.
+// `st` / `lk` may live in global memory (k_tree_step) or in LDS (k_small_tree).  ZERO_SLOT: clear the histogram slot the next
+// k_hist launch accumulates into with atomics (the fused small-table grower stores its histograms directly).
+template <bool ZERO_SLOT>
+__device__ __forceinline__ void tree_step_pick(TreeState* st, Leaf* lk, HistBin* pool_k, const FeatMeta* __restrict__ fmeta, TreeOut out, long long tbase, const TrainConst& c) {
+    const int lane = lane_id();
     const int L = st->L;
     double bg = -INFINITY; int bf = -1, bl = 0x7FFFFFFF;
     for (int l = lane; l < L; l += 64) {
@@ -607,15 +606,15 @@ __global__ __launch_bounds__(64) void k_tree_step(TreeState* __restrict__ state,
         double g2 = __shfl_xor(bg, off); int f2 = __shfl_xor(bf, off), l2 = __shfl_xor(bl, off);
         if (l2 != 0x7FFFFFFF && (bl == 0x7FFFFFFF || leaf_better(g2, f2, l2, bg, bf, bl))) { bg = g2; bf = f2; bl = l2; }
     }
-    const long long tbase = (long long)it * c.K + k;
     if (L >= c.num_leaves || !(bg > 0.0)) {
         if (lane == 0) { st->done = 1; st->do_partition = 0; st->do_hist = 0; out.L[tbase] = L; }
         return;
     }
     const int right_leaf = L, node = L - 1;
-    // zero the histogram slot the next hist pass will accumulate into
-    HistBin* zs = pool + ((long long)k * c.num_leaves + right_leaf) * c.totbins;
-    for (int i = lane; i < c.totbins; i += 64) { zs[i].g = 0; zs[i].h = 0; }
+    if (ZERO_SLOT) {   // zero the histogram slot the next hist pass will accumulate into
+        HistBin* zs = pool_k + (long long)right_leaf * c.totbins;
+        for (int i = lane; i < c.totbins; i += 64) { zs[i].g = 0; zs[i].h = 0; }
+    }
     if (lane == 0) {
         Leaf P = lk[bl];
         const Cand sp = P.best;
@@ -630,7 +629,7 @@ __global__ __launch_bounds__(64) void k_tree_step(TreeState* __restrict__ state,
         Lf.best.gain = -INFINITY; Lf.best_feature = -1;
         Rf.parent_node = node; Rf.is_left = 0; Rf.depth = P.depth + 1; Rf.Gq = P.Gq - sp.left_gq; Rf.Hq = P.Hq - sp.left_hq;
         Rf.best.gain = -INFINITY; Rf.best_feature = -1;
-        lk[bl] = Lf; lk[right_leaf] = Rf;   // begin/count/buf are completed by k_finish_split
+        lk[bl] = Lf; lk[right_leaf] = Rf;   // begin/count/buf are completed by finish_split
         st->split_leaf = bl; st->right_leaf = right_leaf; st->L = L + 1;
         st->do_partition = 1; st->do_hist = 0;
         st->part_feature = bf; st->part_theta = sp.theta; st->part_dleft = sp.dleft;
@@ -639,6 +638,21 @@ __global__ __launch_bounds__(64) void k_tree_step(TreeState* __restrict__ state,
         st->cursor_left = 0; st->cursor_right = 0;
         out.L[tbase] = L + 1;
     }
+}
+
+__global__ __launch_bounds__(64) void k_tree_step(TreeState* __restrict__ state, Leaf* __restrict__ leaves, const Cand* __restrict__ cand,
+                                                  HistBin* __restrict__ pool, const FeatMeta* __restrict__ fmeta, TreeOut out, int it, TrainConst c) {
+    const int k = blockIdx.x;
+    TreeState* st = &state[k];
+    if (st->done) return;
+    Leaf* lk = leaves + (long long)k * c.num_leaves;
+    const Cand* ck = cand + (long long)k * 2 * c.F;
+    if (st->do_hist) {
+        if (st->hist_is_root) reduce_leaf_best(ck, c.F, &lk[0]);
+        else { reduce_leaf_best(ck, c.F, &lk[st->split_leaf]); reduce_leaf_best(ck + c.F, c.F, &lk[st->right_leaf]); }
+    }
+    __syncthreads();
+    tree_step_pick<true>(st, lk, pool + (long long)k * c.num_leaves * c.totbins, fmeta, out, (long long)it * c.K + k, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -697,19 +711,14 @@ __global__ __launch_bounds__(256) void k_partition(const uint8_t* __restrict__ r
     }
 }
 
-// one wave per class tree: complete the children's ranges and decide the next histogram pass
-__global__ __launch_bounds__(64) void k_finish_split(TreeState* __restrict__ state, Leaf* __restrict__ leaves, TreeOut out, int it, TrainConst c) {
-    const int k = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    TreeState* st = &state[k];
+// complete the children's ranges and decide the next histogram pass (one thread; `nl` = rows that went left)
+__device__ __forceinline__ void finish_split_body(TreeState* st, Leaf* lk, TreeOut out, long long tbase, int nl, const TrainConst& c) {
     if (!st->do_partition) { st->do_hist = 0; return; }
-    Leaf* lk = leaves + (long long)k * c.num_leaves;
-    const int nl = (int)st->cursor_left, nr = st->part_count - nl;
+    const int nr = st->part_count - nl;
     const int nbuf = st->part_buf == 0 ? 1 : 0;
     Leaf& Lf = lk[st->split_leaf]; Leaf& Rf = lk[st->right_leaf];
     Lf.begin = st->part_begin; Lf.count = nl; Lf.buf = nbuf;
     Rf.begin = st->part_begin + nl; Rf.count = nr; Rf.buf = nbuf;
-    const long long tbase = (long long)it * c.K + k;
     out.leaf_count[tbase * c.num_leaves + st->split_leaf] = nl;
     out.leaf_count[tbase * c.num_leaves + st->right_leaf] = nr;
     st->do_partition = 0;
@@ -722,6 +731,14 @@ __global__ __launch_bounds__(64) void k_finish_split(TreeState* __restrict__ sta
     st->hist_begin = st->smaller_is_left ? Lf.begin : Rf.begin;
     st->hist_count = st->smaller_is_left ? nl : nr;
     st->hist_buf = nbuf;
+}
+
+// one wave per class tree
+__global__ __launch_bounds__(64) void k_finish_split(TreeState* __restrict__ state, Leaf* __restrict__ leaves, TreeOut out, int it, TrainConst c) {
+    const int k = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    TreeState* st = &state[k];
+    finish_split_body(st, leaves + (long long)k * c.num_leaves, out, (long long)it * c.K + k, (int)st->cursor_left, c);
 }
 
 __global__ __launch_bounds__(64) void k_init_iter(TreeState* __restrict__ state, Leaf* __restrict__ leaves, HistBin* __restrict__ pool,

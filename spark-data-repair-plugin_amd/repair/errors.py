@@ -463,7 +463,10 @@ class ErrorModel:
             col = input_df[a]
             # object dtype keeps nullable integers integral (CAST(int AS STRING) gives '2', never '2.0')
             vals = col.to_numpy(dtype=object)[rpos[idx].astype(np.int64)]
-            cur[idx] = [None if pd.isna(v) else _to_sql_string(v) for v in vals]
+            null = np.asarray(pd.isna(vals), bool)               # one array pass; NULL cells (the usual error cell) need no formatting
+            out = np.empty(len(vals), object)
+            out[~null] = [_to_sql_string(v) for v in vals[~null]]
+            cur[idx] = out
         cells = cells.assign(current_value=cur)
         noisy_columns = [c for c in input_df.columns if c in set(cells["attribute"])]
         domain_stats = {c: int(input_df[c].nunique(dropna=True)) for c in input_df.columns if c != rid}

@@ -253,12 +253,16 @@ class RepairModel():
             raise ValueError("Supported types are %s, but unsupported ones found: %s" % (",".join(_SUPPORTED_TYPES), ",".join(unsupported)))
         if len(df.columns) < 3:
             raise ValueError("A least three columns (`%s` columns + two more ones) in table '%s'" % (rid, name))
-        if df[rid].nunique(dropna=False) != len(df):
+        if not df[rid].is_unique:
             raise ValueError("Uniqueness does not hold in column '%s' of table '%s' (# of distinct '%s': %d, # of rows: %d)" % (
                 rid, name, rid, df[rid].nunique(dropna=False), len(df)))
         continous = [c for c in df.columns if c != rid and is_numeric_column(df[c])]
         _logger.info("input_table: (%d rows x %d columns)" % (len(df), len(df.columns) - 1))
-        return df.reset_index(drop=True), continous
+        # positional index without copying the table (a frame of 10^6 object cells takes > 1 s to copy + consolidate): nothing
+        # downstream writes into `input_df`, every step that changes cells works on its own copy
+        if isinstance(df.index, pd.RangeIndex) and df.index.start == 0 and df.index.step == 1:
+            return df, continous
+        return df.set_axis(pd.RangeIndex(len(df)), axis=0, copy=False), continous
 
     def _detect_errors(self, input_df: DataFrame, continous_columns: List[str]) -> Any:
         ec = None
@@ -606,7 +610,7 @@ class RepairModel():
 
     def _run_resident(self, plan: Dict[str, Any], input_df: DataFrame, error_cells_df: DataFrame, target_columns: List[str],
                       continous_columns: List[str], repair_data: bool) -> DataFrame:
-        """Steps 2 and 3 of `_run` on the device: the table is encoded once (Arrow dictionaries -> codes, on the device), error
+        """Steps 2 and 3 of `_run` on the device: the table is encoded once (dictionary indices -> codes, on the device), error
         cells are NULLed, the dirty rows split off, one model per target attribute trained and the chained repair run without
         the table leaving HBM (repair.pipeline.repair_frame); the host only shapes the (small) list of repaired cells."""
         from repair.pipeline import repair_frame
@@ -777,6 +781,9 @@ def _sql_type_name(s: Any) -> str:
         return {"8": "tinyint", "16": "smallint", "32": "int"}.get(bits, "bigint")
     if k == "f" or str(s.dtype).startswith("Float"):
         return "float" if "32" in str(s.dtype) else "double"
+    kind = pd.api.types.infer_dtype(s, skipna=True)      # one C pass; only the unusual answers need the element-wise look below
+    if kind in ("string", "empty"):
+        return "string"
     vals = s.dropna()
     if len(vals) and all(isinstance(v, datetime.datetime) for v in vals):
         return "timestamp"

@@ -160,10 +160,9 @@ def test_random_configurations_stress():
         assert mo.save() == mg.save(), "trial %d differs: n=%d F=%d K=%d %r" % (trial, n, F, K, kw)
 
 
-@pytest.mark.parametrize("env", ["RGBM_LAZY_SCORE", "RGBM_GRAPH"])
+@pytest.mark.parametrize("env", ["RGBM_LAZY_SCORE"])
 def test_opt_in_experiments_stay_bit_exact(env):
-    """Opt-in variants kept in the library (deferred AddScore inside the gradient kernel; hipGraph replay of an
-    iteration) must not change a bit either."""
+    """Opt-in variants kept in the library (deferred AddScore inside the gradient kernel) must not change a bit either."""
     from oracle import oracle as O
     from repair import _native as N
     X, nc, y, K = _xy(30000, 10, 7, seed=97)   # K = 24 -> multiclass
