@@ -30,6 +30,7 @@
 #include "rgbm_host.h"
 #include "rgbm_kernels.h"
 #include "rgbm_level.h"
+#include "rgbm_small.h"
 
 #define RGBM_VERSION 102   // numerics spec v1.02 (v1.01: hessian scale exact for power-of-two bounds; v1.02: h derived from the quantised g)
 
@@ -545,9 +546,19 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                        d_cols.p, d_ncod.p, d_lut_off.p, d_lut.p, d_miss.p, F, nchunk, d_rec.p);
     // grower choice: the level-synchronous streaming grower (rgbm_level.h) whenever it applies; RGBM_GROWER=leafwise
     // forces the index-list grower (both are HIP; they produce identical models)
+    // A third grower exists as an opt-in (rgbm_small.h, RGBM_GROWER=small, or RGBM_SMALL_ROWS=n for "up to n training rows"): the leaf-wise
+    // loop of one class tree inside ONE launch.  It produces the same models (tests/test_gpu_growers.py runs every case through all
+    // three growers) but measured slower than the level grower's kernel chain on the sizes it was meant for (MI355X, 10 000 rows:
+    // 0.72 vs 0.50 ms per boosting iteration; the reference-default job 3.43 vs 1.88 s), so nothing selects it by default.
     const char* genv = getenv("RGBM_GROWER");
-    const bool level_mode = p.max_depth >= 1 && p.max_depth <= LV_MAX_DEPTH && F <= 255 && !(genv && strcmp(genv, "leafwise") == 0);
     const bool use_bagging = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
+    long long small_rows = 0;
+    if (const char* e = getenv("RGBM_SMALL_ROWS")) small_rows = atoll(e);
+    const size_t sm_hist = std::max<size_t>(lds_hist, (size_t)p.num_leaves * 8);
+    const size_t sm_bytes = sm_lds_bytes(sm_hist, p.num_leaves, F);
+    const bool small_ok = !dp && !stats && F <= SM_MAX_FEATS && p.num_leaves >= 2 && p.num_leaves <= SM_MAX_LEAVES && sm_bytes <= 160 * 1024;
+    const bool small_mode = small_ok && (genv ? strcmp(genv, "small") == 0 : n_train <= small_rows);
+    const bool level_mode = !small_mode && p.max_depth >= 1 && p.max_depth <= LV_MAX_DEPTH && F <= 255 && !(genv && strcmp(genv, "leafwise") == 0);
     if (dp && (!level_mode || use_bagging || sample_weight_host))
         throw std::invalid_argument("row-sharded training supports the level grower (1 <= max_depth <= 7) without bagging / per-row weights");
     DevBuf<int32_t> d_base; DevBuf<unsigned int> d_counter(1); d_counter.zero(s);
@@ -731,6 +742,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     }
     const unsigned int* n_in_ptr = use_bagging ? d_bagcnt.p : nullptr;
 
+    if (small_mode && sm_bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_small_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_bytes));
     if (!level_mode) {
         if (lds_hist > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
         if (lds_hist > 160 * 1024) throw std::invalid_argument("histogram working set exceeds LDS");
@@ -877,6 +889,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         if (level_mode) {
             enqueue_level_growth();
             hipLaunchKernelGGL(k_next_iteration, dim3(1), dim3(1), 0, s, d_it.p);
+            continue;
+        }
+        if (small_mode) {
+            hipLaunchKernelGGL(k_small_tree, dim3(K), dim3(SM_THREADS), sm_bytes, s, d_rec.p, d_gh.p, d_idx0.p, d_idx1.p, d_base.p, d_pool.p, d_fmeta.p, d_cmeta.p,
+                               usedp, to, d_init.p, d_upd.p, d_state.p, d_any.p, d_score.p, n_in_ptr, it, sm_hist, tc);
+            if (use_bagging)
+                hipLaunchKernelGGL(k_score_update_oob, dim3(upd_gx, K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(d_rec.p), d_oob.p, d_bagcnt.p,
+                                   d_state.p, to, d_fmeta.p, d_upd.p, d_score.p, it, tc);
             continue;
         }
         hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);

@@ -1,9 +1,9 @@
-"""-m gpu: the two HIP tree growers (level-synchronous streaming grower, leaf-wise index-list grower)
-against the CPU oracle and against each other, bit-exact.
+"""-m gpu: the three HIP tree growers (level-synchronous streaming grower, leaf-wise index-list grower, fused small-table
+grower) against the CPU oracle and against each other, bit-exact.
 
-The level grower (csrc/rgbm_level.h) is used for 1 <= max_depth <= 7 and F <= 255, everything else
-takes the leaf-wise grower (csrc/rgbm_kernels.h).  RGBM_GROWER=leafwise forces the latter, which is
-how the same configuration is run through both here.
+The level grower (csrc/rgbm_level.h) is used for 1 <= max_depth <= 7 and F <= 255, everything else takes the leaf-wise grower
+(csrc/rgbm_kernels.h); the fused one-launch-per-tree grower (csrc/rgbm_small.h) is an opt-in.  RGBM_GROWER=level|small|leafwise
+forces one of them, which is how the same configuration is run through all of them here.
 """
 import os
 
@@ -16,16 +16,15 @@ pytestmark = pytest.mark.gpu
 
 
 class _grower:
-    """level = the fused level pass; split = route + list-accumulate kernels (the default for large fits); leafwise."""
+    """level = the fused level pass; split = route + stream kernels (the default for large fits); leafwise; small = the fused
+    one-launch-per-tree grower (opt-in)."""
 
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
         self.prev = {k: os.environ.get(k) for k in ("RGBM_GROWER", "RGBM_LEVEL_SPLIT")}
-        os.environ.pop("RGBM_GROWER", None)
-        if self.name == "leafwise":
-            os.environ["RGBM_GROWER"] = "leafwise"
+        os.environ["RGBM_GROWER"] = {"level": "level", "split": "level", "leafwise": "leafwise", "small": "small"}[self.name]
         os.environ["RGBM_LEVEL_SPLIT"] = "1" if self.name == "split" else "0"
 
     def __exit__(self, *a):
@@ -47,7 +46,10 @@ def _three_way(X, n_codes, y, K, obj, cw=None, yv=None, **kw):
         ms = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
     with _grower("leafwise"):
         mw = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
+    with _grower("small"):
+        mf = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
     bo = mo.save()
+    assert mf.save() == bo, "fused small-table grower differs from the oracle"
     assert ml.save() == bo, "level grower (fused pass) differs from the oracle"
     assert ms.save() == bo, "level grower (route + list passes) differs from the oracle"
     assert mw.save() == bo, "leaf-wise grower differs from the oracle"
@@ -156,8 +158,10 @@ def test_random_configurations_stress():
                   min_gain_to_split=float(rng.choice([0.0, 0.0, 0.05])), feature_fraction=float(rng.choice([1.0, 1.0, 0.6])))
         cw = balanced_weights(y, K)
         mo = O.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
-        mg = N.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
-        assert mo.save() == mg.save(), "trial %d differs: n=%d F=%d K=%d %r" % (trial, n, F, K, kw)
+        for g in ("level", "small"):
+            with _grower(g):
+                mg = N.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
+            assert mo.save() == mg.save(), "trial %d differs (%s grower): n=%d F=%d K=%d %r" % (trial, g, n, F, K, kw)
 
 
 @pytest.mark.parametrize("env", ["RGBM_LAZY_SCORE"])
@@ -172,7 +176,8 @@ def test_opt_in_experiments_stay_bit_exact(env):
     prev = os.environ.get(env)
     os.environ[env] = "1"
     try:
-        mg = N.train(X, nc, y, K, class_weight=cw, **kw)
+        with _grower("level"):
+            mg = N.train(X, nc, y, K, class_weight=cw, **kw)
     finally:
         if prev is None:
             os.environ.pop(env, None)
@@ -203,15 +208,16 @@ def test_random_configurations_stress_wide_and_sampled():
         if reg:
             vals = np.sort(rng.normal(size=25))
             y = ((z + X[1]) % 25).astype(np.int32)
-            mo = O.train(X, cards.astype(np.int32), y, 25, y_value=vals, objective=2, num_class=2, **kw)
-            mg = N.train(X, cards.astype(np.int32), y, 25, y_value=vals, objective=2, num_class=2, **kw)
+            args, kws = (X, cards.astype(np.int32), y, 25), dict(y_value=vals, objective=2, num_class=2, **kw)
         else:
             K = int(rng.choice([2, 4, 7, 17]))
             y = np.where(rng.random(n) < 0.3, rng.integers(0, K, n), (z + X[2]) % K).astype(np.int32)
-            cw = balanced_weights(y, K)
-            mo = O.train(X, cards.astype(np.int32), y, K, class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), **kw)
-            mg = N.train(X, cards.astype(np.int32), y, K, class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), **kw)
-        assert mo.save() == mg.save(), "trial %d differs: n=%d F=%d %r" % (trial, n, F, kw)
+            args, kws = (X, cards.astype(np.int32), y, K), dict(class_weight=balanced_weights(y, K), objective=0 if K == 2 else 1, num_class=max(K, 2), **kw)
+        mo = O.train(*args, **kws)
+        for g in ("level", "small"):
+            with _grower(g):
+                mg = N.train(*args, **kws)
+            assert mo.save() == mg.save(), "trial %d differs (%s grower): n=%d F=%d %r" % (trial, g, n, F, kw)
 
 
 class _env:
@@ -256,7 +262,7 @@ def test_forced_packed_slot_drains_stay_bit_exact(shift, lds):
     for X, nc, y, K, kw, cw, yv in cases:
         mo = O.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
         for split in (0, 1):                                       # the fused level pass, and the route + stream passes
-            with _env(RGBM_LEVEL_SPLIT=split, **env):
+            with _env(RGBM_LEVEL_SPLIT=split, RGBM_GROWER="level", **env):
                 mg = N.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
             assert mo.save() == mg.save(), "objective %d differs with forced drains (split=%d)" % (kw["objective"], split)
 
