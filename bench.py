@@ -174,6 +174,12 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # Testing aid for boxes with fewer GPUs than ranks (BENCH_SHARE_GPU=1): the ranks share the visible devices, the process group runs
+    # over gloo and the job is target-sharded (RCCL refuses two ranks on one device) -- everything but the collectives is the real path.
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        a.mode = "targets"
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -181,7 +187,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("RGBM_COMM_TIMEOUT_S", "180")   # a peer that died inside a collective fails this rank after 3 min, not 10
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if share_gpu else "nccl", rank=rank, world_size=world)
 
     from repair import dist as rdist
     from repair.engine import HipEngine, run_job, model_params, balanced_class_weight
