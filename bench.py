@@ -344,7 +344,7 @@ def main():
         }
         if row_sharding_note:
             out["config"]["row_sharding"] = row_sharding_note
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (the other ranks would sit in the barrier below)
             out["cpu_baseline"] = cpu_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS)
     # tear the communicators down first, flush whatever the C side (RCCL prints a version banner through stdio)
     # still holds, and only then print the ONE JSON line, as the last thing this process writes
