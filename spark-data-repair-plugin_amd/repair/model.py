@@ -781,6 +781,8 @@ def _sql_type_name(s: Any) -> str:
         return {"8": "tinyint", "16": "smallint", "32": "int"}.get(bits, "bigint")
     if k == "f" or str(s.dtype).startswith("Float"):
         return "float" if "32" in str(s.dtype) else "double"
+    if isinstance(s.dtype, pd.CategoricalDtype):         # a dictionary-encoded column has the type of its dictionary
+        return _sql_type_name(s.cat.categories.to_series())
     kind = pd.api.types.infer_dtype(s, skipna=True)      # one C pass; only the unusual answers need the element-wise look below
     if kind in ("string", "empty"):
         return "string"

@@ -156,6 +156,28 @@ def test_gpu_run_takes_the_resident_path_and_matches_both_references():
     print("resident run(): %.2fs wall, %.2fs on the device pipeline, host share %.0f %%" % (wall, device, 100 * (1 - device / wall)))
 
 
+@pytest.mark.parametrize("kind", ["category", "arrow"])
+def test_dictionary_encoded_columns_give_the_same_repairs(oracle_backend, kind):
+    """Columns handed over as pandas Categorical or Arrow-backed strings (what a Parquet / Arrow reader produces) take the cheap
+    encoding path -- their dictionary is factorised, not 10^6 Python objects -- and must repair exactly like object columns."""
+    df, _, _, _ = _synthetic_frame(4000, 6, seed=23)
+    fast = df.copy()
+    for c in df.columns:
+        if c == "tid":
+            continue
+        if kind == "category":
+            fast[c] = pd.Categorical(df[c])
+        else:
+            pa = pytest.importorskip("pyarrow")
+            fast[c] = df[c].astype(pd.ArrowDtype(pa.string()))
+    ma, mb = _model(df), _model(fast)
+    ma._engine_override = mb._engine_override = OracleEngine()
+    a, b = ma.run(), mb.run()
+    assert mb._last_resident_info is not None, "the run did not take the resident path"
+    assert len(a) > 100
+    pd.testing.assert_frame_equal(_sorted(a), _sorted(b.astype({"current_value": object, "repaired": object})), check_dtype=False)
+
+
 def test_unseen_category_in_a_dirty_row_is_missing_for_the_model(oracle_backend):
     """A dirty row with a feature value no training row of that target shows.  The value-space path treats it as missing (it is not in
     the model's dictionary).  The table-wide dictionary does hold it, so the column is marked CATEGORICAL (rgbm_table_set_column_kind)
