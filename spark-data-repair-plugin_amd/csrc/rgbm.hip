@@ -600,6 +600,11 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
     bool use_reduce = false;   // sum the per-workgroup partials in a separate kernel (many workgroups per class tree, or row-sharded)
+    // joint bins for the root pass (rgbm_level.h, k_pack_joint): a second record whose bytes hold GROUPS of low-cardinality features
+    bool joint_root = false; int vtotbins = 0;
+    LevelConst lcj; memset(&lcj, 0, sizeof(lcj));
+    DevBuf<FeatMeta> d_vfmeta; DevBuf<ChunkMeta> d_vcmeta; DevBuf<LvLayout> d_layout_j; DevBuf<uint4> d_rec_j; DevBuf<HistBin> d_part_j, d_red_j;
+    DevBuf<JointFeat> d_jf; DevBuf<int16_t> d_binfeat;
     // Experiment (RGBM_LAZY_SCORE=1, off): defer AddScore into the next iteration's gradient kernel so that the scores are touched
     // once per iteration.  Measured on MI355X (K=64, 10M rows): k_level_final 2.48 -> 0.70 ms, but the per-(row, class) gather of
     // the node delta inside the FP64-bound gradient kernel costs more than it saves (2.8 -> 6.8 ms).
@@ -677,6 +682,57 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         }
         d_lay_table.alloc(lay_table.size()); d_lay_table.upload(lay_table.data(), lay_table.size(), s);
         HIPCHK(hipStreamSynchronize(s));   // lay_table is a local
+        // Joint bins for the root pass (split mode: the tables where the root pass runs at the LDS-atomic rate).  Best-fit-decreasing
+        // packing of the features into groups whose bin counts multiply to <= 256; worth it when it saves at least two atomics per row
+        // and the groups fit one 16-byte record.  RGBM_JOINT_ROOT=0 disables it (same models either way: the sums are exact integers).
+        joint_root = split_mode && !(getenv("RGBM_JOINT_ROOT") && atoi(getenv("RGBM_JOINT_ROOT")) == 0);
+        if (joint_root) {
+            std::vector<int> order(F); for (int f = 0; f < F; ++f) order[f] = f;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fmeta[a].nbins > fmeta[b].nbins; });
+            std::vector<std::vector<int>> groups; std::vector<int> prod;
+            for (int f : order) {
+                int best = -1;
+                for (size_t g = 0; g < groups.size(); ++g)
+                    if (prod[g] * fmeta[f].nbins <= 256 && (best < 0 || prod[g] > prod[best])) best = (int)g;
+                if (best < 0) { groups.emplace_back(); prod.push_back(1); best = (int)groups.size() - 1; }
+                groups[best].push_back(f); prod[best] *= fmeta[f].nbins;
+            }
+            const int VF = (int)groups.size();
+            if (VF > 16 || VF > F - 2) joint_root = false;
+            else {
+                std::vector<FeatMeta> vfm(VF); std::vector<JointFeat> jf(F); std::vector<int16_t> binfeat(tc.totbins, 0);
+                ChunkMeta vcm; vcm.first_feat = 0; vcm.nfeat = VF; vcm.fast_slots = 0; vcm.wide_bins = 0;
+                for (int v = 0; v < VF; ++v) {
+                    FeatMeta& m = vfm[v]; memset(&m, 0, sizeof(m));
+                    m.V = prod[v]; m.has_nan = 0; m.nbins = prod[v]; m.hoff = vcm.wide_bins; m.wide_off = vcm.wide_bins;
+                    int sh = 0; while (sh < 5 && (m.nbins << (sh + 1)) <= 256) ++sh;
+                    m.rep_shift = sh; m.fast_base = vcm.fast_slots; vcm.fast_slots += m.nbins << sh; vcm.wide_bins += m.nbins;
+                    int stride = 1;
+                    for (int f : groups[v]) {
+                        JointFeat& j = jf[f]; memset(&j, 0, sizeof(j));
+                        j.voff = m.hoff; j.stride = stride; j.nbins = fmeta[f].nbins; j.nbv = prod[v]; j.hoff = fmeta[f].hoff; j.vbyte = v;
+                        stride *= fmeta[f].nbins;
+                        for (int b = 0; b < fmeta[f].nbins; ++b) binfeat[fmeta[f].hoff + b] = (int16_t)f;
+                    }
+                }
+                vtotbins = vcm.wide_bins;
+                const long long avail = (long long)lc.lds_bytes - lv_fixed_bytes(vcm, LV_MAX_EXP, vfm.data());
+                if (avail < lv_layout_bytes(vfm.data(), vcm, 0, 1)) joint_root = false;
+                else {
+                    LvLayout lay1; lv_choose_layout(vfm.data(), vcm, 1, avail, lay1);
+                    std::vector<LvLayout> layk((size_t)K, lay1);
+                    d_vfmeta.alloc(VF); d_vfmeta.upload(vfm.data(), VF, s); d_vcmeta.alloc(1); d_vcmeta.upload(&vcm, 1, s);
+                    d_layout_j.alloc(K); d_layout_j.upload(layk.data(), K, s);
+                    d_jf.alloc(F); d_jf.upload(jf.data(), F, s); d_binfeat.alloc(binfeat.size()); d_binfeat.upload(binfeat.data(), binfeat.size(), s);
+                    d_rec_j.alloc((size_t)N);
+                    hipLaunchKernelGGL(k_pack_joint, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_rec.p, (long long)N, F, d_jf.p, d_rec_j.p);
+                    d_part_j.alloc((size_t)K * lc.gx * vtotbins); d_red_j.alloc((size_t)K * vtotbins + (size_t)K * 128 /* k_level_reduce parks the counts behind the bins */);
+                    lcj = lc; lcj.nchunk = 1; lcj.F = VF; lcj.totbins = vtotbins; lcj.max_built = 1;
+                    if (!use_reduce) { use_reduce = true; d_part_red.alloc((size_t)K * lc.max_built * tc.totbins + (size_t)K * 128); }
+                    HIPCHK(hipStreamSynchronize(s));   // the vectors above are locals
+                }
+            }
+        }
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
         HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
@@ -791,7 +847,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
 #define RGBM_LAUNCH_PASS2(R, B, M, S, INBAG) RGBM_LAUNCH_PASS3(R, B, M, S, false, INBAG)
 #define RGBM_LAUNCH_PASS(R, B, M, INBAG) RGBM_LAUNCH_PASS2(R, B, M, false, INBAG)
         // chunk layout: 0 = one 16-feature chunk, 2 = exactly two (both records prefetched), 3 = more
-        if (root) { if (g_only) RGBM_LAUNCH_PASS3(true, false, 0, false, true, nullptr); else RGBM_LAUNCH_PASS(true, false, 0, nullptr); }
+        if (root && joint_root) {   // the root pass over the joint record: one atomic per feature GROUP and row
+            const dim3 jgrid((unsigned)lc.gx * (unsigned)K, 1, 1);
+            if (g_only) hipLaunchKernelGGL((k_level_pass<true, false, 0, false, true>), jgrid, dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node_a.p, node_b_p, (const uint8_t*)nullptr,
+                                           d_plan.p, d_layout_j.p, d_part_j.p, d_count.p, d_vfmeta.p, d_vcmeta.p, with_hist, lcj, (const uint8_t*)d_ylab.p, (const double*)(d_cw32.n ? d_cw32.p : nullptr));
+            else hipLaunchKernelGGL((k_level_pass<true, false, 0>), jgrid, dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node_a.p, node_b_p, (const uint8_t*)nullptr,
+                                    d_plan.p, d_layout_j.p, d_part_j.p, d_count.p, d_vfmeta.p, d_vcmeta.p, with_hist, lcj, (const uint8_t*)nullptr, (const double*)nullptr);
+        }
+        else if (root) { if (g_only) RGBM_LAUNCH_PASS3(true, false, 0, false, true, nullptr); else RGBM_LAUNCH_PASS(true, false, 0, nullptr); }
         else if (split_mode) {
             if (g_only) { if (use_bagging) RGBM_LAUNCH_PASS3(false, true, 0, true, true, d_inbag.p); else RGBM_LAUNCH_PASS3(false, false, 0, true, true, nullptr); }
             else if (use_bagging) RGBM_LAUNCH_PASS2(false, true, 0, true, d_inbag.p); else RGBM_LAUNCH_PASS2(false, false, 0, true, nullptr);
@@ -817,6 +880,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             // row-sharded: partials of this rank -> compact buffer -> integer all-reduce; the split kernel then sees ONE partial
             auto exchange = [&](bool root, int nb) -> std::pair<const HistBin*, LevelConst> {
                 if (!use_reduce) return {d_part.p, lc};
+                if (root && joint_root) {   // partials -> one joint histogram per class tree (k_level_reduce in the joint bin space) -> marginals of the real features
+                    hipLaunchKernelGGL(k_level_reduce, dim3((vtotbins + 63) / 64, 1, K), dim3(256), 0, s, d_part_j.p, d_red_j.p, d_plan.p, d_count.p, 1, 1, lcj);
+                    hipLaunchKernelGGL(k_level_marginal, dim3((tc.totbins + 255) / 256, K), dim3(256), 0, s, d_red_j.p, d_part_red.p, d_plan.p, d_count.p, d_jf.p, d_binfeat.p, vtotbins, lc);
+                } else
                 hipLaunchKernelGGL(k_level_reduce, dim3((tc.totbins + 63) / 64, nb, K), dim3(256), 0, s, d_part.p, d_part_red.p, d_plan.p, d_count.p, root ? 1 : 0, nb, lc);
                 if (dp) {
                     const size_t nh = (size_t)K * nb * tc.totbins * 2;          // int64 words of histograms, then K*256 child counts

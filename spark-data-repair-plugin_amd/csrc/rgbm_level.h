@@ -777,6 +777,55 @@ __global__ __launch_bounds__(256) void k_level_reduce(const HistBin* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Joint bins for the root pass.  The root pass is bound by the LDS-atomic rate: one packed atomic per feature and row
+// (15 for the synthetic table).  Features with few bins are therefore COMBINED: a group of features whose bin counts
+// multiply to <= 256 shares one byte of a second, "joint" record (code = sum of bin_f * stride_f) and one histogram of
+// prod(nbins) joint bins, so a row costs one atomic per GROUP (7 instead of 15).  The sums are exact integers, so the
+// histogram of every real feature is recovered exactly as a marginal of its group's joint histogram; that happens here,
+// in the reduction over the workgroup partials that the root pass needs anyway.  Only the root pass uses the joint record
+// (one built node: the joint histograms fit the LDS with room for replication); routing, the level passes and the
+// predictor keep the plain record.
+// ------------------------------------------------------------------------------------------------
+struct JointFeat { int32_t voff /* offset of the group's joint histogram */, stride, nbins /* of this feature */, nbv /* joint bins of the group */, hoff, vbyte /* byte of the joint record */, pad0, pad1; };
+
+// joint record of every row from its plain bin record(s); thread per row
+__global__ __launch_bounds__(256) void k_pack_joint(const uint4* __restrict__ rec, long long N, int F, const JointFeat* __restrict__ jf, uint4* __restrict__ rec_joint) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int f = 0; f < F; ++f) {
+        const uint32_t bin = rec8[((long long)(f >> 4) * N + i) * 16 + (f & 15)];
+        const int vb = jf[f].vbyte;
+        w[vb >> 2] += (bin * (uint32_t)jf[f].stride) << (8 * (vb & 3));    // a group's code stays below 256: no carry into the next byte
+    }
+    rec_joint[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// After k_level_reduce has summed the workgroup partials of a root pass over the joint record (same kernel, joint bin space):
+// the histogram of every real feature is the marginal of its group's joint histogram.  grid (ceil(totbins / 256), K), block 256:
+// one thread per real bin, <= 256 / nbins terms each.
+__global__ __launch_bounds__(256) void k_level_marginal(const HistBin* __restrict__ red_j /* [K][vtotbins] */, HistBin* __restrict__ red, const LvPlan* __restrict__ plan,
+                                                        const int32_t* __restrict__ count, const JointFeat* __restrict__ jf, const int16_t* __restrict__ bin_feat /* [totbins] */,
+                                                        int vtotbins, LevelConst c) {
+    const int k = blockIdx.y;
+    if (blockIdx.x == 0)   // the local child counts ride behind the histograms (k_level_reduce does the same)
+        reinterpret_cast<long long*>(red + (long long)c.K * c.totbins)[(long long)k * 256 + threadIdx.x] = (long long)count[(long long)k * 256 + threadIdx.x];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= c.totbins) return;
+    HistBin acc; acc.g = 0; acc.h = 0;
+    if (!plan[k].done) {
+        const JointFeat f = jf[bin_feat[b]];
+        const int digit = b - f.hoff;
+        const int period = f.stride * f.nbins;               // joint codes with this digit: hi * period + digit * stride + lo, lo < stride
+        const HistBin* src = red_j + (long long)k * vtotbins + f.voff;
+        for (int base = digit * f.stride; base < f.nbv; base += period)
+            for (int lo = 0; lo < f.stride; ++lo) { const HistBin v = src[base + lo]; acc.g += v.g; acc.h += v.h; }
+    }
+    red[(long long)k * c.totbins + b] = acc;
+}
+
 __global__ __launch_bounds__(256) void k_counts_unpack(const long long* __restrict__ cnt64, int32_t* __restrict__ count_g) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     count_g[i] = (int32_t)cnt64[i];
