@@ -45,9 +45,9 @@ class ErrorDetector(metaclass=ABCMeta):
         df = self._input()
         return pd.DataFrame({str(self.row_id): pd.Series([], dtype=df[str(self.row_id)].dtype), "attribute": pd.Series([], dtype=object)})
 
-    def _cells(self, mask: pd.Series, attr: str) -> pd.DataFrame:
-        ids = self._input().loc[mask.to_numpy(), str(self.row_id)]
-        return pd.DataFrame({str(self.row_id): ids.to_numpy(), "attribute": attr})
+    def _cells(self, mask: Any, attr: str) -> pd.DataFrame:
+        ids = self._input()[str(self.row_id)].to_numpy()[np.asarray(mask, bool)]
+        return pd.DataFrame({str(self.row_id): ids, "attribute": attr})
 
     def detect(self) -> pd.DataFrame:
         assert self.row_id is not None and self.qualified_input_name is not None
@@ -72,7 +72,8 @@ class NullErrorDetector(ErrorDetector):
 
     def _detect_impl(self) -> pd.DataFrame:
         df = self._input()
-        return _concat([self._cells(df[c].isna(), c) for c in df.columns if c != self.row_id and c in self._targets],
+        from repair.utils import column_isna
+        return _concat([self._cells(column_isna(df, c), c) for c in df.columns if c != self.row_id and c in self._targets],
                        self._empty_dataframe())
 
 
@@ -469,7 +470,8 @@ class ErrorModel:
             cur[idx] = out
         cells = cells.assign(current_value=cur)
         noisy_columns = [c for c in input_df.columns if c in set(cells["attribute"])]
-        domain_stats = {c: int(input_df[c].nunique(dropna=True)) for c in input_df.columns if c != rid}
+        from repair.utils import column_nunique
+        domain_stats = {c: column_nunique(input_df, c) for c in input_df.columns if c != rid}
         # discretizable attributes (RepairApi.discretizeTable): continuous ones, or 1 < |domain| <= threshold
         discretized = [c for c in input_df.columns if c != rid and (c in continous_columns or 1 < domain_stats[c] <= self.discrete_thres)]
         target_columns = [c for c in noisy_columns if c in discretized]

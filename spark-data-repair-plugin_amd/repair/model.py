@@ -756,8 +756,10 @@ class RepairModel():
             # the reference names the (qualified) input table here (model.py:1525-1526); a DataFrame input has no name
             raise ValueError("Target attributes not found in %s: %s" % (self._qualified_input_name(), to_list_str(self.targets)))
         self.opts.setdefault("model.gpu.device_id", self.opts.get("model.gpu.device_id", "0"))
-        df, elapsed = self._run(input_df, continous_columns, detect_errors_only, compute_repair_candidate_prob,
-                                compute_repair_prob, compute_repair_score, repair_data, maximal_likelihood_repair)
+        from repair.utils import column_code_cache
+        with column_code_cache(input_df):     # NULL detection, domain statistics and the resident encoding share one hash pass per column
+            df, elapsed = self._run(input_df, continous_columns, detect_errors_only, compute_repair_candidate_prob,
+                                    compute_repair_prob, compute_repair_score, repair_data, maximal_likelihood_repair)
         _logger.info("!!!Total Processing time is %s(s)!!!" % elapsed)
         return df
 

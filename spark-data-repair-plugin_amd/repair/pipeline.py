@@ -252,12 +252,11 @@ def encode_frame(df, columns):
         numeric = pd.api.types.is_numeric_dtype(s) and not pd.api.types.is_bool_dtype(s)
         if numeric:
             codes, uniq = pd.factorize(s.to_numpy(dtype="float64", na_value=np.nan), use_na_sentinel=True)
-        elif isinstance(s.dtype, pd.api.extensions.ExtensionDtype):
-            # categorical / Arrow-backed / pandas string columns carry their dictionary or a contiguous buffer already: factorize works on
-            # that (3-15 ms per 10^6 cells) instead of on 10^6 Python objects
-            codes, uniq = pd.factorize(s, use_na_sentinel=True)
         else:
-            codes, uniq = pd.factorize(s.to_numpy(dtype=object), use_na_sentinel=True)
+            # one hash pass per column and run: inside RepairModel.run() the NULL detector / domain statistics have factorised the column
+            # already (repair.utils.column_code_cache); categorical / Arrow-backed columns factorise through their own dictionary or buffer
+            from repair.utils import column_factorize
+            codes, uniq = column_factorize(df, c)
         vals = np.asarray(uniq, dtype=np.float64 if numeric else object)
         order = np.argsort(vals, kind="stable")
         remap = np.empty(len(vals), np.int32)
