@@ -305,3 +305,46 @@ def test_gpu_device_option_reaches_the_estimator():
     assert fixed_params({}, False, 0, -1)["device_id"] == 0
     with pytest.raises(ValueError, match="should be non-negative"):
         fixed_params({"model.gpu.device_id": "-1"}, True, 4, -1)
+
+
+def test_column_code_cache_agrees_with_pandas():
+    """`repair.utils.column_isna / column_nunique / column_factorize` (one shared hash pass per object column inside
+    `column_code_cache`) must say what pandas says, for every kind of column `RepairModel.run()` can meet."""
+    import numpy as np
+    import pandas as pd
+    from repair.utils import column_code_cache, column_factorize, column_isna, column_nunique
+    rng = np.random.default_rng(5)
+    n = 500
+    df = pd.DataFrame({
+        "s": rng.choice(np.array(["a", "bb", "ccc", None], object), n),
+        "mixed_nan": rng.choice(np.array(["x", "y", np.nan, None], object), n),
+        "f": np.where(rng.random(n) < 0.1, np.nan, rng.integers(0, 7, n).astype(float)),
+        "i": rng.integers(0, 5, n),
+        "nullable_int": pd.array(np.where(rng.random(n) < 0.1, None, rng.integers(0, 4, n)), dtype="Int64"),
+        "b": rng.choice(np.array([True, False, None], object), n),
+        "cat": pd.Categorical(rng.choice(np.array(["p", "q", None], object), n)),
+        "all_null": np.array([None] * n, object),
+    })
+    for inside in (False, True):
+        ctx = column_code_cache(df) if inside else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            for c in df.columns:
+                assert np.array_equal(column_isna(df, c), df[c].isna().to_numpy()), c
+                assert column_nunique(df, c) == df[c].nunique(dropna=True), c
+            for c in ("s", "mixed_nan", "b", "cat", "all_null"):
+                codes, uniq = column_factorize(df, c)
+                assert codes.dtype == np.int32 and np.array_equal(codes < 0, df[c].isna().to_numpy())
+                back = np.array([None if k < 0 else uniq[k] for k in codes], object)
+                want = df[c].astype(object).where(~df[c].isna(), None).to_numpy()
+                assert all((a is None and b is None) or a == b for a, b in zip(back, want)), c
+        finally:
+            if ctx:
+                ctx.__exit__(None, None, None)
+    # the cache belongs to ONE frame: another frame with the same columns is not served from it
+    other = df.copy()
+    other.loc[0, "s"] = None if df.loc[0, "s"] is not None else "a"
+    with column_code_cache(df):
+        column_isna(df, "s")
+        assert np.array_equal(column_isna(other, "s"), other["s"].isna().to_numpy())
