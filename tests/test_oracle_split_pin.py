@@ -165,3 +165,71 @@ def test_three_iterations_keep_sklearns_structure():
         assert [c for _, c in ol] == [c for _, c in sl]
     # iterations 2+ start from non-dyadic scores: float32 gradients (sklearn) vs 2^-k fixed point (D1) differ by ~1e-6 per row
     assert np.abs(m.predict(X)[:, 0] - est.predict(X.T.astype(np.float64))).max() <= 1e-4
+
+
+def _balanced_labels(X, K, seed):
+    """Labels with a strong dependence on the features and EXACTLY n / K rows per class: the priors are 1 / K, so the init scores and
+    every first-iteration gradient / hessian (p - y, p (1 - p) with p = 1 / K) are dyadic for K = 2, 4 -- exact in float32 (sklearn)
+    and in the oracle's fixed point alike."""
+    rng = np.random.default_rng(seed)
+    n = X.shape[1]
+    score = 3.0 * (X[3] % 4) + 2.0 * X[1] + (X[5] % 3) + 1.5 * X[0] * (X[2] > 2) + rng.random(n) * 2.5
+    order = np.argsort(score, kind="stable")
+    y = np.empty(n, np.int32)
+    y[order] = np.repeat(np.arange(K, dtype=np.int32), n // K)
+    return y
+
+
+@pytest.mark.parametrize("seed,leaves,depth,min_leaf", [(21, 31, 7, 20), (23, 15, 4, 40), (29, 63, 6, 10)])
+def test_binary_first_tree_equals_sklearn_classifier(seed, leaves, depth, min_leaf):
+    """The binary objective (`binary_objective.hpp`: labels +-1, response = -label / (1 + exp(label score)), h = |r| (1 - |r|)) against
+    scikit-learn's log-loss classifier (g = p - y, h = p (1 - p)): the same numbers.  Balanced classes: init score 0, g = +-0.5,
+    h = 0.25, all exact; the first tree must agree at every node, in every leaf value and in every probability."""
+    from sklearn.ensemble import HistGradientBoostingClassifier
+    X, cards, _ = _dyadic_regression_table(seed)
+    y = _balanced_labels(X, 2, seed)
+    lr = 0.5
+    m = O.train(X, cards, y, 2, objective=0, num_class=2, n_estimators=1, learning_rate=lr, num_leaves=leaves, max_depth=depth, min_data_in_leaf=min_leaf)
+    est = HistGradientBoostingClassifier(max_iter=1, learning_rate=lr, max_leaf_nodes=leaves, max_depth=depth, min_samples_leaf=min_leaf,
+                                         l2_regularization=0.0, max_bins=255, early_stopping=False).fit(X.T.astype(np.float64), y)
+    _, (t,) = _parse(m.save())
+    si, sl = _sk_nodes(est._predictors[0][0])
+    oi, ol = _orc_nodes(t)
+    assert len(oi) >= 7
+    _same_structure(oi, si, 1e-9)
+    assert [c for _, c in ol] == [c for _, c in sl]
+    assert np.allclose([v for v, _ in ol], [v for v, _ in sl], rtol=0, atol=1e-9)             # init score 0: nothing to add
+    assert np.abs(m.predict(X)[:, 1] - est.predict_proba(X.T.astype(np.float64))[:, 1]).max() <= 1e-9     # predict: [n][2] probabilities
+
+
+@pytest.mark.parametrize("seed", [31, 33, 37, 41])
+def test_multiclass_first_trees_match_sklearn_up_to_lightgbms_hessian_factor(seed):
+    """Softmax, K = 4 balanced classes: p = 1/4, g = 1/4 or -3/4, p (1 - p) = 3/16 -- exact on both sides.  LightGBM multiplies the
+    softmax hessian by K / (K - 1) (`multiclass_objective.hpp`, factor_), scikit-learn does not; a uniform hessian factor leaves every
+    arg-max of the split search where it is, so the K first trees must have scikit-learn's structure node for node, with gains and
+    leaf values scaled by (K - 1) / K = 3/4 and the init score log(1/4) added to the leaves (AddBias).
+    Seed 31 holds a genuine TIE: in one class tree two thresholds of the last split give different partitions (48 | 24 and 24 | 48 rows)
+    with the same gain 3.0.  LightGBM scans the bins from the right and keeps the first maximum, scikit-learn from the left: the oracle
+    must show LightGBM's choice (the larger threshold) -- the only difference allowed."""
+    from sklearn.ensemble import HistGradientBoostingClassifier
+    K, lr = 4, 0.5
+    X, cards, _ = _dyadic_regression_table(seed)
+    y = _balanced_labels(X, K, seed)
+    m = O.train(X, cards, y, K, objective=1, num_class=K, n_estimators=1, learning_rate=lr, num_leaves=31, max_depth=7, min_data_in_leaf=20)
+    est = HistGradientBoostingClassifier(max_iter=1, learning_rate=lr, max_leaf_nodes=31, max_depth=7, min_samples_leaf=20,
+                                         l2_regularization=0.0, max_bins=255, early_stopping=False).fit(X.T.astype(np.float64), y)
+    _, trees = _parse(m.save())
+    assert len(trees) == K
+    ties = 0
+    for k in range(K):
+        si, sl = _sk_nodes(est._predictors[0][k])
+        oi, ol = _orc_nodes(trees[k])
+        assert len(oi) >= 5
+        _same_structure([(f, b, g / 0.75) for f, b, g in oi], si, 1e-9)
+        if [c for _, c in ol] == [c for _, c in sl]:
+            assert np.allclose([v - np.log(0.25) for v, _ in ol], [0.75 * v for v, _ in sl], rtol=0, atol=1e-9)
+        else:   # equal gains at every node (checked above), a larger threshold at the tied one, the same rows in total
+            ties += 1
+            assert sum(c for _, c in ol) == sum(c for _, c in sl)
+            assert sum(bo > bs for (_, bo, _), (_, bs, _) in zip(oi, si)) >= 1
+    assert ties == (1 if seed == 31 else 0)
