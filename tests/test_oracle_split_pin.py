@@ -233,3 +233,33 @@ def test_multiclass_first_trees_match_sklearn_up_to_lightgbms_hessian_factor(see
             assert sum(c for _, c in ol) == sum(c for _, c in sl)
             assert sum(bo > bs for (_, bo, _), (_, bs, _) in zip(oi, si)) >= 1
     assert ties == (1 if seed == 31 else 0)
+
+
+@pytest.mark.parametrize("seed", [3, 5, 7, 11])
+def test_missing_values_first_tree_is_sklearns_partition(seed):
+    """NULL cells (code -1: the last, "NaN" bin of the feature, D3) against scikit-learn's missing-value handling: both try the
+    missing rows on either side of every threshold and keep the better one.  Which child is called left can differ where a split
+    separates the NULLs from everything else, so the comparison is on what the tree IS: the same gains, the same leaves (value, rows)
+    and the same prediction for every training row."""
+    from sklearn.ensemble import HistGradientBoostingRegressor
+    X, cards, y = _dyadic_regression_table(seed)
+    rng = np.random.default_rng(seed + 100)
+    Xn = X.copy()
+    for f, frac in ((3, 0.08), (5, 0.03)):      # NULLs that carry signal: mostly rows with a large label
+        Xn[f] = np.where(rng.random(X.shape[1]) < np.where(y > np.median(y), 2 * frac, 0.2 * frac), -1, X[f])
+    vals = np.unique(y)
+    m = O.train(Xn, cards, np.searchsorted(vals, y).astype(np.int32), len(vals), y_value=vals, objective=2, n_estimators=1, learning_rate=0.5,
+                num_leaves=31, max_depth=7, min_data_in_leaf=20)
+    Xs = Xn.T.astype(np.float64)
+    Xs[Xs < 0] = np.nan
+    est = HistGradientBoostingRegressor(max_iter=1, learning_rate=0.5, max_leaf_nodes=31, max_depth=7, min_samples_leaf=20, l2_regularization=0.0,
+                                        max_bins=255, early_stopping=False).fit(Xs, y)
+    feats, (t,) = _parse(m.save())
+    assert [f["has_nan"] for f in feats] == [0, 0, 0, 1, 0, 1, 0]
+    si, sl = _sk_nodes(est._predictors[0][0])
+    oi, ol = _orc_nodes(t)
+    assert any(f in (3, 5) for f, _, _ in oi), "no split on a feature with NULLs: the case tests nothing"
+    assert np.allclose(sorted(g for _, _, g in oi), sorted(g for _, _, g in si), rtol=1e-9, atol=0)
+    base = float(np.ravel(est._baseline_prediction)[0])
+    assert np.allclose(sorted(ol), sorted((base + v, c) for v, c in sl), rtol=0, atol=1e-9)
+    assert np.abs(m.predict(Xn)[:, 0] - est.predict(Xs)).max() <= 1e-9
