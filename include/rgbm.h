@@ -14,7 +14,11 @@
  *     outside [0, n_codes)) means NULL / unknown category == LightGBM's NaN;
  *   - return 0 on success, negative on error; rgbm_last_error() gives the (thread-local) message;
  *   - device_id >= 0 selects the HIP device; there is NO CPU fallback: without a usable GPU every
- *     compute entry point fails with RGBM_ERR_NO_DEVICE.
+ *     compute entry point fails with RGBM_ERR_NO_DEVICE;
+ *   - threads: every call is re-entrant.  Training / prediction calls own a HIP stream each, so any number of threads may
+ *     train from ONE table at once.  The relational table calls (detect / null / gather / count / read / write / pmf) share
+ *     the table's stream and scratch and are serialised per table by the library; the two-step detect -> rgbm_table_cells_fetch
+ *     protocol keeps its result in the table, so one thread at a time should drive that pair.
  */
 #ifndef RGBM_H_
 #define RGBM_H_

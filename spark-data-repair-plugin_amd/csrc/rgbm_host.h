@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <utility>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -99,6 +100,9 @@ struct rgbm_table {
     rgh::DevBuf<long long> cell_rows; rgh::DevBuf<int32_t> cell_cols; int64_t n_cells = 0;
     // stream + scratch of the relational steps (rgbm_prep.hip), kept with the table: a hipMalloc / hipFree / stream
     // creation per call costs more than the kernels (one call at a time per table, as the header says)
+    // Python threads share one table (the folds of a hyper-parameter search gather from the training table, ctypes drops the
+    // GIL): every entry point that touches the stream / scratch / cell list holds prep_mu from the first use to its final synchronise.
+    mutable std::mutex prep_mu;
     mutable hipStream_t stream = nullptr;
     mutable rgh::DevBuf<unsigned char> scratch[12];
     ~rgbm_table() { if (stream) (void)hipStreamDestroy(stream); }

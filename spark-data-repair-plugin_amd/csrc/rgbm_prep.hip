@@ -359,7 +359,7 @@ RGBM_EXPORT int rgbm_table_detect_nulls(rgbm_table* t, const int32_t* cols, int3
         use_device(t->device);
         check_cols(*t, cols, n_cols, "rgbm_table_detect_nulls");
         if (n_cols == 0) { t->n_cells = 0; *n_cells_out = 0; return RGBM_OK; }
-        hipStream_t s = table_stream(*t);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); hipStream_t s = table_stream(*t);
         const int32_t* d_cols = scr_upload<int32_t>(*t, 6, cols, (size_t)n_cols, s);
         *n_cells_out = compact<0>(*t, nullptr, d_cols, n_cols, true, s);
         return RGBM_OK;
@@ -382,7 +382,7 @@ RGBM_EXPORT int rgbm_table_detect_constraint(rgbm_table* t, const int32_t* eq_co
             span *= ks.radix[i];
             if (span >= ((unsigned __int128)1 << 63)) throw std::invalid_argument("rgbm_table_detect_constraint: the EQ attributes span more than 2^63 value combinations");
         }
-        hipStream_t s = table_stream(*t);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); hipStream_t s = table_stream(*t);
         const long long n = t->n;
         // the table never needs more slots than twice the number of possible keys
         unsigned long long want = (unsigned long long)n * 2ull;
@@ -418,7 +418,7 @@ RGBM_EXPORT int rgbm_table_rows_of_cells(rgbm_table* t, const int64_t* rows, int
     if (!t || !n_rows_out || n_cells < 0 || (n_cells > 0 && !rows)) return fail(RGBM_ERR_ARG, "rgbm_table_rows_of_cells: bad argument");
     return guarded([&]() {
         use_device(t->device);
-        hipStream_t s = table_stream(*t);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); hipStream_t s = table_stream(*t);
         uint8_t* mask = scr<uint8_t>(*t, 5, (size_t)t->n);
         HIPCHK(hipMemsetAsync(mask, 0, (size_t)t->n, s));
         static_assert(sizeof(long long) == sizeof(int64_t), "row positions are 64-bit");
@@ -433,6 +433,7 @@ RGBM_EXPORT int rgbm_table_cells_fetch(const rgbm_table* t, int64_t* rows_out, i
     if (!t) return fail(RGBM_ERR_ARG, "rgbm_table_cells_fetch: bad argument");
     return guarded([&]() {
         use_device(t->device);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu);
         if (t->n_cells > 0) {
             if (rows_out) HIPCHK(hipMemcpy(rows_out, t->cell_rows.p, (size_t)t->n_cells * 8, hipMemcpyDeviceToHost));
             if (cols_out) {
@@ -452,7 +453,7 @@ RGBM_EXPORT int rgbm_table_null_cells(rgbm_table* t, const int64_t* rows, const 
         use_device(t->device);
         check_cols(*t, target_cols, n_targets, "rgbm_table_null_cells");
         if (n_cells == 0 || n_targets == 0) return RGBM_OK;
-        hipStream_t s = table_stream(*t);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); hipStream_t s = table_stream(*t);
         std::vector<uint8_t> is_t((size_t)t->c, 0);
         for (int i = 0; i < n_targets; ++i) is_t[target_cols[i]] = 1;
         const uint8_t* d_t = scr_upload<uint8_t>(*t, 6, is_t.data(), is_t.size(), s);
@@ -473,7 +474,7 @@ RGBM_EXPORT int rgbm_table_write_cells(rgbm_table* t, const int64_t* rows, const
         if (n_cells == 0) return RGBM_OK;
         for (int64_t i = 0; i < n_cells; ++i)
             if (cols[i] >= 0 && cols[i] < t->c && codes[i] >= t->n_codes[cols[i]]) throw std::invalid_argument("rgbm_table_write_cells: code outside the column's dictionary");
-        hipStream_t s = table_stream(*t);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); hipStream_t s = table_stream(*t);
         const long long* d_rows = scr_upload<long long>(*t, 7, reinterpret_cast<const long long*>(rows), (size_t)n_cells, s);
         const int32_t* d_cols = scr_upload<int32_t>(*t, 8, cols, (size_t)n_cells, s);
         const int32_t* d_vals = scr_upload<int32_t>(*t, 9, codes, (size_t)n_cells, s);
@@ -489,7 +490,7 @@ RGBM_EXPORT int rgbm_table_read_cells(const rgbm_table* t, const int64_t* rows, 
     return guarded([&]() {
         use_device(t->device);
         if (n_cells == 0) return RGBM_OK;
-        hipStream_t s = table_stream(*t);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); hipStream_t s = table_stream(*t);
         const long long* d_rows = scr_upload<long long>(*t, 7, reinterpret_cast<const long long*>(rows), (size_t)n_cells, s);
         const int32_t* d_cols = scr_upload<int32_t>(*t, 8, cols, (size_t)n_cells, s);
         int32_t* d_out = scr<int32_t>(*t, 9, (size_t)n_cells);
@@ -507,7 +508,7 @@ RGBM_EXPORT int rgbm_table_gather_rows(const rgbm_table* t, const int64_t* rows,
     return guarded([&]() {
         use_device(t->device);
         for (int64_t i = 0; i < n_rows; ++i) if (rows[i] < 0 || rows[i] >= t->n) throw std::invalid_argument("rgbm_table_gather_rows: row position out of range");
-        hipStream_t s = table_stream(*t);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); hipStream_t s = table_stream(*t);
         std::unique_ptr<rgbm_table> o(new rgbm_table());
         o->device = t->device; o->n = n_rows; o->c = t->c; o->n_codes = t->n_codes; o->col_values = t->col_values; o->col_kind = t->col_kind;
         o->codes.alloc((size_t)n_rows * t->c);
@@ -525,7 +526,7 @@ RGBM_EXPORT int rgbm_table_count_codes(const rgbm_table* t, int32_t col, int64_t
     if (!t || !counts_out || col < 0 || col >= t->c) return fail(RGBM_ERR_ARG, "rgbm_table_count_codes: bad argument");
     return guarded([&]() {
         use_device(t->device);
-        hipStream_t s = table_stream(*t);
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); hipStream_t s = table_stream(*t);
         const int nc = t->n_codes[col];
         unsigned long long* d_cnt = scr<unsigned long long>(*t, 9, (size_t)nc + 1);
         HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)nc + 1) * 8, s));
@@ -586,7 +587,7 @@ RGBM_EXPORT int rgbm_table_repair_pmf(rgbm_table* t, const rgbm_model* m, int32_
         model_shape(m, &obj, &K, &F);
         if (obj == 2) throw std::invalid_argument("rgbm_table_repair_pmf: a regressor has no class distribution (model.py:1214-1221 handles continuous attributes)");
         if (F != f) throw std::invalid_argument("rgbm_table_repair_pmf: the model was trained on a different number of features");
-        struct { hipStream_t s; } sg{table_stream(*t)};
+        std::lock_guard<std::mutex> prep_lk(t->prep_mu); struct { hipStream_t s; } sg{table_stream(*t)};
         const int32_t* d_tc = scr_upload<int32_t>(*t, 6, &target_col, 1, sg.s);
         const long long cells = compact<0>(*t, nullptr, d_tc, 1, false, sg.s);      // ascending rows whose target cell is NULL
         *n_cells_out = cells;

@@ -613,9 +613,17 @@ class RepairModel():
         """Steps 2 and 3 of `_run` on the device: the table is encoded once (dictionary indices -> codes, on the device), error
         cells are NULLed, the dirty rows split off, one model per target attribute trained and the chained repair run without
         the table leaving HBM (repair.pipeline.repair_frame); the host only shapes the (small) list of repaired cells."""
-        from repair.pipeline import repair_frame
+        from repair.pipeline import NotResidentEligible, repair_frame
         rid = self._row_id
         max_rows = int(self._get_option_value(*self._opt_max_training_row_num))
+        if repair_data:
+            # The repair UDF fills EVERY NULL target cell of a dirty row (model.py:1128,1133), the cell list below only the error
+            # cells: with setErrorCells / non-NULL detectors a dirty row may hold further NULLs -- those runs keep the value-space path.
+            dirty = input_df[rid].isin(set(error_cells_df[rid].tolist())).to_numpy()
+            nulls_in_dirty = int(input_df.loc[dirty, target_columns].isna().to_numpy().sum())
+            null_error_cells = int(error_cells_df["current_value"].isna().to_numpy().sum())
+            if nulls_in_dirty > null_error_cells:
+                raise NotResidentEligible("%d NULL target cells of dirty rows are not error cells" % (nulls_in_dirty - null_error_cells))
 
         def sample(_attr: str, rows: np.ndarray) -> Optional[np.ndarray]:
             # `_sample_training_data_from`: the same seeded sample as DataFrame.sample(n, random_state=42) on the attribute's non-NULL rows
@@ -667,12 +675,15 @@ class RepairModel():
         plan = self._resident_plan(input_df, target_columns, continous_columns, domain_stats, compute_repair_candidate_prob,
                                    maximal_likelihood_repair)
         if plan is not None:
-            from repair.pipeline import UnseenCategories
+            from repair.pipeline import NotResidentEligible
             try:
                 return self._run_resident(plan, input_df, error_cells_df, target_columns, continous_columns, repair_data)
-            except UnseenCategories as e:
-                # a dirty row carries a categorical value that the target's training rows never show: per-model dictionaries (the
-                # value-space path) treat it as missing, the table-wide dictionary would not -- keep the reference behaviour
+            except NotResidentEligible as e:
+                # only known once the error cells are NULLed: a target left with a single class / no value (the reference's PoorModel
+                # short-cut, model.py:1008-1017), or NULL target cells in dirty rows that are not error cells under repair_data.
+                # (Unseen categories of a dirty row need no fallback: the table marks categorical columns, so a model treats a
+                # category its training rows do not show as missing, like the reference's per-model encoders.)
+                self._last_resident_info = None
                 _logger.info("resident path not taken: %s" % e)
 
         # 2. Repair Model Training Phase

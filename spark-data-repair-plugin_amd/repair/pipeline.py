@@ -99,7 +99,13 @@ def search_on_table(engine, table, t, n_codes, base_params, opts, y_value=None, 
     return {_POINT_TO_CORE[k]: (int(v) if k in ("num_leaves", "subsample_freq", "min_child_samples") else float(v)) for k, v in point.items()}
 
 
-class UnseenCategories(ValueError):
+class NotResidentEligible(ValueError):
+    """The run is not the plain per-attribute model loop after all (only known once the error cells are NULLed): a discrete target
+    is left with fewer than two classes, a continuous one with no value.  The reference short-cuts those with `PoorModel`
+    (model.py:1008-1017, 779-783); `RepairModel._run` catches this and takes the value-space path, which has that short-cut."""
+
+
+class UnseenCategories(NotResidentEligible):
     """A dirty row holds a categorical feature value that none of the target's training rows has (see `unseen_categories`)."""
 
 
@@ -172,9 +178,9 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
         cnt, _ = table.count_codes(t)
         if t in continuous:
             if int((cnt > 0).sum()) < 1:
-                raise ValueError("continuous target column %d has no non-NULL row to learn from" % t)
+                raise NotResidentEligible("continuous target column %d has no non-NULL row to learn from" % t)
         elif int((cnt > 0).sum()) < 2:
-            raise ValueError("target column %d has fewer than two classes among its non-NULL rows; the reference short-cuts such "
+            raise NotResidentEligible("target column %d has fewer than two classes among its non-NULL rows; the reference short-cuts such "
                              "attributes with a constant model (model.py:1008-1017) -- drop it from `targets`" % t)
         label_counts[t] = cnt
     t_prep = time.perf_counter() - t0
@@ -318,6 +324,14 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
                 new[live] = np.searchsorted(live_codes, remaps[j][live]).astype(np.int32)
                 dicts[j] = dicts[j][live_codes]
                 remaps[j] = new
+    if error_cells is not None and not detect_nulls and not constraints:
+        # every error cell is known and NULLed: the class counts the models will see are final.  Say so BEFORE anything is uploaded
+        # (a constraint / regex / user-given cell may hold the only occurrence of a class; an all-NULL numeric column has no value)
+        for t in targets:
+            j = pos[t]
+            live = len(np.unique(indices[j][indices[j] >= 0]))
+            if live < (1 if t in continuous_columns else 2):
+                raise NotResidentEligible("target `%s` is left with %d distinct value(s) once the error cells are removed" % (t, live))
     table = engine.upload_dictionaries(indices, remaps)
     for j, c in enumerate(cols):               # numeric columns: bin bounds at the midpoints of the values, like LightGBM on raw numbers
         if dicts[j].dtype != object and len(dicts[j]) > 0:

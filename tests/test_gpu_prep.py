@@ -226,3 +226,27 @@ def test_candidate_distributions_edge_cases():
     K = int(cards[3])
     assert rows.tolist() == [1, 2] and (cls[:, K:] == -1).all() and (pr[:, K:] == 0).all() and (np.sort(cls[:, :K], axis=1) == np.arange(K)).all()
     assert (np.diff(pr[:, :K], axis=1) <= 0).all() and np.allclose(pr.sum(1), 1.0)
+
+
+def test_concurrent_gathers_and_counts_on_one_table():
+    """The folds of a resident hyper-parameter search gather from ONE training table on a thread pool (pipeline.search_on_table;
+    ctypes drops the GIL).  The table's stream and scratch are shared, so the library serialises these calls per table:
+    24 threads x 6 rounds of different row sets must each get exactly their rows."""
+    from concurrent.futures import ThreadPoolExecutor
+    tab, dirty, cards = _table(300000, 6, seed=21, null_ratio=0.03)
+    rng = np.random.default_rng(5)
+    jobs = [np.sort(rng.choice(300000, size=int(rng.integers(1, 200000)), replace=False)) for _ in range(48)]
+
+    def run(i):
+        rows = jobs[i]
+        sub = tab.gather_rows(rows)
+        cnt, n_null = tab.count_codes(i % 6)
+        got = np.stack([sub.read_column(c) for c in range(6)])
+        return i, got, cnt, n_null
+
+    with ThreadPoolExecutor(24) as ex:
+        for _ in range(3):
+            for i, got, cnt, n_null in ex.map(run, range(48)):
+                assert np.array_equal(got, dirty[:, jobs[i]]), "gather %d returned other rows" % i
+                col = dirty[i % 6]
+                assert n_null == int((col < 0).sum()) and np.array_equal(cnt, np.bincount(col[col >= 0], minlength=int(cards[i % 6])))

@@ -107,6 +107,70 @@ def test_hyperparameter_search_on_resident_tables_equals_the_value_space_search(
     pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
 
 
+def _given_cells_model(df, cells, **opts):
+    m = RepairModel().setInput(df).setRowId("tid").setErrorCells(cells)
+    for k, v in dict({"model.hp.max_evals": "1", "model.lgb.n_estimators": "12", "model.lgb.learning_rate": "0.2"}, **opts).items():
+        m = m.option(k, str(v))
+    return m
+
+
+def _both_paths_given_cells(df, cells, engine, repair_data=False):
+    import os
+    slow = _given_cells_model(df, cells)
+    os.environ["REPAIR_RESIDENT"] = "0"
+    try:
+        a = slow.run(repair_data=repair_data)
+    finally:
+        os.environ.pop("REPAIR_RESIDENT", None)
+    fast = _given_cells_model(df, cells)
+    fast._engine_override = engine
+    b = fast.run(repair_data=repair_data)
+    return a, b, fast
+
+
+def test_error_cell_holding_the_only_occurrence_of_a_class_falls_back(oracle_backend):
+    """`domain_stats` is counted before the error cells are NULLed.  A given error cell that holds the only occurrence of
+    one of a target's two classes leaves one class: the reference short-cuts that attribute with PoorModel (model.py:1008-1017); the
+    resident pipeline says NotResidentEligible before uploading anything and `_run` takes the value-space path."""
+    df, _, _, _ = _synthetic_frame(400, 5, seed=23, null_ratio=0.0)
+    df["c0"] = "a"
+    df.loc[7, "c0"] = "b"                                            # the only "b"
+    cells = pd.DataFrame({"tid": [7, 11, 12], "attribute": ["c0", "c1", "c2"]})
+    a, b, fast = _both_paths_given_cells(df, cells, OracleEngine())
+    assert getattr(fast, "_last_resident_info", None) is None        # fell back
+    pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
+    assert set(b["attribute"]) <= {"c0", "c1", "c2"} and (b[b["attribute"] == "c0"]["repaired"] == "a").all()
+
+
+def test_repair_data_with_null_cells_that_are_not_error_cells_falls_back(oracle_backend):
+    """the repair UDF fills every NULL target cell of a dirty row (model.py:1128,1133), not only the listed error cells."""
+    df, _, _, _ = _synthetic_frame(500, 5, seed=29, null_ratio=0.0)
+    df.loc[20, "c1"] = None                                          # a NULL in a target column of a dirty row, NOT an error cell
+    cells = pd.DataFrame({"tid": [20, 21, 30], "attribute": ["c2", "c1", "c2"]})
+    a, b, fast = _both_paths_given_cells(df, cells, OracleEngine(), repair_data=True)
+    assert getattr(fast, "_last_resident_info", None) is None
+    pd.testing.assert_frame_equal(a.sort_values("tid").reset_index(drop=True), b.sort_values("tid").reset_index(drop=True))
+    assert b.loc[b["tid"] == 20, "c1"].notna().all()                 # filled, as the reference's UDF does
+    # without such cells the same call stays resident
+    df2, _, _, _ = _synthetic_frame(500, 5, seed=29, null_ratio=0.0)
+    a2, b2, fast2 = _both_paths_given_cells(df2, cells, OracleEngine(), repair_data=True)
+    assert getattr(fast2, "_last_resident_info", None) is not None
+    pd.testing.assert_frame_equal(a2.sort_values("tid").reset_index(drop=True), b2.sort_values("tid").reset_index(drop=True))
+
+
+def test_unseen_category_in_a_dirty_row_is_missing_on_both_paths(oracle_backend):
+    """a dirty row carries a category of feature c3 that no training row of target c1 shows.  The value-space path's per-model
+    dictionary has no code for it (missing); the resident table marks categorical columns (`set_column_kind`) so the model treats it as
+    missing too: same repairs, no fallback."""
+    df, _, _, _ = _synthetic_frame(1500, 5, seed=31, null_ratio=0.0)
+    df.loc[40, "c3"] = "zz_never_seen"                               # only this row holds it ...
+    df.loc[40, "c1"] = None                                          # ... and its c1 is NULL: not a training row of the c1 model
+    df.loc[[50, 60, 70], "c1"] = None
+    a, b = _both_paths(df, OracleEngine())
+    assert (a["tid"] == 40).any()
+    pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
+
+
 @pytest.mark.gpu
 def test_gpu_run_takes_the_resident_path_and_matches_both_references():
     """HIP engine vs the HIP estimators of the value-space path on 20 000 rows; then 1M rows through `run()`: every repaired label
