@@ -37,7 +37,8 @@ def make_params(**kw):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "rgbm_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("rgbm_oracle.c", "rgbm_oracle_train.inc")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
 
@@ -51,6 +52,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_train.restype = C.c_int
         _lib.orc_train2.restype = C.c_int
+        _lib.orc_train2_f32.restype = C.c_int
         _lib.orc_predict.restype = C.c_int
         _lib.orc_model_save.restype = C.c_int
         _lib.orc_model_load.restype = C.c_int
@@ -108,8 +110,11 @@ class OracleModel:
 
 
 def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample_weight=None, feature_values=None,
-          categorical=None, **params):
-    """X: [F][N] int32 codes column-major; y_code: [N] int32.  feature_values: {feature index: ascending distinct values} of the
+          categorical=None, numerics="spec", **params):
+    """X: [F][N] int32 codes column-major; y_code: [N] int32.  numerics: "spec" = the numerics the product implements (DESIGN.md
+    section 3: LightGBM's float32 g / h per row, EXACT integer histogram sums on a fixed-point grid), "lightgbm_f32" = LightGBM's own
+    arithmetic (the same float32 g / h, double histogram sums in row order) -- the two modes of oracle/rgbm_oracle_train.inc, compared by
+    tests/test_numerics_bound.py.  feature_values: {feature index: ascending distinct values} of the
     NUMERIC features (bin bounds at value midpoints, like Table.set_column_values on the product side); categorical: indices of the
     CATEGORICAL features (codes no training row holds are missing at prediction time, like Table.set_column_kind)."""
     X = np.ascontiguousarray(X, np.int32)
@@ -133,9 +138,10 @@ def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample
     if categorical:
         kinds = np.zeros(F, np.int32)
         kinds[list(categorical)] = 1
-    rc = lib().orc_train2(_p(X, C.c_int32), C.c_int64(N), C.c_int32(F), _p(n_codes, C.c_int32),
-                          _p(y_code, C.c_int32), C.c_int32(n_y_codes), _p(yv, C.c_double),
-                          _p(cw, C.c_double), _p(sw, C.c_double), C.byref(p), fv_arr, _p(kinds, C.c_int32), C.byref(h))
+    fn = {"spec": lib().orc_train2, "lightgbm_f32": lib().orc_train2_f32}[numerics]
+    rc = fn(_p(X, C.c_int32), C.c_int64(N), C.c_int32(F), _p(n_codes, C.c_int32),
+            _p(y_code, C.c_int32), C.c_int32(n_y_codes), _p(yv, C.c_double),
+            _p(cw, C.c_double), _p(sw, C.c_double), C.byref(p), fv_arr, _p(kinds, C.c_int32), C.byref(h))
     if rc:
         raise RuntimeError("orc_train failed: %d" % rc)
     return OracleModel(h)

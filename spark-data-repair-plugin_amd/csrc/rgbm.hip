@@ -30,9 +30,8 @@
 #include "rgbm_host.h"
 #include "rgbm_kernels.h"
 #include "rgbm_level.h"
-#include "rgbm_small.h"
 
-#define RGBM_VERSION 102   // numerics spec v1.02 (v1.01: hessian scale exact for power-of-two bounds; v1.02: h derived from the quantised g)
+#define RGBM_VERSION 200   // numerics spec v2: float32 (g, h) as LightGBM computes them, exact integer histogram sums on a fixed-point grid (rgbm_numerics.h)
 
 namespace {
 
@@ -339,6 +338,23 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 
 
 // LightGBM utils/random.h (as remembered)
+// Test / experiment switches, read from the environment at the start of every training call (tests flip them between calls); none
+// is needed in normal use.  RGBM_GROWER=leafwise|level, RGBM_TIMING=1 (host wall-clock of the phases to stderr), RGBM_LV_LDS=bytes
+// (shrinks the LDS pool of the level passes: more built-slot windows per level), RGBM_LV_BLOCKS / RGBM_MT_BLOCKS (row blocks per class
+// tree of the root / level passes), RGBM_MT_TREES (cap on the class trees per level-pass workgroup), RGBM_JOINT_ROOT=0.
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; bool joint_root = true; bool timing = false; };
+RunSwitches read_switches() {
+    RunSwitches w;
+    if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
+    if (const char* e = getenv("RGBM_LV_LDS")) w.lv_lds = atoi(e);
+    if (const char* e = getenv("RGBM_LV_BLOCKS")) w.lv_blocks = atoll(e);
+    if (const char* e = getenv("RGBM_MT_BLOCKS")) w.mt_blocks = atoll(e);
+    if (const char* e = getenv("RGBM_MT_TREES")) w.mt_T = atoi(e);
+    if (const char* e = getenv("RGBM_JOINT_ROOT")) w.joint_root = atoi(e) != 0;
+    w.timing = getenv("RGBM_TIMING") != nullptr;
+    return w;
+}
+
 struct LgbRand {
     uint32_t x;
     explicit LgbRand(uint32_t seed) : x(seed) {}
@@ -408,7 +424,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     hipEvent_t ev_begin, ev_end; HIPCHK(hipEventCreate(&ev_begin)); HIPCHK(hipEventCreate(&ev_end));
     HIPCHK(hipEventRecord(ev_begin, s));
 
-    const bool timing = getenv("RGBM_TIMING") != nullptr;   // host wall-clock of the phases, to stderr
+    const RunSwitches sw = read_switches();
+    const bool timing = sw.timing;   // host wall-clock of the phases, to stderr
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     // ---- 1. code frequencies of the training rows (features + the target itself)
@@ -480,7 +497,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             m.rep_shift = sh; m.fast_base = cm.fast_slots; m.wide_off = cm.wide_bins;
             cm.fast_slots += m.nbins << sh; cm.wide_bins += m.nbins;
         }
-        lds_hist = std::max(lds_hist, (size_t)cm.fast_slots * 8 + (size_t)cm.wide_bins * 16);
+        lds_hist = std::max(lds_hist, (size_t)cm.fast_slots * 16);      // leaf-wise k_hist: replicated (g, h) slots, 16 B each
     }
 
     // ---- 3. label statistics, init scores (BoostFromScore), quantisation scales
@@ -523,10 +540,11 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (obj == 2) { bound_g = (ymax - ymin) * w_max; if (!(bound_g > 0.0)) bound_g = 1.0; bound_h = w_max; }
     else if (obj == 0) { bound_g = w_max; bound_h = 0.25 * w_max; }
     else { bound_g = w_max; bound_h = factor * 0.25 * w_max; }
-    // hessians reach their bound exactly (regression: h = w): bound * 2^e_h must stay STRICTLY below 2^21, so the scale uses the
-    // frexp exponent (one less than the gradients' rule when the bound is an exact power of two; numerics spec v1.01)
-    int ex_h = 0; (void)std::frexp(bound_h, &ex_h);
-    const int e_g = 20 - ceil_log2(bound_g), e_h = 21 - ex_h;
+    // fixed-point grid of the histogram sums (numerics v2, rgbm_numerics.h): |g| <= bound_g and h <= bound_h hold for every row, so with
+    // e = E - ceil_log2(bound) every converted value is at most 2^E in magnitude and an int64 sum over all training rows (of all ranks)
+    // stays below 2^62
+    int Ebits = 62 - ceil_log2((double)std::max<int64_t>(n_train, 2)); if (Ebits > 40) Ebits = 40;
+    const int e_g = Ebits - ceil_log2(bound_g), e_h = Ebits - ceil_log2(bound_h);
 
     TrainConst tc; memset(&tc, 0, sizeof(tc));
     tc.sg = std::ldexp(1.0, e_g); tc.sh = std::ldexp(1.0, e_h); tc.inv_sg = std::ldexp(1.0, -e_g); tc.inv_sh = std::ldexp(1.0, -e_h);
@@ -544,21 +562,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint4> d_rec((size_t)nchunk * N);
     hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tab.codes.p, (long long)N, 0ll, (long long)N,
                        d_cols.p, d_ncod.p, d_lut_off.p, d_lut.p, d_miss.p, F, nchunk, d_rec.p);
-    // grower choice: the level-synchronous streaming grower (rgbm_level.h) whenever it applies; RGBM_GROWER=leafwise
-    // forces the index-list grower (both are HIP; they produce identical models)
-    // A third grower exists as an opt-in (rgbm_small.h, RGBM_GROWER=small, or RGBM_SMALL_ROWS=n for "up to n training rows"): the leaf-wise
-    // loop of one class tree inside ONE launch.  It produces the same models (tests/test_gpu_growers.py runs every case through all
-    // three growers) but measured slower than the level grower's kernel chain on the sizes it was meant for (MI355X, 10 000 rows:
-    // 0.72 vs 0.50 ms per boosting iteration; the reference-default job 3.43 vs 1.88 s), so nothing selects it by default.
-    const char* genv = getenv("RGBM_GROWER");
+    // grower choice: the level-synchronous streaming grower (rgbm_level.h) whenever it applies; RGBM_GROWER=leafwise forces the
+    // index-list grower (both are HIP; they produce identical models)
     const bool use_bagging = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
-    long long small_rows = 0;
-    if (const char* e = getenv("RGBM_SMALL_ROWS")) small_rows = atoll(e);
-    const size_t sm_hist = std::max<size_t>(lds_hist, (size_t)p.num_leaves * 8);
-    const size_t sm_bytes = sm_lds_bytes(sm_hist, p.num_leaves, F);
-    const bool small_ok = !dp && !stats && F <= SM_MAX_FEATS && p.num_leaves >= 2 && p.num_leaves <= SM_MAX_LEAVES && sm_bytes <= 160 * 1024;
-    const bool small_mode = small_ok && (genv ? strcmp(genv, "small") == 0 : n_train <= small_rows);
-    const bool level_mode = !small_mode && p.max_depth >= 1 && p.max_depth <= LV_MAX_DEPTH && F <= 255 && !(genv && strcmp(genv, "leafwise") == 0);
+    const bool level_mode = p.max_depth >= 1 && p.max_depth <= LV_MAX_DEPTH && F <= 255 && sw.grower != 2;
     if (dp && (!level_mode || use_bagging || sample_weight_host))
         throw std::invalid_argument("row-sharded training supports the level grower (1 <= max_depth <= 7) without bagging / per-row weights");
     DevBuf<int32_t> d_base; DevBuf<unsigned int> d_counter(1); d_counter.zero(s);
@@ -566,23 +573,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         d_base.alloc(n_train);
         hipLaunchKernelGGL(k_iota_train, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, (long long)N, d_base.p, d_counter.p);
     }
-    // Split mode decision (needed here: it picks the layout of the gradient buffer).  Split mode (route + stream kernels) pays off once a
-    // level pass is bound by its traffic / LDS atomics rather than by launch latency; small fits keep the fused pass (one launch fewer
-    // per level).  RGBM_LEVEL_SPLIT=0/1 overrides.
-    bool split_mode = level_mode && p.max_depth >= 2 && (long long)K * N >= (1ll << 21);
-    if (const char* e = getenv("RGBM_LEVEL_SPLIT")) split_mode = level_mode && p.max_depth >= 2 && atoi(e) != 0;
-    // g-only gradient buffer (numerics v1.02: h is a function of the quantised g, the label and its weight): the level passes of split
-    // mode then stream 4 B instead of 8 per (row, class tree).  Needs byte labels and per-label weights (<= 128 labels) only.  RGBM_G_ONLY=0 disables it.
-    // (regression + bagging keeps (g,h): an out-of-bag row has g = 0 like an in-bag row with a zero residual, but must not add its h = w)
-    bool g_only = split_mode && !sample_weight_host && n_y <= 128 && !(obj == 2 && use_bagging);
-    if (const char* e = getenv("RGBM_G_ONLY")) g_only = g_only && atoi(e) != 0;
-    tc.g_only = g_only ? 1 : 0;
-    DevBuf<int2> d_gh(g_only ? ((size_t)K * N + 1) / 2 : (size_t)K * N); d_gh.zero(s);
-    DevBuf<uint8_t> d_ylab; DevBuf<double> d_cw32;
-    if (g_only) {
-        d_ylab.alloc(N);
-        hipLaunchKernelGGL(k_ylab, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, (long long)N, d_ylab.p);
-    }
+    DevBuf<float2> d_gh((size_t)K * N); d_gh.zero(s);      // float32 (g, h) of every (row, class tree); non-training rows stay (0, 0)
     DevBuf<double> d_score((size_t)K * N), d_init(K);
     d_init.upload(init.data(), K, s);
     hipLaunchKernelGGL(k_init_score, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_score.p, (long long)N, K, d_init.p);
@@ -594,51 +585,37 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         d_state.alloc(K); d_leaves.alloc((size_t)K * NL); d_cand.alloc((size_t)K * 2 * F);
         d_upd.alloc((size_t)K * NL); d_sorted.alloc((size_t)K * NL * 3);
     }
-    // level grower state
+    // ---- level grower state
     LevelConst lc; memset(&lc, 0, sizeof(lc));
-    DevBuf<uint8_t> d_node_a, d_node_b; DevBuf<LvPlan> d_plan; DevBuf<LvLayout> d_layout, d_lay_table; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
+    DevBuf<uint8_t> d_node; DevBuf<LvPlan> d_plan; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     int n_hnodes = 1;
-    bool use_reduce = false;   // sum the per-workgroup partials in a separate kernel (many workgroups per class tree, or row-sharded)
+    bool use_reduce = false;   // root pass: sum the per-workgroup partials in a separate kernel (many workgroups per class tree, joint bins, or row-sharded)
     // joint bins for the root pass (rgbm_level.h, k_pack_joint): a second record whose bytes hold GROUPS of low-cardinality features
     bool joint_root = false; int vtotbins = 0;
     LevelConst lcj; memset(&lcj, 0, sizeof(lcj));
-    DevBuf<FeatMeta> d_vfmeta; DevBuf<ChunkMeta> d_vcmeta; DevBuf<LvLayout> d_layout_j; DevBuf<uint4> d_rec_j; DevBuf<HistBin> d_part_j, d_red_j;
+    DevBuf<FeatMeta> d_vfmeta; DevBuf<ChunkMeta> d_vcmeta; DevBuf<uint4> d_rec_j; DevBuf<HistBin> d_part_j, d_red_j;
     DevBuf<JointFeat> d_jf; DevBuf<int16_t> d_binfeat;
-    // Experiment (RGBM_LAZY_SCORE=1, off): defer AddScore into the next iteration's gradient kernel so that the scores are touched
-    // once per iteration.  Measured on MI355X (K=64, 10M rows): k_level_final 2.48 -> 0.70 ms, but the per-(row, class) gather of
-    // the node delta inside the FP64-bound gradient kernel costs more than it saves (2.8 -> 6.8 ms).
-    const bool lazy_score = level_mode && obj == 1 && K <= 112 && getenv("RGBM_LAZY_SCORE") != nullptr;
-    std::vector<int> lv_groups(LV_MAX_DEPTH + 1, 1);
+    // one k_level_mt launch of a level: (chunk, window of built slots); the first one of a level routes
+    struct MtLaunch { int ch, slot0, nslots, route, T, G, gx; };
+    std::vector<std::vector<MtLaunch>> mt_plan(LV_MAX_DEPTH + 1);
+    std::vector<int> mt_gx(LV_MAX_DEPTH + 1, 8);           // row blocks per class tree of a level's launches (one value per level: the partials share it)
     if (level_mode) {
         const long long ntiles = (N + LV_TILE - 1) / LV_TILE;
-        // workgroups per (class tree, chunk): one 1024-thread workgroup per CU; pick the count that fills whole
-        // rounds of 256 CUs best, with <= 2^22 rows per workgroup (32-bit carry words) and >= 1 tile each
         lc.lds_bytes = LV_LDS_BYTES;
-        if (const char* e = getenv("RGBM_LV_LDS")) { int v = atoi(e); if (v >= 65536 && v <= LV_LDS_BYTES) lc.lds_bytes = v; }
-        if (const char* e = getenv("RGBM_LV_DRAIN_SHIFT")) { int v = atoi(e); if (v >= 0 && v <= 31) lc.drain_shift = v; }   // testing: force packed-slot drains
-        const long long cu_slots = 256ll * std::max(1, std::min(LV_LDS_TOTAL / lc.lds_bytes, 2048 / LV_THREADS));   // resident workgroups
-        const long long per = (long long)K * nchunk;
-        long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
-        long long gx = gmin; double best_eff = -1.0;
-        for (long long g = gmin; g < gmin + 512 && g <= std::max(gmin, ntiles); ++g) {
-            const long long tot = g * per, rounds = (tot + cu_slots - 1) / cu_slots;
-            const double eff = (double)tot / (double)(rounds * cu_slots);
-            if (eff > best_eff + 1e-9) { best_eff = eff; gx = g; }
-            if (tot >= cu_slots && eff >= 0.999) break;
-        }
-        gx = std::min<long long>(gx, std::max<long long>(gmin, ntiles));
-        lc.gx = (int)gx; lc.max_built = 1 << std::max(0, p.max_depth - 2); lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
+        if (sw.lv_lds >= 65536 && sw.lv_lds <= LV_LDS_BYTES) lc.lds_bytes = sw.lv_lds;      // testing: a smaller LDS pool forces several built-slot windows per level
+        lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
         lc.num_leaves = NL; lc.max_depth = p.max_depth; lc.min_data_in_leaf = p.min_data_in_leaf; lc.N = N; lc.NS = (N + 15) & ~15ll;
+        lc.sg = tc.sg; lc.sh = tc.sh;
+        lc.sib_local = (dp && g_comm.rank == 0) ? 1 : 0;
         n_hnodes = (1 << p.max_depth) - 1;
-        lc.split_mode = split_mode ? 1 : 0;
-        lc.inv_sg = tc.inv_sg; lc.sh = tc.sh; lc.factor = tc.factor; lc.objective = obj; lc.n_labels = n_y;
-        if (split_mode) {
-            // Row blocks instead of strided tiles (k_level_pass): a multiple of 8 blocks per class tree (one XCD each).  Every block costs
-            // a workgroup's set-up, pipeline ramp and flush (~10-20 us), every round of 256 workgroups ends with a tail; measured at
-            // K = 64 (10M rows): 8 blocks 23.0, 16 blocks 21.0, 40 blocks 23.2 ms per iteration.  So: about four rounds when the class
-            // trees alone nearly fill the chip (>= 16 of them), else the fewest blocks that fill one round; the multiple of 8 with the
-            // best last-round occupancy, the smallest among equals.  RGBM_LV_BLOCKS overrides.
+        // ---- root pass: one 1024-thread workgroup per CU and (class tree, row block, chunk).  Contiguous row blocks, a multiple of 8 per
+        // class tree with all class trees of a row block on one XCD (k_level_root), about four rounds of 256 workgroups when the class
+        // trees alone nearly fill the chip (measured at K = 64, 10M rows: 8 / 16 / 40 blocks per class tree = 23.0 / 21.0 / 23.2 ms per
+        // iteration), else the fewest blocks that fill one round; <= 2^22 rows per workgroup.  RGBM_LV_BLOCKS overrides.
+        {
+            const long long cu_slots = 256, per = (long long)K * nchunk;
+            const long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
             auto eff_of = [&](long long g) { const long long tot = g * per, rounds = (tot + cu_slots - 1) / cu_slots; return (double)tot / (double)(rounds * cu_slots); };
             const long long gfloor = std::max<long long>(8, (gmin + 7) / 8 * 8), gcap = std::max<long long>(gfloor, std::min<long long>(512, (ntiles + 7) / 8 * 8));
             long long g2 = gfloor; double best2 = -1.0;
@@ -649,43 +626,56 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 if (e >= 0.99) break;
             }
             if (best2 < 0.0) for (long long g = gfloor; g <= gcap; g += 8) { const double e = eff_of(g); if (e > best2 + 1e-9) { best2 = e; g2 = g; } if (e >= 0.99) break; }
-            if (const char* e = getenv("RGBM_LV_BLOCKS")) { long long v = atoll(e); if (v >= 1) g2 = (v + 7) / 8 * 8; }
-            lc.gx = (int)g2;
+            if (sw.lv_blocks >= 1) g2 = (sw.lv_blocks + 7) / 8 * 8;
+            lc.gx = (int)g2; lc.xcd_blocks = 1; lc.max_built = 1;
         }
-        lc.sib_local = (dp && g_comm.rank == 0) ? 1 : 0;
-        d_node_a.alloc((size_t)K * lc.NS);
-        if (!split_mode) d_node_b.alloc((size_t)K * lc.NS);            // split mode routes in place
-
-        d_plan.alloc(K); d_layout.alloc((size_t)K * nchunk); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
-        d_part.alloc((size_t)K * lc.gx * lc.max_built * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
-        d_count.alloc((size_t)K * 256); use_reduce = dp || lc.gx > 4;
-        if (dp) d_count_g.alloc((size_t)K * 256);
-        if (use_reduce) { d_part_red.alloc((size_t)K * lc.max_built * tc.totbins + (size_t)K * 128 /* K*256 int64 counts */); }
-        d_leafnode.alloc((size_t)K * LV_MAX_LEAVES); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
-        for (int level = 1; level < p.max_depth; ++level) {   // worst-case histogram groups of pass `level`
-            const int n_exp = 1 << (level - 1);
-            long long npg = n_exp;
+        for (int ch = 0; ch < nchunk; ++ch)
+            if ((long long)lv_slots(fmeta.data() + cmeta[ch].first_feat, cmeta[ch].nfeat, 0) * 16 + LV_ROOT_FIXED > lc.lds_bytes)
+                throw std::invalid_argument("histogram of one node exceeds LDS");
+        // ---- level passes (k_level_mt).  Per chunk: how many built nodes the LDS holds next to the rings (cap), hence how many class
+        // trees share a workgroup (T = cap / worst-case built nodes of the level, 2^(L-1)) or, when one class tree's nodes do not fit,
+        // how many launches ("windows" of built slots) the level takes.  Every class tree group gets the same row blocks, a multiple of 8
+        // (one XCD each), enough to fill the chip once (<= 2^22 rows per workgroup).
+        size_t part_items = (size_t)K * lc.gx;                   // root partials: one node per (class tree, row block)
+        for (int level = 1; level < p.max_depth; ++level) {
+            const int worst = 1 << (level - 1);
+            int G_first = 1;
             for (int ch = 0; ch < nchunk; ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
-                long long fit = (lc.lds_bytes - lv_fixed_bytes(cmeta[ch], LV_MAX_EXP, fm) - (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 2) / lv_node_bytes(fm, cmeta[ch], 0);
-                if (fit < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
-                npg = std::min(npg, fit);
+                const long long node_bytes = (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 16;
+                long long cap = (lc.lds_bytes - mt_fixed_bytes(cmeta[ch].wide_bins)) / std::max<long long>(node_bytes, 1);
+                cap = std::min<long long>(cap, MT_MAX_NODES);
+                if (cap < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
+                const int win = (int)std::min<long long>(worst, cap);                    // built slots per launch
+                int T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(cap / win, MT_MAX_T), std::min<long long>(K, MT_MAX_RT / (2 * worst))));
+                if (sw.mt_T >= 1) T = std::max(1, std::min(T, sw.mt_T));
+                const int G = (K + T - 1) / T;
+                if (ch == 0) G_first = G;
+                for (int s0 = 0; s0 < worst; s0 += win)
+                    mt_plan[level].push_back(MtLaunch{ch, s0, win, (ch == 0 && s0 == 0) ? 1 : 0, T, G, 0});
             }
-            lv_groups[level] = (int)((n_exp + npg - 1) / npg);
+            const long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
+            long long gx = std::max<long long>(8, (256 / std::max(1, G_first)) / 8 * 8);
+            gx = std::max<long long>(gx, (gmin + 7) / 8 * 8);
+            const long long nwt = (N + MT_WT_ROWS - 1) / MT_WT_ROWS;
+            gx = std::min<long long>(gx, std::max<long long>(8, (nwt / MT_WAVES + 7) / 8 * 8));   // at least ~one wave tile per wave
+            if (sw.mt_blocks >= 1) gx = (sw.mt_blocks + 7) / 8 * 8;
+            mt_gx[level] = (int)gx;
+            for (auto& L : mt_plan[level]) L.gx = (int)gx;
+            part_items = std::max(part_items, (size_t)K * (size_t)gx * (size_t)worst);
         }
-        // packed-slot layouts for every possible group size, chosen once on the host (greedy, lv_choose_layout)
-        std::vector<LvLayout> lay_table((size_t)nchunk * (LV_MAX_BUILT + 1));
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
-            for (int g = 0; g <= LV_MAX_BUILT; ++g)
-                lv_choose_layout(fm, cmeta[ch], std::max(g, 1), lc.lds_bytes - lv_fixed_bytes(cmeta[ch], LV_MAX_EXP, fm), lay_table[(size_t)ch * (LV_MAX_BUILT + 1) + g]);
-        }
-        d_lay_table.alloc(lay_table.size()); d_lay_table.upload(lay_table.data(), lay_table.size(), s);
-        HIPCHK(hipStreamSynchronize(s));   // lay_table is a local
-        // Joint bins for the root pass (split mode: the tables where the root pass runs at the LDS-atomic rate).  Best-fit-decreasing
-        // packing of the features into groups whose bin counts multiply to <= 256; worth it when it saves at least two atomics per row
-        // and the groups fit one 16-byte record.  RGBM_JOINT_ROOT=0 disables it (same models either way: the sums are exact integers).
-        joint_root = split_mode && !(getenv("RGBM_JOINT_ROOT") && atoi(getenv("RGBM_JOINT_ROOT")) == 0);
+        d_node.alloc((size_t)K * lc.NS);
+        d_plan.alloc(K); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
+        d_part.alloc(part_items * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
+        d_count.alloc((size_t)K * 256); use_reduce = dp || lc.gx > 4;
+        if (dp) d_count_g.alloc((size_t)K * 256);
+        const int max_built_all = 1 << std::max(0, p.max_depth - 2);
+        d_part_red.alloc((size_t)K * max_built_all * tc.totbins + (size_t)K * 128 /* K*256 int64 counts */);
+        d_leafnode.alloc((size_t)K * LV_MAX_LEAVES); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
+        // Joint bins for the root pass (the tables where the root pass runs at the LDS-atomic rate).  Best-fit-decreasing packing of the
+        // features into groups whose bin counts multiply to <= 256; worth it when it saves at least two atomics per row and the groups
+        // fit one 16-byte record.  RGBM_JOINT_ROOT=0 disables it (same models either way: the sums are exact integers).
+        joint_root = sw.joint_root && (long long)K * N >= (1ll << 21);
         if (joint_root) {
             std::vector<int> order(F); for (int f = 0; f < F; ++f) order[f] = f;
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fmeta[a].nbins > fmeta[b].nbins; });
@@ -716,35 +706,26 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                     }
                 }
                 vtotbins = vcm.wide_bins;
-                const long long avail = (long long)lc.lds_bytes - lv_fixed_bytes(vcm, LV_MAX_EXP, vfm.data());
-                if (avail < lv_layout_bytes(vfm.data(), vcm, 0, 1)) joint_root = false;
+                if ((long long)lv_slots(vfm.data(), VF, 0) * 16 + LV_ROOT_FIXED > lc.lds_bytes) joint_root = false;
                 else {
-                    LvLayout lay1; lv_choose_layout(vfm.data(), vcm, 1, avail, lay1);
-                    std::vector<LvLayout> layk((size_t)K, lay1);
                     d_vfmeta.alloc(VF); d_vfmeta.upload(vfm.data(), VF, s); d_vcmeta.alloc(1); d_vcmeta.upload(&vcm, 1, s);
-                    d_layout_j.alloc(K); d_layout_j.upload(layk.data(), K, s);
                     d_jf.alloc(F); d_jf.upload(jf.data(), F, s); d_binfeat.alloc(binfeat.size()); d_binfeat.upload(binfeat.data(), binfeat.size(), s);
                     d_rec_j.alloc((size_t)N);
                     hipLaunchKernelGGL(k_pack_joint, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_rec.p, (long long)N, F, d_jf.p, d_rec_j.p);
                     d_part_j.alloc((size_t)K * lc.gx * vtotbins); d_red_j.alloc((size_t)K * vtotbins + (size_t)K * 128 /* k_level_reduce parks the counts behind the bins */);
                     lcj = lc; lcj.nchunk = 1; lcj.F = VF; lcj.totbins = vtotbins; lcj.max_built = 1;
-                    if (!use_reduce) { use_reduce = true; d_part_red.alloc((size_t)K * lc.max_built * tc.totbins + (size_t)K * 128); }
+                    use_reduce = true;
                     HIPCHK(hipStreamSynchronize(s));   // the vectors above are locals
                 }
             }
         }
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<true, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_pass<false, true, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_root, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
@@ -753,12 +734,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     TreeOut to{t_L.p, t_feat.p, t_theta.p, t_dleft.p, t_left.p, t_right.p, t_gain.p, t_val.p, t_cnt.p};
     DevBuf<double> d_cw, d_yv, d_sw;
     if (class_weight) { d_cw.alloc(n_y); d_cw.upload(class_weight, n_y, s); }
-    std::vector<double> cw32h;
-    if (g_only && class_weight) {   // the weight a row of label c carries: float32-rounded, as the gradient kernels round it
-        cw32h.resize(n_y); for (int c = 0; c < n_y; ++c) cw32h[c] = (double)(float)class_weight[c];
-        d_cw32.alloc(n_y); d_cw32.upload(cw32h.data(), n_y, s);
-        HIPCHK(hipStreamSynchronize(s));
-    }
     if (y_value) { d_yv.alloc(n_y); d_yv.upload(y_value, n_y, s); }
     if (sample_weight_host) { d_sw.alloc(N); d_sw.upload(sample_weight_host, N, s); }
 
@@ -798,7 +773,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     }
     const unsigned int* n_in_ptr = use_bagging ? d_bagcnt.p : nullptr;
 
-    if (small_mode && sm_bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_small_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_bytes));
     if (!level_mode) {
         if (lds_hist > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
         if (lds_hist > 160 * 1024) throw std::invalid_argument("histogram working set exceeds LDS");
@@ -822,118 +796,97 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     };
 
     const int score_gx = (int)std::max<long long>(1, std::min<long long>((N + 1023) / 1024, (2048 + K - 1) / K));
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> route_ev;
-    uint8_t* const node_b_p = split_mode ? d_node_a.p : d_node_b.p;      // split mode: one node-id array, updated in place
-    const int route_gx = (int)std::max<long long>(1, std::min<long long>(((N + RT_WT_ROWS - 1) / RT_WT_ROWS + 3) / 4, 256ll * 8 / std::max(1, (K + RT_KS - 1) / RT_KS)));
-    auto launch_route = [&]() {
+    auto timed = [&](bool root, auto&& fn) {   // HIP events around one histogram launch, on the stream it is launched on
         hipEvent_t a = nullptr, b = nullptr;
         if (stats) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
-        const dim3 g(route_gx, (K + RT_KS - 1) / RT_KS), blk(RT_THREADS);
-        if (nchunk == 1) hipLaunchKernelGGL((k_level_route<1>), g, blk, 0, s, d_rec.p, d_node_a.p, d_plan.p, lc);
-        else if (nchunk == 2) hipLaunchKernelGGL((k_level_route<2>), g, blk, 0, s, d_rec.p, d_node_a.p, d_plan.p, lc);
-        else hipLaunchKernelGGL((k_level_route<0>), g, blk, 0, s, d_rec.p, d_node_a.p, d_plan.p, lc);
-        if (stats) { HIPCHK(hipEventRecord(b, s)); route_ev.emplace_back(a, b); }
+        fn();
+        if (stats) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
-    auto launch_pass = [&](bool root, int with_hist, int gz) {
-        hipEvent_t a = nullptr, b = nullptr;
-        const bool timed = stats && with_hist;
-        if (split_mode && !root) launch_route();
-        if (timed) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
-        const dim3 pass_grid = split_mode ? dim3((unsigned)lc.gx * (unsigned)K, 1, gz) : dim3(lc.gx, K, gz);
-#define RGBM_LAUNCH_PASS3(R, B, M, S, G, INBAG)                                                                                                 \
-        hipLaunchKernelGGL((k_level_pass<R, B, M, S, G>), pass_grid, dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node_a.p, node_b_p, \
-                           (const uint8_t*)(INBAG), d_plan.p, d_layout.p, d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, with_hist, lc,          \
-                           (const uint8_t*)d_ylab.p, (const double*)(d_cw32.n ? d_cw32.p : nullptr))
-#define RGBM_LAUNCH_PASS2(R, B, M, S, INBAG) RGBM_LAUNCH_PASS3(R, B, M, S, false, INBAG)
-#define RGBM_LAUNCH_PASS(R, B, M, INBAG) RGBM_LAUNCH_PASS2(R, B, M, false, INBAG)
-        // chunk layout: 0 = one 16-feature chunk, 2 = exactly two (both records prefetched), 3 = more
-        if (root && joint_root) {   // the root pass over the joint record: one atomic per feature GROUP and row
-            const dim3 jgrid((unsigned)lc.gx * (unsigned)K, 1, 1);
-            if (g_only) hipLaunchKernelGGL((k_level_pass<true, false, 0, false, true>), jgrid, dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node_a.p, node_b_p, (const uint8_t*)nullptr,
-                                           d_plan.p, d_layout_j.p, d_part_j.p, d_count.p, d_vfmeta.p, d_vcmeta.p, with_hist, lcj, (const uint8_t*)d_ylab.p, (const double*)(d_cw32.n ? d_cw32.p : nullptr));
-            else hipLaunchKernelGGL((k_level_pass<true, false, 0>), jgrid, dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node_a.p, node_b_p, (const uint8_t*)nullptr,
-                                    d_plan.p, d_layout_j.p, d_part_j.p, d_count.p, d_vfmeta.p, d_vcmeta.p, with_hist, lcj, (const uint8_t*)nullptr, (const double*)nullptr);
+    auto launch_root = [&]() {
+        timed(true, [&]() {
+            if (joint_root)   // the root pass over the joint record: one pair of atomics per feature GROUP and row
+                hipLaunchKernelGGL(k_level_root, dim3((unsigned)lc.gx * (unsigned)K, 1, 1), dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node.p, d_plan.p, d_part_j.p,
+                                   d_vfmeta.p, d_vcmeta.p, lcj);
+            else
+                hipLaunchKernelGGL(k_level_root, dim3((unsigned)lc.gx * (unsigned)K, 1, nchunk), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, d_plan.p, d_part.p,
+                                   d_fmeta.p, d_cmeta.p, lc);
+        });
+    };
+    // the k_level_mt launches of one level; returns the LevelConst that describes the partials they wrote
+    auto launch_level = [&](int level) -> LevelConst {
+        LevelConst ll = lc;
+        ll.xcd_blocks = 0; ll.gx = mt_gx[level]; ll.max_built = 1 << (level - 1);
+        for (const MtLaunch& L : mt_plan[level]) {
+            LevelConst l1 = ll;
+            l1.mt_T = L.T; l1.mt_G = L.G; l1.mt_ch = L.ch; l1.mt_slot0 = L.slot0; l1.mt_nslots = L.nslots; l1.mt_route = L.route;
+            const dim3 grid((unsigned)L.G * (unsigned)L.gx), blk(LV_THREADS);
+            const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
+            timed(false, [&]() {
+#define RGBM_LAUNCH_MT(NCHR, BAG, INBAG) hipLaunchKernelGGL((k_level_mt<NCHR, BAG>), grid, blk, lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+                                                            d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, l1)
+                if (use_bagging) { if (nchr == 1) RGBM_LAUNCH_MT(1, true, d_inbag.p); else if (nchr == 2) RGBM_LAUNCH_MT(2, true, d_inbag.p); else RGBM_LAUNCH_MT(0, true, d_inbag.p); }
+                else { if (nchr == 1) RGBM_LAUNCH_MT(1, false, nullptr); else if (nchr == 2) RGBM_LAUNCH_MT(2, false, nullptr); else RGBM_LAUNCH_MT(0, false, nullptr); }
+#undef RGBM_LAUNCH_MT
+            });
         }
-        else if (root) { if (g_only) RGBM_LAUNCH_PASS3(true, false, 0, false, true, nullptr); else RGBM_LAUNCH_PASS(true, false, 0, nullptr); }
-        else if (split_mode) {
-            if (g_only) { if (use_bagging) RGBM_LAUNCH_PASS3(false, true, 0, true, true, d_inbag.p); else RGBM_LAUNCH_PASS3(false, false, 0, true, true, nullptr); }
-            else if (use_bagging) RGBM_LAUNCH_PASS2(false, true, 0, true, d_inbag.p); else RGBM_LAUNCH_PASS2(false, false, 0, true, nullptr);
-            if (const char* e = g_only ? nullptr : getenv("RGBM_DBG_STREAM")) {   // timing experiment: throw-away launches of the stream pass without batches (1) / without ring appends (2)
-                for (int mode = 1; mode <= atoi(e); ++mode) { lc.pad0 = mode; RGBM_LAUNCH_PASS2(false, false, 0, true, nullptr); }
-                lc.pad0 = 0;
-            }
-        }
-        else if (use_bagging) { if (nchunk == 1) RGBM_LAUNCH_PASS(false, true, 0, d_inbag.p); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, true, 2, d_inbag.p); else RGBM_LAUNCH_PASS(false, true, 3, d_inbag.p); }
-        else { if (nchunk == 1) RGBM_LAUNCH_PASS(false, false, 0, nullptr); else if (nchunk == 2) RGBM_LAUNCH_PASS(false, false, 2, nullptr); else RGBM_LAUNCH_PASS(false, false, 3, nullptr); }
-#undef RGBM_LAUNCH_PASS
-#undef RGBM_LAUNCH_PASS2
-#undef RGBM_LAUNCH_PASS3
-        if (timed) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
+        return ll;
     };
 
     DevBuf<int32_t> d_it(1); d_it.zero(s);   // device-side iteration counter (k_next_iteration)
     // one boosting iteration of the level grower after the gradients: an iteration-invariant launch sequence
     auto enqueue_level_growth = [&]() {
             d_count.zero(s);
-            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_fmeta.p, d_cmeta.p, n_in_ptr, (long long)n_train, lc);
+            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, n_in_ptr, (long long)n_train, lc);
             int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
-            // row-sharded: partials of this rank -> compact buffer -> integer all-reduce; the split kernel then sees ONE partial
-            auto exchange = [&](bool root, int nb) -> std::pair<const HistBin*, LevelConst> {
-                if (!use_reduce) return {d_part.p, lc};
+            // partials of this rank -> compact buffer (-> integer all-reduce when row-sharded); the split kernel then sees ONE partial
+            auto exchange = [&](bool root, int nb, const LevelConst& lp) -> std::pair<const HistBin*, LevelConst> {
+                if (root && !use_reduce) return {d_part.p, lp};
                 if (root && joint_root) {   // partials -> one joint histogram per class tree (k_level_reduce in the joint bin space) -> marginals of the real features
                     hipLaunchKernelGGL(k_level_reduce, dim3((vtotbins + 63) / 64, 1, K), dim3(256), 0, s, d_part_j.p, d_red_j.p, d_plan.p, d_count.p, 1, 1, lcj);
                     hipLaunchKernelGGL(k_level_marginal, dim3((tc.totbins + 255) / 256, K), dim3(256), 0, s, d_red_j.p, d_part_red.p, d_plan.p, d_count.p, d_jf.p, d_binfeat.p, vtotbins, lc);
                 } else
-                hipLaunchKernelGGL(k_level_reduce, dim3((tc.totbins + 63) / 64, nb, K), dim3(256), 0, s, d_part.p, d_part_red.p, d_plan.p, d_count.p, root ? 1 : 0, nb, lc);
+                hipLaunchKernelGGL(k_level_reduce, dim3((tc.totbins + 63) / 64, nb, K), dim3(256), 0, s, d_part.p, d_part_red.p, d_plan.p, d_count.p, root ? 1 : 0, nb, lp);
                 if (dp) {
                     const size_t nh = (size_t)K * nb * tc.totbins * 2;          // int64 words of histograms, then K*256 child counts
                     all_reduce(d_part_red.p, nh + (size_t)K * 256, AR_I64, s);
                     hipLaunchKernelGGL(k_counts_unpack, dim3(K), dim3(256), 0, s, reinterpret_cast<const long long*>(d_part_red.p) + nh, d_count_g.p);
                 }
-                LevelConst r = lc; r.gx = 1; r.max_built = nb;
+                LevelConst r = lp; r.gx = 1; r.max_built = nb;
                 return {d_part_red.p, r};
             };
-            launch_pass(true, 1, nchunk);
+            launch_root();
             {
-                auto ex = exchange(true, 1);
+                auto ex = exchange(true, 1, lc);
                 hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p, cntg, d_count.p, d_fmeta.p,
                                    d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             for (int level = 1; level < p.max_depth; ++level) {
-                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, level, tc, lc);
-                launch_pass(false, 1, nchunk * lv_groups[level]);
-                auto ex = exchange(false, 1 << (level - 1));
+                hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_snodes.p, d_lcand.p, d_fmeta.p, level, tc, lc);
+                const LevelConst lp = launch_level(level);
+                auto ex = exchange(false, 1 << (level - 1), lp);
                 hipLaunchKernelGGL(k_level_split<false>, dim3((F + 1) / 2, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
                                    cntg, d_count.p, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
-            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_layout.p, d_lay_table.p, d_snodes.p, d_lcand.p, d_fmeta.p, d_cmeta.p, p.max_depth, tc, lc);
+            hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_snodes.p, d_lcand.p, d_fmeta.p, p.max_depth, tc, lc);
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
-            if (lazy_score) hipLaunchKernelGGL(k_level_final<false>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, node_b_p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
-                                               d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
-            else hipLaunchKernelGGL(k_level_final<true>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node_a.p, node_b_p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
-                                    d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
+            hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
+                               d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
             if (dp) { HIPCHK(hipMemcpyAsync(d_count_g.p, d_count.p, (size_t)K * 256 * 4, hipMemcpyDeviceToDevice, s)); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
             hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, d_it.p, tc);
     };
 
     auto enqueue_grad = [&]() {
-        const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw = sample_weight_host ? d_sw.p : nullptr;
+        const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw_ = sample_weight_host ? d_sw.p : nullptr;
         const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
-        uint8_t* node0 = level_mode ? d_node_a.p : nullptr;
-        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K < 16 && !lazy_score)
-            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K <= 112) {
-            PendingTree pend; memset(&pend, 0, sizeof(pend));
-            if (lazy_score) {
-                pend.node_a = d_node_a.p; pend.node_b = node_b_p; pend.buf = &d_plan.p[0].buf; pend.buf_stride = (long long)(sizeof(LvPlan) / sizeof(int32_t));
-                pend.node_delta = d_ndelta.p; pend.tree_L = t_L.p; pend.itp = d_it.p;
-            }
-            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8 + (size_t)K * 64, s, d_score.p, d_ycol, cw, sw, inbag, d_gh.p, node0, lc.NS, pend, tc);
-        }
-        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
-        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw, inbag, d_gh.p, node0, lc.NS, tc);
+        uint8_t* node0 = level_mode ? d_node.p : nullptr;
+        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1 && K < 16)
+            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1 && K <= 112)
+            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
+        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
+        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
     };
 
     if (timing) HIPCHK(hipStreamSynchronize(s));
@@ -956,14 +909,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         if (level_mode) {
             enqueue_level_growth();
             hipLaunchKernelGGL(k_next_iteration, dim3(1), dim3(1), 0, s, d_it.p);
-            continue;
-        }
-        if (small_mode) {
-            hipLaunchKernelGGL(k_small_tree, dim3(K), dim3(SM_THREADS), sm_bytes, s, d_rec.p, d_gh.p, d_idx0.p, d_idx1.p, d_base.p, d_pool.p, d_fmeta.p, d_cmeta.p,
-                               usedp, to, d_init.p, d_upd.p, d_state.p, d_any.p, d_score.p, n_in_ptr, it, sm_hist, tc);
-            if (use_bagging)
-                hipLaunchKernelGGL(k_score_update_oob, dim3(upd_gx, K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(d_rec.p), d_oob.p, d_bagcnt.p,
-                                   d_state.p, to, d_fmeta.p, d_upd.p, d_score.p, it, tc);
             continue;
         }
         hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);
@@ -1031,11 +976,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             stats->hist_rows = rows_acc; stats->root_rows = root_rows;
             // algorithmic bytes: F bin bytes + 8 B (g,h) per accumulated row
             stats->hist_bytes = rows_acc * ((int64_t)F + 8);
-            for (auto& ev : route_ev) {
-                float m2 = 0.f; HIPCHK(hipEventElapsedTime(&m2, ev.first, ev.second));
-                stats->route_ms += m2; stats->route_launches += 1;
-                (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
-            }
             (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
             return guard.release();
         }

@@ -4,7 +4,7 @@
 //   codes   int32 [C][N]            the label-encoded table, column-major, resident (rgbm_table)
 //   rec     u8    [nchunk][N][16]   per-model bin records: 16 features per 16-byte record so one
 //                                   lane loads one row with a single dwordx4; chunk-major
-//   gh      int2  [K][N]            quantised (gradient, hessian) of every class tree
+//   gh      f32x2 [K][N]            (gradient, hessian) of every class tree: LightGBM's float32 values (numerics v2)
 //   score   f64   [K][N]            raw scores
 //   idx     i32   2 x [K][n_train]  ping-pong row-index lists, partitioned per leaf
 //   pool    i64x2 [K][NL][totbins]  per-leaf histograms (exact integer sums)
@@ -59,7 +59,6 @@ struct TrainConst {
     double l1, l2, min_gain_to_split, min_sum_hessian, learning_rate, factor;
     int32_t min_data_in_leaf, max_depth, num_leaves, F, K, totbins, nchunk, objective;
     long long N, n_train;
-    int32_t g_only, pad_;    // 1: the gradient kernels store the quantised gradient only (int32 [K][N]); the level passes recompute h (h_from_g)
 };
 
 // packed tree node for the predictor: one 8-byte load per visit

@@ -3,8 +3,8 @@
 // Kernel inventory (LightGBM concept each one re-creates):
 //   k_count_codes    per-feature code frequencies of the training rows   (BinMapper::FindBin input)
 //   k_pack_bins      int32 codes -> u8 bin records, 16 features / 16 B    (Dataset construction)
-//   k_grad_*         scores -> quantised (g,h) per row and class          (ObjectiveFunction::GetGradients)
-//   k_hist           packed-u64 LDS histogram scan  *** the roofline kernel ***  (ConstructHistograms)
+//   k_grad_*         scores -> float32 (g,h) per row and class            (ObjectiveFunction::GetGradients)
+//   k_hist           LDS histogram scan of the leaf-wise grower             (ConstructHistograms)
 //   k_split_find     parent-minus-child subtraction + per-feature threshold scan (FindBestThreshold)
 //   k_tree_step      argmax over features/leaves, Tree::Split bookkeeping
 //   k_partition      unstable two-cursor row partition                    (DataPartition::Split)
@@ -23,10 +23,8 @@ namespace rg {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-// (g, h) of one (row, class tree): int2 [K][N], or -- TrainConst::g_only -- the gradient alone as int32 [K][N] in the same buffer
-__device__ __forceinline__ void store_gh(int2* gh, long long idx, int gq, int hq, int g_only) {
-    if (g_only) reinterpret_cast<int32_t*>(gh)[idx] = gq; else gh[idx] = make_int2(gq, hq);
-}
+// (g, h) of one (row, class tree): float2 [K][N] -- LightGBM's score_t pair, the double expression rounded once to float32
+__device__ __forceinline__ void store_gh(float2* gh, long long idx, double g, double h) { gh[idx] = make_float2((float)g, (float)h); }
 
 struct TreeOut {   // flat device arrays of every tree of the model, [(it*K+k)] major
     int32_t* L; int32_t* feat; int32_t* theta; int32_t* dleft; int32_t* left; int32_t* right; double* gain;
@@ -85,12 +83,6 @@ __global__ __launch_bounds__(256) void k_pack_bins(const int32_t* __restrict__ c
     }
 }
 
-// labels as bytes for the g-only level passes: 255 = not a training row
-__global__ __launch_bounds__(256) void k_ylab(const int32_t* __restrict__ ycol, long long N, uint8_t* __restrict__ ylab) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < N) { const int y = ycol[i]; ylab[i] = (y < 0 || y > 254) ? (uint8_t)255 : (uint8_t)y; }
-}
-
 __global__ void k_iota_train(const int32_t* __restrict__ ycol, long long N, int32_t* __restrict__ out, unsigned int* __restrict__ counter) {
     // unstable compaction of training rows (order is irrelevant: every sum downstream is an exact integer)
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,7 +108,7 @@ template <int OBJ>
 __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, const int32_t* __restrict__ ycol,
                                               const double* __restrict__ y_value, const double* __restrict__ class_w,
                                               const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
-                                              int2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
+                                              float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
                                               long long NS, TrainConst c) {
     const long long N = c.N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
@@ -129,23 +121,19 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
         if (y < 0) continue;   // not a training row: its gh stays 0 for ever
         if (row_in_bag && !row_in_bag[i]) {   // out of bag this round: contributes nothing to any histogram
             const int K = (OBJ == 1) ? c.K : 1;
-            for (int k = 0; k < K; ++k) store_gh(gh, (long long)k * N + i, 0, 0, c.g_only);
+            for (int k = 0; k < K; ++k) store_gh(gh, (long long)k * N + i, 0.0, 0.0);
             continue;
         }
         double wi = class_w ? class_w[y] : 1.0;
         if (sample_w) wi = wi * sample_w[i];
         wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
-        const double inv_wi = rg_inv_weight(wi); (void)inv_wi;
-        if (OBJ == 0) {
+        if (OBJ == 0) {   // binary_objective.hpp GetGradients (sigmoid = 1, label_weight = 1)
             double label = (y > 0) ? 1.0 : -1.0;
             double response = -label / (1.0 + rg_exp(label * score[i]));
             double abs_r = fabs(response);
-            (void)abs_r;
-            const int gq = quant_g(response * wi, c.sg);
-            store_gh(gh, i, gq, c.g_only ? 0 : h_from_g(gq, false, wi, rg_inv_weight(wi), 0, c.inv_sg, c.sh, c.factor), c.g_only);
-        } else if (OBJ == 2) {
-            double g = (score[i] - y_value[y]) * wi, h = wi;
-            store_gh(gh, i, quant_g(g, c.sg), quant_h(h, c.sh), c.g_only);
+            store_gh(gh, i, response * wi, abs_r * (1.0 - abs_r) * wi);
+        } else if (OBJ == 2) {   // RegressionL2loss::GetGradients
+            store_gh(gh, i, (score[i] - y_value[y]) * wi, wi);
         } else {
             const int K = c.K;
             double wmax = score[i];
@@ -154,8 +142,7 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
             for (int k = 0; k < K; ++k) wsum += rg_exp(score[(long long)k * N + i] - wmax);
             for (int k = 0; k < K; ++k) {
                 double pk = rg_exp(score[(long long)k * N + i] - wmax) / wsum;
-                const int gq = quant_g(((y == k) ? (pk - 1.0) : pk) * wi, c.sg);
-                store_gh(gh, (long long)k * N + i, gq, c.g_only ? 0 : h_from_g(gq, y == k, wi, inv_wi, 1, c.inv_sg, c.sh, c.factor), c.g_only);
+                store_gh(gh, (long long)k * N + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);   // MulticlassSoftmax::GetGradients
             }
         }
     }
@@ -167,22 +154,10 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
 // (order-independent), exp(s_k - max) overwrites the tile, ONE wave adds the K terms of every row in class order (the
 // summation order of the numerics spec), and every wave finishes its own classes.  Same arithmetic, in the same order,
 // as k_grad<1>; 4x the waves per LDS byte of a thread-per-row layout, which is what an FP64-bound kernel needs.
-// Lazy AddScore (level grower): the score update of the PREVIOUS tree is applied here, from the final node id of every
-// row (k_level_final<false> stored it) and the node -> delta table of the replay -- the scores are read and written once
-// per iteration instead of twice.  `pend` is null on the leaf-wise path.
-struct PendingTree {
-    const uint8_t* node_a; const uint8_t* node_b;   // final node ids of the previous iteration live in a or b (per class)
-    const int32_t* buf;                              // [K] which of the two, stride `buf_stride` ints (LvPlan::buf)
-    long long buf_stride;
-    const double* node_delta;                        // [K][256]
-    const int32_t* tree_L;                           // [NE][K] leaves of every tree
-    const int32_t* itp;                              // device-side iteration counter
-};
-
-__global__ __launch_bounds__(256) void k_grad_mc(double* __restrict__ score, const int32_t* __restrict__ ycol,
+__global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ score, const int32_t* __restrict__ ycol,
                                                  const double* __restrict__ class_w, const double* __restrict__ sample_w,
-                                                 const uint8_t* __restrict__ row_in_bag, int2* __restrict__ gh,
-                                                 uint8_t* __restrict__ node0, long long NS, PendingTree pend, TrainConst c) {
+                                                 const uint8_t* __restrict__ row_in_bag, float2* __restrict__ gh,
+                                                 uint8_t* __restrict__ node0, long long NS, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem);          // [K][64]
     double* pmax = tile + (size_t)c.K * 64;                  // [4][64]
@@ -194,29 +169,8 @@ __global__ __launch_bounds__(256) void k_grad_mc(double* __restrict__ score, con
     const long long ic = valid ? i : N - 1;
     double m = -INFINITY;
     const int y = ycol[ic];
-    const int it = pend.itp ? pend.itp[0] : 0;
-    if (it > 0) {
-        // pending AddScore of the previous tree: three unrolled sweeps so that the loads of a sweep are all in flight together
-        // (node ids -> LDS, then the delta gathers, then the scores)
-        uint8_t* ntile = reinterpret_cast<uint8_t*>(psum + 64);     // [K][64] node ids of this row block
-        const int32_t* Lp = pend.tree_L + (long long)(it - 1) * K;
 #pragma unroll 4
-        for (int k = wv; k < K; k += 4) {
-            const uint8_t* nd = (pend.buf[(long long)k * pend.buf_stride] ? pend.node_b : pend.node_a) + (long long)k * NS;
-            ntile[k * 64 + r] = (Lp[k] > 1) ? nd[ic] : (uint8_t)255;
-        }
-#pragma unroll 4
-        for (int k = wv; k < K; k += 4) {
-            const int n = ntile[k * 64 + r];
-            const double d = (n != 255) ? pend.node_delta[k * 256 + n] : 0.0;
-            const double v = score[(long long)k * N + ic] + d;
-            if (n != 255 && valid) score[(long long)k * N + i] = v;
-            tile[k * 64 + r] = v; if (v > m) m = v;
-        }
-    } else {
-#pragma unroll 4
-        for (int k = wv; k < K; k += 4) { const double v = score[(long long)k * N + ic]; tile[k * 64 + r] = v; if (v > m) m = v; }
-    }
+    for (int k = wv; k < K; k += 4) { const double v = score[(long long)k * N + ic]; tile[k * 64 + r] = v; if (v > m) m = v; }
     pmax[wv * 64 + r] = m;
     if (node0 && valid) {   // every training row restarts in node 0 (the root); all other rows never take part
         const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
@@ -231,16 +185,14 @@ __global__ __launch_bounds__(256) void k_grad_mc(double* __restrict__ score, con
     if (wv == 0) { double wsum = 0.0; for (int k = 0; k < K; ++k) wsum += tile[k * 64 + r]; psum[r] = wsum; }
     __syncthreads();
     if (!valid || y < 0) return;    // not a training row: its gh stays 0 for ever
-    if (out_of_bag) { for (int k = wv; k < K; k += 4) store_gh(gh, (long long)k * N + i, 0, 0, c.g_only); return; }
+    if (out_of_bag) { for (int k = wv; k < K; k += 4) store_gh(gh, (long long)k * N + i, 0.0, 0.0); return; }
     double wi = class_w ? class_w[y] : 1.0;
     if (sample_w) wi = wi * sample_w[i];
     wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
-        const double inv_wi = rg_inv_weight(wi); (void)inv_wi;
     const double wsum = psum[r];
     for (int k = wv; k < K; k += 4) {
         const double pk = tile[k * 64 + r] / wsum;
-        const int gq = quant_g(((y == k) ? (pk - 1.0) : pk) * wi, c.sg);
-        store_gh(gh, (long long)k * N + i, gq, c.g_only ? 0 : h_from_g(gq, y == k, wi, inv_wi, 1, c.inv_sg, c.sh, c.factor), c.g_only);
+        store_gh(gh, (long long)k * N + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
     }
 }
 
@@ -249,7 +201,7 @@ __global__ __launch_bounds__(256) void k_grad_mc(double* __restrict__ score, con
 template <int R>
 __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ score, const int32_t* __restrict__ ycol,
                                                     const double* __restrict__ class_w, const double* __restrict__ sample_w,
-                                                    const uint8_t* __restrict__ row_in_bag, int2* __restrict__ gh,
+                                                    const uint8_t* __restrict__ row_in_bag, float2* __restrict__ gh,
                                                     uint8_t* __restrict__ node0, long long NS, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem) + threadIdx.x;   // element k at tile[k * R]
@@ -267,34 +219,28 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ s
         for (int kk = 0; kk < K; ++kk) node0[(long long)kk * NS + i] = v;
     }
     if (y < 0) return;
-    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) store_gh(gh, (long long)kk * N + i, 0, 0, c.g_only); return; }
+    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) store_gh(gh, (long long)kk * N + i, 0.0, 0.0); return; }
     double wi = class_w ? class_w[y] : 1.0;
     if (sample_w) wi = wi * sample_w[i];
     wi = (double)(float)wi;
-    const double inv_wi = rg_inv_weight(wi);
     double wsum = 0.0;
     for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
     for (int kk = 0; kk < K; ++kk) {
         const double pk = tile[kk * R] / wsum;
-        const int gq = quant_g(((y == kk) ? (pk - 1.0) : pk) * wi, c.sg);
-        store_gh(gh, (long long)kk * N + i, gq, c.g_only ? 0 : h_from_g(gq, y == kk, wi, inv_wi, 1, c.inv_sg, c.sh, c.factor), c.g_only);
+        store_gh(gh, (long long)kk * N + i, ((y == kk) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: hist_build -- THE roofline kernel.
-//   grid (gx, K, nchunk), block 256.  Each lane owns one row per step: one dwordx4 load brings its
-//   16 bin codes, one dwordx2 load its (g,h); (g<<32 | h) is ONE 64-bit LDS atomic per feature
-//   into a per-workgroup packed histogram.  Low-cardinality features are replicated `rep` times
-//   (slot = bin*rep + lane%rep) so that lanes hitting the same bin do not serialise on one LDS
-//   address.  Every TILE_ROWS rows the packed 32+32-bit slots are drained into a 64+64-bit LDS
-//   histogram (no overflow: 2048*(2^20-1) < 2^31, 2048*(2^21-1) < 2^32), which is flushed to the
-//   leaf's global histogram with 64-bit atomics once per workgroup.  All sums are integers, so
-//   the result is independent of scheduling.
-//   Algorithmic bytes per scanned row: 16 B/chunk of bins (F useful) + 8 B (g,h) (+4 B row index
-//   off the root).
+// K3: hist_build of the LEAF-WISE grower (the fallback path; the level grower's passes are in rgbm_level.h).
+//   grid (gx, K, nchunk), block 256.  Each lane owns one row per step: one dwordx4 load brings its 16 bin codes, one dwordx2
+//   load its float32 (g,h), which go onto the model's fixed-point grid (fx_from_f32) and into the per-workgroup LDS histogram
+//   with two 64-bit atomics per feature.  Low-cardinality features are replicated `rep` times (slot = bin*rep + lane%rep) so
+//   that lanes hitting the same bin do not serialise on one LDS address.  The workgroup's histogram is flushed to the leaf's
+//   global histogram with 64-bit atomics once.  All sums are integers, so the result is independent of scheduling.
+//   Algorithmic bytes per scanned row: 16 B/chunk of bins (F useful) + 8 B (g,h) (+4 B row index off the root).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, const int2* __restrict__ gh,
+__global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, const float2* __restrict__ gh,
                                               const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1,
                                               const int32_t* __restrict__ base_idx, const TreeState* __restrict__ state,
                                               HistBin* __restrict__ pool, const FeatMeta* __restrict__ fmeta,
@@ -304,11 +250,9 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
     const TreeState st = state[k];
     if (!st.do_hist) return;
     const ChunkMeta cm = cmeta[ch];
-    unsigned long long* fast = reinterpret_cast<unsigned long long*>(smem);
-    HistBin* wide = reinterpret_cast<HistBin*>(smem + (size_t)cm.fast_slots * 8);
+    HistBin* fast = reinterpret_cast<HistBin*>(smem);          // [fast_slots] replicated (g, h) sums
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < cm.fast_slots; i += 256) fast[i] = 0ull;
-    for (int i = tid; i < cm.wide_bins; i += 256) { wide[i].g = 0; wide[i].h = 0; }
+    for (int i = tid; i < cm.fast_slots; i += 256) { fast[i].g = 0; fast[i].h = 0; }
     __syncthreads();
 
     // per-feature slot bases / replication shifts of this chunk (uniform -> scalar registers)
@@ -322,7 +266,7 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
     const long long cnt = st.hist_is_root ? N : (long long)st.hist_count;
     const int32_t* idx = st.hist_buf == 0 ? idx0 + (long long)k * c.n_train : (st.hist_buf == 1 ? idx1 + (long long)k * c.n_train : base_idx);
     const uint4* recc = rec + (long long)ch * N;
-    const int2* ghk = gh + (long long)k * N;
+    const float2* ghk = gh + (long long)k * N;
     const long long ntiles = (cnt + TILE_ROWS - 1) / TILE_ROWS;
 
     for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -333,49 +277,36 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
             if (p < cnt) {
                 long long row = st.hist_is_root ? p : (long long)idx[st.hist_begin + p];
                 uint4 r = recc[row];
-                int2 g = ghk[row];
-                unsigned long long packed = ((unsigned long long)(long long)g.x << 32) + (unsigned long long)(unsigned int)g.y;
-                if (packed != 0ull) {
+                const float2 g = ghk[row];
+                if (g.x != 0.0f || g.y != 0.0f) {   // non-training / out-of-bag rows carry (0, 0)
+                    const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, c.sg), hq = (unsigned long long)fx_from_f32(g.y, c.sh);
                     uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         if (j < cm.nfeat) {
                             uint32_t bin = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                             int slot = fbase[j] + (int)(bin << fshift[j]) + (lane & ((1 << fshift[j]) - 1));
-                            atomicAdd(&fast[slot], packed);
+                            atomicAdd(reinterpret_cast<unsigned long long*>(&fast[slot].g), gq);
+                            atomicAdd(reinterpret_cast<unsigned long long*>(&fast[slot].h), hq);
                         }
                     }
                 }
             }
         }
-        __syncthreads();
-        // drain packed -> wide
-        for (int j = 0; j < cm.nfeat; ++j) {
-            const int nslots = fm[j].nbins << fm[j].rep_shift;
-            for (int s2 = tid; s2 < nslots; s2 += 256) {
-                unsigned long long v = fast[fm[j].fast_base + s2];
-                if (v) {
-                    fast[fm[j].fast_base + s2] = 0ull;
-                    int bin = s2 >> fm[j].rep_shift;
-                    long long gq = (long long)(int)(v >> 32);
-                    long long hq = (long long)(unsigned int)(v & 0xFFFFFFFFull);
-                    HistBin* wb = &wide[fm[j].wide_off + bin];
-                    atomicAdd(reinterpret_cast<unsigned long long*>(&wb->g), (unsigned long long)gq);
-                    atomicAdd(reinterpret_cast<unsigned long long*>(&wb->h), (unsigned long long)hq);
-                }
-            }
-        }
-        __syncthreads();
     }
+    __syncthreads();
     // flush to the leaf histogram being built (always the slot of the newest leaf; root: slot 0)
     const int slot_leaf = st.hist_is_root ? 0 : st.right_leaf;
     HistBin* dst = pool + ((long long)k * c.num_leaves + slot_leaf) * c.totbins;
     for (int j = 0; j < cm.nfeat; ++j) {
+        const int sh = fm[j].rep_shift;
         for (int b = tid; b < fm[j].nbins; b += 256) {
-            HistBin v = wide[fm[j].wide_off + b];
+            long long tg = 0, th = 0;
+            const HistBin* src = fast + fm[j].fast_base + (b << sh);
+            for (int r2 = 0; r2 < (1 << sh); ++r2) { tg += src[r2].g; th += src[r2].h; }
             HistBin* d = &dst[fm[j].hoff + b];
-            if (v.g) atomicAdd(reinterpret_cast<unsigned long long*>(&d->g), (unsigned long long)v.g);
-            if (v.h) atomicAdd(reinterpret_cast<unsigned long long*>(&d->h), (unsigned long long)v.h);
+            if (tg) atomicAdd(reinterpret_cast<unsigned long long*>(&d->g), (unsigned long long)tg);
+            if (th) atomicAdd(reinterpret_cast<unsigned long long*>(&d->h), (unsigned long long)th);
         }
     }
 }

@@ -6,11 +6,12 @@
 // k_partition 50 %, k_hist 24 % of the time, profiles/r01a_*).  This grower produces the SAME tree,
 // bit for bit, from at most max_depth+1 fully coalesced streaming passes over the row block:
 //
-//   * every row carries the id of the speculative node it sits in (u8 [K][N], ping-pong);
+//   * every row carries the id of the speculative node it sits in (u8 [K][N], updated in place);
 //   * pass L routes every row from its depth-(L-1) node to the depth-L child (one byte compare on
-//     the record that is loaded anyway), counts rows per child exactly, and accumulates the
-//     histogram of ONE child per expanded parent (the other is parent - child: sums are exact
-//     integers, so which child is built never changes a bit of the result);
+//     a record that sits in registers), and accumulates the histogram of ONE child per expanded
+//     parent (the other is parent - child: sums are exact integers, so which child is built never
+//     changes a bit of the result); rows of the built child are counted, the sibling's count is
+//     parent - built;
 //   * k_level_split scans both children of every expanded parent (same FindBestThreshold code as
 //     the leaf-wise path);
 //   * k_level_plan decides which nodes of the new level to expand.  A node is expanded unless it
@@ -24,11 +25,9 @@
 // Used when 1 <= max_depth <= 7 and F <= 255 (the reference fixes max_depth = 7, train.py:109);
 // every other configuration takes the leaf-wise path of rgbm_kernels.h.
 //
-// LDS per workgroup (1024 threads, one workgroup per CU): route table | child counters |
-// packed 32+32-bit histogram slots [built node][feature][bin][replica] | 32-bit carry words per
-// bin.  Packed slots are drained lazily: every lane budgets the |g| and h it has added since the
-// last drain so that no field can exceed 2047 + sum of the 1024 lane budgets < 2^31 (2^32 for h);
-// a drain moves the bits >= 2^11 to the carry words (see k_level_pass).
+// Numerics v2 (rgbm_numerics.h): (g, h) are LightGBM's float32 values; a histogram slot is a pair of
+// int64 sums on the model's fixed-point grid, updated with two 64-bit LDS atomics.  No packing, no
+// carries, no drains: a slot cannot overflow (|value| <= 2^E, E <= 62 - log2 rows).
 #pragma once
 #include "rgbm_kernels.h"
 
@@ -38,33 +37,21 @@ constexpr int LV_INACTIVE = 255;     // node id of rows that do not take part (t
 constexpr int LV_MAX_EXP = 64;       // expanded parents per level (depth <= 6)
 constexpr int LV_MAX_BUILT = 32;     // built children per level (parents of depth <= 5)
 constexpr int LV_CNT_REP = 16;
-#ifndef LV_THREADS_N
-#define LV_THREADS_N 1024    // threads of a level-pass workgroup
-#endif
-#ifndef LV_BLOCKS_PER_CU
-#define LV_BLOCKS_PER_CU 1   // resident level-pass workgroups per CU; they share the 160 KB of LDS
-#endif
-constexpr int LV_THREADS = LV_THREADS_N;
-constexpr int LV_TILE = 2 * LV_THREADS;      // two rows per lane and tile
+constexpr int LV_THREADS = 1024;     // threads of a pass workgroup: one workgroup per CU, it owns the CU's LDS
+constexpr int LV_TILE = 2 * LV_THREADS;      // root pass: two rows per lane and tile
 constexpr int LV_LDS_TOTAL = 160 * 1024;
-constexpr int LV_LDS_BYTES = (LV_LDS_TOTAL / LV_BLOCKS_PER_CU) & ~1023;
-constexpr int LV_CARRY_SHIFT = 11;
+constexpr int LV_LDS_BYTES = LV_LDS_TOTAL;
 constexpr int LV_MAX_DEPTH = 7;
 constexpr int LV_MAX_LEAVES = 128;
-// split mode (k_level_route + k_level_pass<STREAM>)
-constexpr int LV_SRING = 192;                           // entries of a wave's built-row ring (k_level_pass<STREAM>): <= 64 pending + 128 appended per tile
-constexpr int LV_SRING_BYTES = (LV_THREADS / 64) * LV_SRING * 12;   // entry = g, h, row (4 B each)
-constexpr int RT_KS = 32;                               // class trees per route workgroup (LDS route tables: 512 B each)
-constexpr int RT_THREADS = 256;
-constexpr int RT_WT_ROWS = 256;                         // rows of one wave tile: 4 consecutive rows per lane
-#ifndef LV_RING
-#define LV_RING 0       // 1: level passes compact the rows that feed a histogram into full waves (per-wave LDS ring).
-                        // Measured on MI355X (K=64, 10M rows): halves the LDS atomic instructions but the pass time is unchanged
-                        // (2.9 ms either way: VALU issue + s_waitcnt bound, not LDS bound), so the simpler path is the default.
-#endif
-constexpr int LV_LIST = 256;                                   // ring entries per wave
-constexpr int LV_LIST_BYTES = LV_RING ? (LV_THREADS / 64) * LV_LIST * 4 : 0;
-static_assert(!LV_RING || LV_TILE <= 2048, "ring entries hold an 11-bit row offset");
+
+// multi-tree level pass (k_level_mt)
+constexpr int MT_MAX_T = 64;                 // class trees per workgroup
+constexpr int MT_MAX_NODES = 128;            // built nodes per workgroup (all its class trees together)
+constexpr int MT_MAX_RT = 256;               // route / child-lookup entries per workgroup (<= 2^L per class tree)
+constexpr int MT_WT_ROWS = 256;              // rows of one wave tile: 4 consecutive rows per lane
+constexpr int MT_RING = 128;                 // entries of a wave's built-row ring: <= 63 waiting + <= 64 appended per row step
+constexpr int MT_CNT_REP = 8;
+constexpr int MT_WAVES = LV_THREADS / 64;
 
 struct SNode {   // speculative node of one class tree
     long long Gq, Hq;
@@ -77,7 +64,7 @@ struct SNode {   // speculative node of one class tree
 };
 
 struct LvPlan {   // per class tree; rewritten by k_level_init / k_level_plan
-    int32_t n_nodes, lvl_first, lvl_end, n_exp, n_built, n_groups, npg, buf, buf_in, done, error, child_first, n_hslots, pad;
+    int32_t n_nodes, lvl_first, lvl_end, n_exp, n_built, pad0, pad1, pad2, pad3, done, error, child_first, n_hslots, pad4;
     long long n_in;
     uint8_t exp[LV_MAX_EXP];           // expanded parents (ascending node id)
     uint8_t built_is_left[LV_MAX_EXP];
@@ -85,20 +72,16 @@ struct LvPlan {   // per class tree; rewritten by k_level_init / k_level_plan
     uint32_t route1[256];              // left | right<<8 | left built slot<<16 | right built slot<<24  (0xFF = none)
 };
 
-struct LvLayout {   // per (class tree, chunk): packed-slot layout of the coming pass
-    int32_t spn;                       // packed slots per built node
-    int32_t sh[16], fbase[16];
-};
-
 struct LevelConst {
-    int32_t gx, max_built, nchunk, K, F, totbins, num_leaves, max_depth, min_data_in_leaf, lds_bytes;
-    int32_t drain_shift, pad0;   // testing: the per-lane drain budgets are shifted right by this much (0 in production), which forces drains on small inputs
-    int32_t split_mode;          // 1: route + stream-accumulate kernels (k_level_route / k_level_pass<STREAM>); sibling counts are parent - built
-    int32_t sib_local;           // split mode: k_level_split also writes the derived sibling count into the LOCAL count array (row-sharded: rank 0 only)
-    long long N, NS;   // rows; row stride of the node-id arrays (multiple of 16)
-    // GONLY passes (split mode): the gradient buffer holds int32 g only; h = h_from_g(g, label, weight) for the rows that are accumulated
-    double inv_sg, sh, factor;
-    int32_t objective, n_labels;
+    int32_t gx;                  // row blocks per class tree of THIS launch (partials: [K][gx][max_built][totbins])
+    int32_t max_built;           // built-node stride of the partials of THIS launch
+    int32_t nchunk, K, F, totbins, num_leaves, max_depth, min_data_in_leaf, lds_bytes;
+    int32_t sib_local;           // k_level_split also writes the derived sibling count into the LOCAL count array (row-sharded: rank 0 only)
+    int32_t xcd_blocks;          // root pass: 1-D grid of K * gx blocks, contiguous row blocks, all class trees of a row block on one XCD
+    // k_level_mt launch: class trees per workgroup, tree groups, chunk whose features are accumulated, built-slot window, routing?
+    int32_t mt_T, mt_G, mt_ch, mt_slot0, mt_nslots, mt_route;
+    long long N, NS;             // rows; row stride of the node-id arrays (multiple of 16)
+    double sg, sh;               // 2^e_g, 2^e_h: float32 (g, h) -> fixed point (fx_from_f32)
 };
 
 __device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
@@ -107,7 +90,9 @@ __device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// packed-slot layout for `ng` built nodes of one chunk inside `avail` bytes of LDS
+// LDS histogram layout of a chunk: a slot is a HistBin (16 B); feature j holds nbins << sh_j slots (bin-major, replica-minor) so
+// that lanes hitting the same bin spread over 2^sh_j addresses.  One uniform cap s for all features, limited per feature so that
+// nbins << sh <= 2048.
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline int lv_cap_shift(int nbins) { int s = 0; while (s < 5 && (nbins << (s + 1)) <= 2048) ++s; return s; }
 
@@ -117,53 +102,27 @@ __host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int s) {
     return t;
 }
 
-// bytes one built node needs in chunk `cm` at replication cap s (packed slots + carry words + slot->bin map share)
-__host__ __device__ inline long long lv_node_bytes(const FeatMeta* fm, const ChunkMeta& cm, int s) {
-    return (long long)lv_slots(fm, cm.nfeat, s) * 8 + (long long)cm.wide_bins * 8;
-}
-
-// everything that depends on the replication cap s for `nodes` built nodes: packed slots + carry words per node, plus the slot->wide map
-__host__ __device__ inline long long lv_layout_bytes(const FeatMeta* fm, const ChunkMeta& cm, int s, long long nodes) {
-    return nodes * lv_node_bytes(fm, cm, s) + (long long)lv_slots(fm, cm.nfeat, s) * 2;
-}
-
-__host__ __device__ inline long long lv_fixed_bytes(const ChunkMeta& cm, int n_exp, const FeatMeta* fm) {
-    // route tables + child counters + (wide->slot, wide->hoff) tables + alignment slack (the slot->wide map is charged to the layout: lv_layout_bytes)
-    (void)fm;
-    return 2048 + 16 + LV_LIST_BYTES + LV_SRING_BYTES + 256 + (long long)2 * n_exp * LV_CNT_REP * 4 + (long long)cm.wide_bins * 8 + 64;
-}
-
-// Packed-slot layout of one chunk for `nodes` built nodes inside `avail` bytes: the largest uniform replication 2^s (s <= 5,
-// at most 2048 slots per feature) that fits.  (A greedy variant that replicates the feature with the fewest slots first was
-// measured 10 % slower: the synthetic columns are correlated, so high-cardinality features collide as well, and the drain
-// budget of k_level_pass scales with the SMALLEST replication factor.)  Computed on the host, once per group size.
-__host__ __device__ inline void lv_choose_layout(const FeatMeta* fm, const ChunkMeta& cm, long long nodes, long long avail, LvLayout& L) {
-    int s = 5;
-    while (s > 0 && lv_layout_bytes(fm, cm, s, nodes) > avail) --s;
-    int off = 0;
-    for (int j = 0; j < 16; ++j) {
-        if (j < cm.nfeat) { const int cs = lv_cap_shift(fm[j].nbins); L.sh[j] = s < cs ? s : cs; L.fbase[j] = off; off += fm[j].nbins << L.sh[j]; }
-        else { L.sh[j] = 0; L.fbase[j] = 0; }
-    }
-    L.spn = off;
+// bytes the root pass needs besides the histogram: nothing but alignment slack
+constexpr int LV_ROOT_FIXED = 256;
+// bytes k_level_mt needs besides the histogram: tree table | node -> tree map | route entries | built-row counters | per-wave rings
+// (record 16 B + (g, h) 8 B + slot 2 B per entry) | wide-bin tables (8 B per bin of the chunk) | slack
+__host__ __device__ inline long long mt_fixed_bytes(int wide_bins) {
+    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
+           (long long)MT_WAVES * MT_RING * (16 + 8 + 2) + (long long)wide_bins * 8 + 512;
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_level_init: per class tree, start of a boosting iteration
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, const LvLayout* __restrict__ lay_table /* [nchunk][LV_MAX_BUILT+1] */,
-                                                   SNode* __restrict__ nodes, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
+__global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, SNode* __restrict__ nodes,
                                                    const unsigned int* __restrict__ n_in_ptr, long long n_train, LevelConst c) {
     const int k = blockIdx.x, lane = lane_id();
     LvPlan* pp = &plan[k];
     const long long n_in = n_in_ptr ? (long long)n_in_ptr[0] : n_train;
     for (int i = lane; i < 256; i += 64) { pp->route0[i] = 0; pp->route1[i] = 0xFFFFFFFFu; }
-    if (lane < c.nchunk) {
-        layout[(long long)k * c.nchunk + lane] = lay_table[lane * (LV_MAX_BUILT + 1) + 1];   // one built node (the root)
-    }
     if (lane == 0) {
-        pp->n_nodes = 1; pp->lvl_first = 0; pp->lvl_end = 1; pp->n_exp = 0; pp->n_built = 1; pp->n_groups = 1; pp->npg = 1;
-        pp->buf = 0; pp->buf_in = 0; pp->error = 0; pp->child_first = 1; pp->n_hslots = 1; pp->n_in = n_in;
+        pp->n_nodes = 1; pp->lvl_first = 0; pp->lvl_end = 1; pp->n_exp = 0; pp->n_built = 1;
+        pp->error = 0; pp->child_first = 1; pp->n_hslots = 1; pp->n_in = n_in;
         pp->done = (n_in < (long long)c.min_data_in_leaf * 2) ? 1 : 0;   // BeforeFindBestSplit on the root
         SNode r; memset(&r, 0, sizeof(r));
         r.count = (int)n_in; r.depth = 0; r.parent = -1; r.left = -1; r.right = -1; r.best_feature = -1; r.searched = 0; r.hslot = 0;
@@ -173,574 +132,402 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, Lv
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_level_pass: THE roofline kernel of this grower.  grid (gx, K, nchunk * groups), block 1024.
-//   ROOT: every active row sits in node 0, whose histogram is built (no routing, no counting).
-//   else: route + count (chunk 0 / group 0 blocks write the new node ids) + histogram of the
-//         built children that belong to this block's group.
-// Algorithmic bytes per accumulated row: F bin bytes + 8 B (g,h); the pass also streams the node
-// ids (1 B in, 1 B out) and the records of rows it only routes.
+// k_level_root: ConstructHistograms of the root.  Every training row of class tree k sits in node 0: one coalesced pass over the
+// (joint) bin record and the float32 (g, h) of every row, two 64-bit LDS atomics per feature (group).  One 1024-thread workgroup
+// per CU owns the CU's LDS; the next tile is in flight while this tile's atomics run.
+//   grid: xcd_blocks ? K * gx (1-D; id -> xcd = id % 8, r = id / 8, class tree = r % K, row block = (r / K) * 8 + xcd: all class trees
+//         of a row block on ONE XCD, which then shares its L2 copy of the block's records) : (gx, K), strided tiles;  grid.z = chunk.
+// Algorithmic bytes per row: F bin bytes + 8 B (g, h).
 // ------------------------------------------------------------------------------------------------
-//   STREAM (split mode): no routing -- k_level_route has already moved every row to its child.  The pass streams the node
-//         ids (1 B) and (g,h) (8 B) of every row, fully coalesced, and looks the node id up in an LDS table: rows that sit
-//         in a BUILT child are appended to the wave's LDS ring (g, h, row); whenever 64 of them are waiting, their records
-//         are re-read (L2: the 64 class trees walk the rows in lock step) and the packed atomics run on a FULL wave.  A wave
-//         instruction of LDS atomics costs the same for 6 active lanes as for 64 (profiles/r01_lds_atomic_active_lanes.txt),
-//         and a built child holds ~12 % of the rows: the fused pass pays that instruction for every 64-row step, this one
-//         for every 64 built rows.  Rows per built child are counted here; the sibling is parent - built (k_level_split).
-//   GONLY: the (g,h) buffer holds the quantised gradient alone (int32 [K][N], TrainConst::g_only): the pass streams 4 B instead of 8 per
-//         (row, class tree) and derives h from g, the row's label (u8 `ylab`) and the label's weight (`cw32`, float32-rounded; LDS copy)
-//         for the rows it accumulates -- numerics v1.02 defines h that way for every path, so the histograms are the same integers.
-template <bool ROOT, bool BAG, int MULTI /* 0: one 16-feature chunk; 2: exactly two (the other chunk's record is prefetched too); 3: more */, bool STREAM = false, bool GONLY = false>
-__global__ __launch_bounds__(LV_THREADS, LV_BLOCKS_PER_CU) void k_level_pass(const uint4* __restrict__ rec, const int2* __restrict__ gh,
-                                                           uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
-                                                           const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan,
-                                                           const LvLayout* __restrict__ layout, HistBin* __restrict__ part,
-                                                           int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta,
-                                                           const ChunkMeta* __restrict__ cmeta, int with_hist, LevelConst c,
-                                                           const uint8_t* __restrict__ ylab = nullptr, const double* __restrict__ cw32 = nullptr) {
-    static_assert(!GONLY || ROOT || STREAM, "g-only buffers exist in split mode only");
+__global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __restrict__ rec, const float2* __restrict__ gh, const uint8_t* __restrict__ node,
+                                                              const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
+                                                              const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta, LevelConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // Block -> (class tree, row block).  Fused mode: grid (gx, K): block x walks the tiles x, x + gx, ... of class tree blockIdx.y.
-    // Split mode: 1-D grid of K * gx blocks (gx a multiple of 8), every block owns a CONTIGUOUS run of tiles, and the decode makes
-    // the launch order walk the table front to back with ALL class trees of a row block on ONE XCD (blocks land on XCD id % 8):
-    //     id -> xl = id % 8,  r = id / 8,  class tree = r % K,  row block = (r / K) * 8 + xl
-    // The class trees re-read the bin records of the rows they accumulate; spread over the chip and drifting apart over a whole
-    // pass they missed L2 half of the time (2-4 GB of a level pass's 8-10 GB).  Now the ~32 workgroups that are resident on an XCD
-    // share one 4 MB slice of records, start together and finish within ~0.2 ms.
     int k, bx, nbx;
-    if (c.split_mode) {
-        const unsigned id = blockIdx.x, r = id >> 3;
-        k = (int)(r % (unsigned)c.K); bx = (int)(r / (unsigned)c.K) * 8 + (int)(id & 7u); nbx = c.gx;
-    } else { k = blockIdx.y; bx = blockIdx.x; nbx = gridDim.x; }
-    const int ch = blockIdx.z % c.nchunk, grp = blockIdx.z / c.nchunk;
-    const LvPlan* pp = &plan[k];
-    if (pp->done) return;
-    const int n_exp = (ROOT || STREAM) ? 0 : pp->n_exp;
-    const int n_built = with_hist ? pp->n_built : 0;
-    const int npg = pp->npg;
-    const bool writer = !ROOT && !STREAM && ch == 0 && grp == 0;
-    const int g0 = grp * npg;
-    int ng = n_built - g0; if (ng > npg) ng = npg; if (ng < 0) ng = 0;
-    if (grp >= pp->n_groups && !writer) return;
-    if (ng == 0 && !writer) return;
-
+    if (c.xcd_blocks) { const unsigned id = blockIdx.x, r = id >> 3; k = (int)(r % (unsigned)c.K); bx = (int)(r / (unsigned)c.K) * 8 + (int)(id & 7u); nbx = c.gx; }
+    else { k = blockIdx.y; bx = blockIdx.x; nbx = gridDim.x; }
+    const int ch = blockIdx.z;
+    if (plan[k].done) return;
     const ChunkMeta cm = cmeta[ch];
     const FeatMeta* fm = fmeta + cm.first_feat;
-    const LvLayout lay = layout[(long long)k * c.nchunk + ch];
-    const int spn = lay.spn, wb = cm.wide_bins;
-    const int tid = threadIdx.x, lane = tid & 63;
-
-    // ---- LDS carve-up
-    uint2* route = reinterpret_cast<uint2*>(smem);                                      // [256] (w0, w1) of LvPlan::route0/1
-    int32_t* drain_flag = reinterpret_cast<int32_t*>(route + 256);                      // [4] (16 B), relaxed atomic accesses
-    uint32_t* lst = reinterpret_cast<uint32_t*>(route + 256) + 4 + (tid >> 6) * LV_LIST;   // this wave's ring (LV_RING)
-    uint32_t* sring = reinterpret_cast<uint32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4 + (tid >> 6) * (LV_SRING * 3);   // STREAM: [3][LV_SRING] g | h | row
-    uint8_t* bslot = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4 + LV_SRING_BYTES / 4);   // STREAM: node id -> group-local built slot
-    int32_t* cnt = reinterpret_cast<int32_t*>(route + 256) + 4 + LV_LIST_BYTES / 4 + LV_SRING_BYTES / 4 + 64;
-    const int ncnt = STREAM ? ng * LV_CNT_REP : 2 * n_exp * LV_CNT_REP;   // STREAM: rows per built child of this group
-    int32_t* wide_g = cnt + ncnt;
-    uint32_t* wide_h = reinterpret_cast<uint32_t*>(wide_g + (size_t)ng * wb);
-    uint32_t* w_slot = wide_h + (size_t)ng * wb;          // [wb] first packed slot of the bin | sh << 24
-    uint32_t* w_hoff = w_slot + wb;                       // [wb] offset of the bin inside a node histogram
-    uint16_t* s2w = reinterpret_cast<uint16_t*>(w_hoff + wb);   // [spn] packed slot -> carry-word index
-    size_t off = reinterpret_cast<unsigned char*>(s2w + spn) - smem;
-    off = (off + 15) & ~(size_t)15;
-    unsigned long long* fast = reinterpret_cast<unsigned long long*>(smem + off);
-
-    if (!ROOT && !STREAM) for (int i = tid; i < 256; i += LV_THREADS) {
-        // LDS copy of the route table, specialised for this block: built slots become group-local (0xFF = the child's
-        // histogram is not this block's business) and an unexpanded node routes to itself, so the row loop needs no selects
-        const uint32_t w0 = pp->route0[i]; uint32_t w1 = pp->route1[i];
-        if (w0 & (1u << 24)) {
-            const int ls = (int)((w1 >> 16) & 0xFFu), rs = (int)(w1 >> 24);
-            const uint32_t l2 = (ls != 0xFF && ls >= g0 && ls - g0 < ng) ? (uint32_t)(ls - g0) : 0xFFu;
-            const uint32_t r2 = (rs != 0xFF && rs >= g0 && rs - g0 < ng) ? (uint32_t)(rs - g0) : 0xFFu;
-            w1 = (w1 & 0xFFFFu) | l2 << 16 | r2 << 24;
-        } else w1 = (uint32_t)i | (uint32_t)i << 8 | 0xFFFF0000u;
-        route[i] = make_uint2(w0, w1);
-    }
-    if (tid < 4) drain_flag[tid] = 0;
-    double2* wtab = reinterpret_cast<double2*>(route);     // GONLY: (weight, 1 / weight) of every label (<= 128; the route table's 2 KB are free in ROOT / STREAM passes)
-    if (GONLY) for (int i = tid; i < 128; i += LV_THREADS) { const double w = (cw32 && i < c.n_labels) ? cw32[i] : 1.0; wtab[i] = make_double2(w, rg_inv_weight(w)); }
-    if (STREAM) {   // k_level_plan numbers the children of expanded parent ei as child_first + 2 ei (left), + 1 (right); one of them is built
-        for (int i = tid; i < 256; i += LV_THREADS) {
-            const int d = i - pp->child_first;
-            uint8_t v = 0xFF;
-            if (d >= 0 && d < 2 * n_built) {
-                const int ei = d >> 1;
-                if ((pp->built_is_left[ei] ? 0 : 1) == (d & 1) && ei >= g0 && ei - g0 < ng) v = (uint8_t)(ei - g0);
-            }
-            bslot[i] = v;
-        }
-    }
-#define LV_FLAG_LOAD() __hip_atomic_load(drain_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define LV_FLAG_STORE(v) __hip_atomic_store(drain_flag, (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-    for (int i = tid; i < ncnt; i += LV_THREADS) cnt[i] = 0;
-    for (int i = tid; i < ng * wb; i += LV_THREADS) { wide_g[i] = 0; wide_h[i] = 0u; }
-    for (int i = tid; i < ng * spn; i += LV_THREADS) fast[i] = 0ull;
-    for (int j = 0; j < cm.nfeat; ++j) {
-        const int nb = fm[j].nbins, sh = lay.sh[j], fb = lay.fbase[j], wo = fm[j].wide_off;
-        for (int b = tid; b < nb; b += LV_THREADS) { w_slot[wo + b] = (uint32_t)(fb + (b << sh)) | ((uint32_t)sh << 24); w_hoff[wo + b] = (uint32_t)(fm[j].hoff + b); }
-        for (int s = tid; s < (nb << sh); s += LV_THREADS) s2w[fb + s] = (uint16_t)((wo + (s >> sh)) | (sh > 0 ? 0x8000 : 0));
-    }
-    // per-feature lane constants: byte offset of this lane's replica of bin 0 (relative to the node's slots), and
-    // the shift that turns a bin into a byte offset
-    int cj[16], fsh3[16];
+    const int tid = threadIdx.x, lane = tid & 63, nfeat = cm.nfeat;
+    // layout: the largest uniform replication that fits
+    int s = 5;
+    while (s > 0 && (long long)lv_slots(fm, nfeat, s) * 16 + LV_ROOT_FIXED > c.lds_bytes) --s;
+    int sh[16], fbase[16], spn = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { fsh3[j] = lay.sh[j] + 3; cj[j] = (lay.fbase[j] + (lane & ((1 << lay.sh[j]) - 1))) * 8; }
-    const int nfeat = cm.nfeat;
+    for (int j = 0; j < 16; ++j) {
+        if (j < nfeat) { const int cs = lv_cap_shift(fm[j].nbins); sh[j] = s < cs ? s : cs; fbase[j] = spn; spn += fm[j].nbins << sh[j]; }
+        else { sh[j] = 0; fbase[j] = 0; }
+    }
+    HistBin* hist = reinterpret_cast<HistBin*>(smem);
+    for (int i = tid; i < spn; i += LV_THREADS) { hist[i].g = 0; hist[i].h = 0; }
+    int cj[16], sh4[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { sh4[j] = sh[j] + 4; cj[j] = (fbase[j] + (lane & ((1 << sh[j]) - 1))) * 16; }
     __syncthreads();
 
     const long long N = c.N;
-    const uint8_t* node_in = (pp->buf_in ? node_b : node_a) + (long long)k * c.NS;
-    uint8_t* node_out = (pp->buf ? node_b : node_a) + (long long)k * c.NS;
-    if (ROOT) node_in = (pp->buf ? node_b : node_a) + (long long)k * c.NS;
+    const uint8_t* node_in = node + (long long)k * c.NS;
     const uint4* recc = rec + (long long)ch * N;
-    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
-    const int2* ghk = gh + (long long)k * N;
-    const int child_first = pp->child_first;
+    const float2* ghk = gh + (long long)k * N;
     const long long ntiles_all = (N + LV_TILE - 1) / LV_TILE;
-    // this block's tiles: t = tbeg, tbeg + tstep, ... < ntiles
-    const long long tbeg = c.split_mode ? ntiles_all * bx / nbx : bx;
-    const long long ntiles = c.split_mode ? ntiles_all * (bx + 1) / nbx : ntiles_all;
-    const long long tstep = c.split_mode ? 1 : nbx;
+    const long long tbeg = c.xcd_blocks ? ntiles_all * bx / nbx : bx;
+    const long long ntiles = c.xcd_blocks ? ntiles_all * (bx + 1) / nbx : ntiles_all;
+    const long long tstep = c.xcd_blocks ? 1 : nbx;
 
-    // Packed-slot overflow control without per-tile barriers.  Every lane keeps the sums of |g| and h it has
-    // added since the last drain; a field of any slot is at most 2047 (drain remainder) + the sum over all 1024
-    // lanes, so it cannot overflow while every lane stays within LB_G / LB_H.  A lane that would exceed its
-    // budget raises the drain flag; waves poll the flag once per row step and rendezvous at a barrier, drain
-    // cooperatively and continue.  Drains are rare for small gradients (multiclass), at worst every 2 rows/lane.
-    // A slot of feature f only receives lanes with the same (lane mod rep_f): 1024 / rep_f lanes, so the budget grows with the
-    // smallest replication factor of this block's layout (x16..32 at the root and the shallow levels).
-    int rep_min = 32;
-    for (int j = 0; j < cm.nfeat; ++j) { const int r = 1 << lay.sh[j]; if (r < rep_min) rep_min = r; }
-    const unsigned LB_G = ((((1u << 31) - 2048u) / LV_THREADS) * (unsigned)rep_min) >> c.drain_shift;
-    const unsigned LB_H = ((unsigned)((((1ull << 32) - 2048ull)) / LV_THREADS) * (unsigned)rep_min) >> c.drain_shift;
-    unsigned acc_g = 0, acc_h = 0;
-    auto drain = [&]() {
-        // move the bits above 2^11 of both fields into the per-bin carry words
-        for (int li = 0; li < ng; ++li) {
-            for (int s2 = tid; s2 < spn; s2 += LV_THREADS) {
-                const size_t i = (size_t)li * spn + s2;
-                const unsigned long long v = fast[i];
-                const int g32 = (int)(v >> 32);
-                const unsigned int h32 = (unsigned int)(v & 0xFFFFFFFFull);
-                const int cg = g32 >> LV_CARRY_SHIFT;
-                const unsigned int chh = h32 >> LV_CARRY_SHIFT;
-                if (cg != 0 || chh != 0u) {
-                    fast[i] = ((unsigned long long)(unsigned int)(g32 & ((1 << LV_CARRY_SHIFT) - 1)) << 32) | (unsigned long long)(h32 & ((1u << LV_CARRY_SHIFT) - 1u));
-                    const int sw = (int)s2w[s2];
-                    const int wi = li * wb + (sw & 0x7FFF);
-                    if (sw & 0x8000) { if (cg != 0) atomicAdd(&wide_g[wi], cg); if (chh != 0u) atomicAdd(&wide_h[wi], chh); }
-                    else { wide_g[wi] += cg; wide_h[wi] += chh; }   // un-replicated bin: this thread is its only writer
-                }
-            }
-        }
-    };
-    // every wave that reaches a rendezvous executes exactly: barrier, [flag set: drain, barrier, clear, barrier]
-    auto rendezvous = [&]() -> bool {
-        __syncthreads();
-        if (!LV_FLAG_LOAD()) return false;
-        drain();
-        __syncthreads();
-        if (tid == 0) LV_FLAG_STORE(0);
-        __syncthreads();
-        acc_g = 0; acc_h = 0;
-        return true;
-    };
-
-    // one histogram update of a (row, built node) pair held by this lane: 15-16 packed LDS atomics, 3 instructions each
-    auto accumulate = [&](bool on, int li, const uint4& r, const int2& g_in) __attribute__((always_inline)) {
-        int2 g = g_in;
-        if (GONLY) {   // g_in = (quantised gradient, label): h is a function of both and of the label's weight (numerics v1.02)
-            const int yl = on ? (g_in.y & 0x7F) : 0;
-            const double2 ww = wtab[yl];
-            g.y = on ? h_from_g(g_in.x, yl == k, ww.x, ww.y, c.objective, c.inv_sg, c.sh, c.factor) : 0;
-        }
-        const unsigned long long packed = ((unsigned long long)(long long)g.x << 32) + (unsigned long long)(unsigned int)g.y;
-        const bool need = on && packed != 0ull;
-        const unsigned ag = (unsigned)(g.x < 0 ? -g.x : g.x), ah = (unsigned)g.y;
-        const bool over = need && (acc_g + ag > LB_G || acc_h + ah > LB_H);
-        if (__any(over)) { if (lane == 0) LV_FLAG_STORE(1); rendezvous(); }   // (the flag itself is polled once per tile, see tile_step)
-        if (need) {
-            acc_g += ag; acc_h += ah;
-            unsigned char* fb = reinterpret_cast<unsigned char*>(fast) + (unsigned)li * (unsigned)(spn * 8);
-            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#ifdef LV_DBG_NO_ATOM   // timing experiment: everything but the LDS atomics (results are wrong)
-#define LV_ATOM(j) asm volatile("" :: "v"(fb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << fsh3[j])), "v"(packed))
-#else
-#define LV_ATOM(j) atomicAdd(reinterpret_cast<unsigned long long*>(fb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << fsh3[j])), packed)
-#endif
-            if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
-                LV_ATOM(0); LV_ATOM(1); LV_ATOM(2); LV_ATOM(3); LV_ATOM(4); LV_ATOM(5); LV_ATOM(6); LV_ATOM(7);
-                LV_ATOM(8); LV_ATOM(9); LV_ATOM(10); LV_ATOM(11); LV_ATOM(12); LV_ATOM(13); LV_ATOM(14);
-                if (nfeat == 16) LV_ATOM(15);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 14; ++j) if (j < nfeat) LV_ATOM(j);
-            }
-#undef LV_ATOM
-        }
-    };
-
-    // Software pipeline: the loads of the next tile are in flight while this tile's LDS atomics run (one workgroup
-    // per CU, so nothing else would hide the HBM latency).  Addresses are a uniform tile base + a 32-bit lane offset.
     constexpr int RPT = LV_TILE / LV_THREADS;
-    int cur_n[RPT], nxt_n[RPT], cur_ib[RPT], nxt_ib[RPT]; uint4 cur_r[RPT], nxt_r[RPT], cur_r2[RPT], nxt_r2[RPT]; int2 cur_g[RPT], nxt_g[RPT];
-    const uint4* rec_other = rec + (long long)(MULTI == 2 ? 1 - ch : ch) * N;   // MULTI == 2: the record that holds the other 16 features
+    int cur_n[RPT], nxt_n[RPT]; uint4 cur_r[RPT], nxt_r[RPT]; float2 cur_g[RPT], nxt_g[RPT];
     // straight-line loads (clamped offsets, no branches) so that the in-order vmcnt bookkeeping stays exact
-    auto fetch = [&](long long t, int (&fn)[RPT], uint4 (&fr)[RPT], uint4 (&fr2)[RPT], int2 (&fg)[RPT], int (&fib)[RPT]) __attribute__((always_inline)) {
+    auto fetch = [&](long long t, int (&fn)[RPT], uint4 (&fr)[RPT], float2 (&fg)[RPT]) __attribute__((always_inline)) {
         const bool tv = t < ntiles;                                   // uniform
         const long long pb = tv ? t * LV_TILE : 0;
         const long long left_rows = N - pb;
         const unsigned lim = (unsigned)(left_rows < LV_TILE ? left_rows : LV_TILE) - 1u;   // last valid offset in the tile
-        const uint8_t* nb_ = node_in + pb; const uint4* rb_ = recc + pb; const int2* gb_ = ghk + pb;
-        const uint8_t* ib_ = BAG ? inbag + pb : nullptr;
 #pragma unroll
-        for (int s = 0; s < RPT; ++s) {
-            const unsigned o = (unsigned)(s * LV_THREADS + tid);
+        for (int q = 0; q < RPT; ++q) {
+            const unsigned o = (unsigned)(q * LV_THREADS + tid);
             const unsigned oc = o < lim ? o : lim;
-            // STREAM: node ids and (g,h) are use-once data; non-temporal loads leave more of L2 / Infinity Cache to the bin records the
-            // batches re-read (measured: -7 % HBM fetch, -2 % time; profiles/r02_stream_pass_experiments.txt)
-            const int nv = STREAM ? (int)__builtin_nontemporal_load(nb_ + oc) : (int)nb_[oc];
-            if (!STREAM) fr[s] = rb_[oc]; else fr[s] = make_uint4(0, 0, 0, 0);
-            if (!ROOT && !STREAM && MULTI == 2) fr2[s] = (rec_other + pb)[oc]; else fr2[s] = make_uint4(0, 0, 0, 0);
-            if (GONLY) {
-                const int32_t* g32 = reinterpret_cast<const int32_t*>(gh) + (long long)k * N + pb;
-                const int gv = STREAM ? __builtin_nontemporal_load(g32 + oc) : g32[oc];
-                fg[s] = make_int2(gv, ROOT ? (int)ylab[pb + oc] : 0);                 // ROOT: the label rides in the h slot (accumulate)
-            }
-            else if (STREAM) { const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long*>(gb_ + oc)); fg[s] = make_int2((int)(v & 0xFFFFFFFFll), (int)(v >> 32)); }
-            else if (ROOT || STREAM || !LV_RING) fg[s] = gb_[oc]; else fg[s] = make_int2(0, 0);
-            fib[s] = BAG ? (int)ib_[oc] : 1;
-            fn[s] = (tv && o <= lim) ? nv : LV_INACTIVE;
+            const int nv = (int)(node_in + pb)[oc];
+            fr[q] = (recc + pb)[oc];
+            fg[q] = (ghk + pb)[oc];
+            fn[q] = (tv && o <= lim) ? nv : LV_INACTIVE;
         }
     };
-    if (STREAM) {
-        // ---- split mode: coalesced stream over (node id, g, h) of every row; built rows go through the wave's LDS ring.
-        // Ring invariant: at most 64 entries wait when a tile starts (<= 128 are appended per tile, LV_SRING = 192).  Whenever
-        // >= 64 wait after a tile, one batch is taken out (its record gather is issued at once and consumed at the START of
-        // the next tile, so an L2 round trip hides behind that tile's loads); more than 128 waiting (a tile of built rows
-        // only: clustered data) are worked off on the spot.
-        uint32_t* ring_g = sring; uint32_t* ring_h = sring + LV_SRING; uint32_t* ring_r = sring + 2 * LV_SRING;
-        int r_head = 0, r_cnt = 0;                       // wave-uniform
-        bool pend = false; uint4 p_rec = make_uint4(0, 0, 0, 0); int2 p_gh = make_int2(0, 0); int p_li = 0;
-        const unsigned long long lane_lt = (1ull << lane) - 1ull;
-        auto take_batch = [&](int nb) __attribute__((always_inline)) {     // nb = min(r_cnt, 64) entries -> p_*, gather issued
-            const bool on = lane < nb;
-            int pos = r_head + lane; if (pos >= LV_SRING) pos -= LV_SRING;
-            const uint32_t row = ring_r[pos], hw = ring_h[pos];             // h < 2^21 (HQ_MAX): the built slot rides in bits 24..31
-            p_gh = make_int2((int)ring_g[pos], GONLY ? (int)ylab[on ? row : 0u] : (int)(hw & 0xFFFFFFu));   // GONLY: (g, label)
-            p_rec = recc[on ? row : 0u];
-            p_li = on ? (int)(hw >> 24) : -1;
-            r_head += nb; if (r_head >= LV_SRING) r_head -= LV_SRING;
-            r_cnt -= nb; pend = true;
-        };
-        auto run_batch = [&]() __attribute__((always_inline)) {
-            if (ch == 0 && p_li >= 0) atomicAdd(&cnt[p_li * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-            accumulate(p_li >= 0, p_li < 0 ? 0 : p_li, p_rec, p_gh);
-            pend = false;
-        };
-        // the loads of TWO tiles are in flight while a tile is processed (three register sets take turns): with one workgroup
-        // per CU, 9 B per row and ~1.5 us of HBM latency, one tile ahead kept only ~18 KB per CU in flight = 3.7 TB/s
-        auto stream_step = [&](long long t, int (&Cn)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT], int (&Xn)[RPT], uint4 (&Xr)[RPT], uint4 (&Xr2)[RPT], int2 (&Xg)[RPT], int (&Xib)[RPT]) __attribute__((always_inline)) {
-            const long long p0 = t * LV_TILE;
-            if (LV_FLAG_LOAD()) rendezvous();
-            fetch(t + 2 * tstep, Xn, Xr, Xr2, Xg, Xib);
-            if (pend) run_batch();
+    auto accumulate = [&](bool on, const uint4& r, const float2& g) __attribute__((always_inline)) {
+        if (on && (g.x != 0.0f || g.y != 0.0f)) {   // out-of-bag rows carry (0, 0)
+            const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, c.sg), hq = (unsigned long long)fx_from_f32(g.y, c.sh);
+            unsigned char* hb = reinterpret_cast<unsigned char*>(hist);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#define LV_ATOM(j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh4[j])); \
+                     atomicAdd(p_, gq); atomicAdd(p_ + 1, hq); }
 #pragma unroll
-            for (int s = 0; s < RPT; ++s) {
-                const unsigned o = (unsigned)(s * LV_THREADS + tid);
-                const int n = Cn[s];
-                const uint32_t bs = bslot[n];                                  // inactive rows carry id 255, which never names a child
-                const bool built = bs != 0xFFu && (!BAG || Cib[s] != 0) && c.pad0 != 2;   // (pad0 == 2: timing experiment, nothing is appended)
-                const unsigned long long m = __ballot(built);
-                if (built) {
-                    int pos = r_head + r_cnt + (int)__popcll(m & lane_lt); if (pos >= LV_SRING) pos -= LV_SRING; if (pos >= LV_SRING) pos -= LV_SRING;
-                    ring_g[pos] = (uint32_t)Cg[s].x; ring_h[pos] = (GONLY ? 0u : (uint32_t)Cg[s].y) | (bs << 24); ring_r[pos] = (uint32_t)(p0 + o);
-                }
-                r_cnt += (int)__popcll(m);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // ring entries are read by other lanes of this wave
-            if (c.pad0 != 0) { r_cnt = 0; r_head = 0; }                  // timing experiment (RGBM_DBG_STREAM): the stream + ring without the batches
-            while (r_cnt > 128) { take_batch(64); run_batch(); }
-            if (r_cnt >= 64) take_batch(64);
-        };
-        int thd_n[RPT], thd_ib[RPT]; uint4 thd_r[RPT], thd_r2[RPT]; int2 thd_g[RPT];
-        long long t = tbeg;
-        fetch(t, cur_n, cur_r, cur_r2, cur_g, cur_ib);
-        fetch(t + tstep, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib);
-        while (t < ntiles) {
-            stream_step(t, cur_n, cur_g, cur_ib, thd_n, thd_r, thd_r2, thd_g, thd_ib); t += tstep; if (t >= ntiles) break;
-            stream_step(t, nxt_n, nxt_g, nxt_ib, cur_n, cur_r, cur_r2, cur_g, cur_ib); t += tstep; if (t >= ntiles) break;
-            stream_step(t, thd_n, thd_g, thd_ib, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib); t += tstep;
+            for (int j = 0; j < 16; ++j) if (j < nfeat) LV_ATOM(j);
+#undef LV_ATOM
         }
-        if (pend) run_batch();
-        while (r_cnt > 0) { take_batch(r_cnt < 64 ? r_cnt : 64); run_batch(); }
-    } else if (ROOT || !LV_RING) {
-        // one tile: prefetch the tile after it into the other register set, then process this one (the two sets swap
-        // roles from call to call, so nothing is copied)
-        auto tile_step = [&](long long t, int (&Cn)[RPT], uint4 (&Cr)[RPT], uint4 (&Cr2)[RPT], int2 (&Cg)[RPT], int (&Cib)[RPT],
-                             int (&Xn)[RPT], uint4 (&Xr)[RPT], uint4 (&Xr2)[RPT], int2 (&Xg)[RPT], int (&Xib)[RPT]) __attribute__((always_inline)) {
-            const long long p0 = t * LV_TILE;
-            // one poll of the drain flag per tile, before this tile's atomics are queued: an LDS read returns behind every
-            // LDS atomic issued before it, so polling inside the row steps would serialise the atomics of consecutive steps
-            if (ng > 0 && LV_FLAG_LOAD()) rendezvous();
-            fetch(t + tstep, Xn, Xr, Xr2, Xg, Xib);
-            uint8_t* ob_ = node_out + p0;
+    };
+    long long t = tbeg;
+    fetch(t, cur_n, cur_r, cur_g);
+    while (t < ntiles) {
+        fetch(t + tstep, nxt_n, nxt_r, nxt_g);
 #pragma unroll
-            for (int s = 0; s < RPT; ++s) {
-                const unsigned o = (unsigned)(s * LV_THREADS + tid);
-                const int n = Cn[s];
-                if (ROOT) { accumulate(n != LV_INACTIVE, 0, Cr[s], Cg[s]); continue; }
-                const bool inrange = p0 + o < N;
-                // branch-free routing (for !MULTI): unexpanded nodes (and the inactive id 255) route to themselves
-                const uint2 e = route[n];
-                const bool expd = (e.x & (1u << 24)) != 0u;
-                const unsigned f = e.x & 0xFFu;
-                unsigned bin;
-                if (MULTI == 0 || MULTI == 2) {
-                    const bool hi = (f & 8u) != 0u;
-                    uint32_t rx = Cr[s].x, ry = Cr[s].y, rz = Cr[s].z, rw = Cr[s].w;
-                    if (MULTI == 2) {   // the split feature may live in the other chunk's record (prefetched alongside)
-                        const bool mine = (f >> 4) == (unsigned)ch;
-                        rx = mine ? rx : Cr2[s].x; ry = mine ? ry : Cr2[s].y; rz = mine ? rz : Cr2[s].z; rw = mine ? rw : Cr2[s].w;
-                    }
-                    const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
-                    bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
-                } else {
-                    bin = 0;
-                    if (expd) {
-                        if ((f >> 4) == (unsigned)ch) {
-                            const bool hi = (f & 8u) != 0u;
-                            const uint32_t rx = Cr[s].x, ry = Cr[s].y, rz = Cr[s].z, rw = Cr[s].w;
-                            const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
-                            bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
-                        } else bin = rec8[((long long)(f >> 4) * N + p0 + o) * 16 + (f & 15u)];
-                    }
-                }
-                const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
-                const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, group-local built slot in bits 16..23
-                const int child = (int)(sel & 0xFFu);
-                const int li = (int)((sel >> 16) & 0xFFu);             // 0xFF: nothing to accumulate here
-                if (writer && expd && Cib[s]) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                if (writer && inrange) ob_[o] = (uint8_t)child;
-                if (ng > 0) accumulate(li != 0xFF, li, Cr[s], Cg[s]);
-            }
-        };
-        long long t = tbeg;
-        fetch(t, cur_n, cur_r, cur_r2, cur_g, cur_ib);
-        while (t < ntiles) {
-            tile_step(t, cur_n, cur_r, cur_r2, cur_g, cur_ib, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib); t += tstep; if (t >= ntiles) break;
-            tile_step(t, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib, cur_n, cur_r, cur_r2, cur_g, cur_ib); t += tstep;
-        }
-    } else {
-        // ---- level pass with compaction.  Phase 1 (every row): route, count, store the new node id; rows that feed a
-        // histogram of this block's group are appended to this wave's LDS ring (4 B: tile index | row offset | slot).
-        // Phase 2: full waves of 64 listed rows reload (rec, gh) -- L2 hits, the records were streamed a moment ago --
-        // and run the packed atomics.  Order inside one tile step: [batch loads] [far prefetch] [routing] [atomics]:
-        // vmcnt retires in order, so waiting for the batch never waits for the prefetch issued after it.
-        const long long gstep = gridDim.x;
-        int lcount = 0, lhead = 0;            // wave-uniform ring state
-        uint32_t ti = 0;                      // index of the current tile among this block's tiles
-        fetch(blockIdx.x, cur_n, cur_r, cur_r2, cur_g, cur_ib);
-        for (long long t = blockIdx.x; t < ntiles; t += gstep, ++ti) {
-            const long long p0 = t * LV_TILE;
-            bool b_on[2]; uint4 b_r[2]; int2 b_g[2]; int b_li[2]; int b_n[2];
+        for (int q = 0; q < RPT; ++q) accumulate(cur_n[q] != LV_INACTIVE, cur_r[q], cur_g[q]);
+        t += tstep; if (t >= ntiles) break;
+        fetch(t + tstep, cur_n, cur_r, cur_g);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int nb = ng > 0 ? (lcount < 64 ? lcount : 64) : 0;
-                b_n[b] = nb; b_on[b] = lane < nb;
-                const uint32_t e = lst[(lhead + (b_on[b] ? lane : 0)) & (LV_LIST - 1)];
-                const long long row = b_on[b] ? ((long long)blockIdx.x + (long long)(e >> 16) * gstep) * LV_TILE + ((e >> 5) & 0x7FFu) : p0;
-                b_li[b] = (int)(e & 31u);
-                b_r[b] = recc[row]; b_g[b] = ghk[row];
-                lhead += nb; lcount -= nb;
-            }
-            fetch(t + gstep, nxt_n, nxt_r, nxt_r2, nxt_g, nxt_ib);
-            uint8_t* ob_ = node_out + p0;
-#pragma unroll
-            for (int s = 0; s < RPT; ++s) {
-                const unsigned o = (unsigned)(s * LV_THREADS + tid);
-                const int n = cur_n[s];
-                int li = -1;
-                const bool inrange = p0 + o < N;
-                int child = n;
-                if (n != LV_INACTIVE) {
-                    const uint2 e = route[n];
-                    if (e.x & (1u << 24)) {
-                        const unsigned f = e.x & 0xFFu;
-                        unsigned bin;
-                        if (!MULTI || (f >> 4) == (unsigned)ch) {
-                            const bool hi = (f & 8u) != 0u;
-                            const uint32_t rx = cur_r[s].x, ry = cur_r[s].y, rz = cur_r[s].z, rw = cur_r[s].w;
-                            const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
-                            bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
-                        } else bin = rec8[((long long)(f >> 4) * N + p0 + o) * 16 + (f & 15u)];
-                        const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
-                        const unsigned sel = left ? e.y : (e.y >> 8);
-                        child = (int)(sel & 0xFFu);
-                        const int bs = (int)((sel >> 16) & 0xFFu);
-                        if (writer && cur_ib[s]) atomicAdd(&cnt[(child - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                        if (bs != 0xFF) li = bs;   // group-local already (LDS copy of the route table)
-                    }
-                }
-                if (writer && inrange) ob_[o] = (uint8_t)child;
-                if (ng > 0) {
-                    const unsigned long long m = __ballot(li >= 0);
-                    if (li >= 0) lst[(lhead + lcount + __popcll(m & ((1ull << lane) - 1ull))) & (LV_LIST - 1)] = (ti << 16) | (o << 5) | (uint32_t)li;
-                    lcount += __popcll(m);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // ring entries are read by other lanes of this wave
-            if (ng > 0) {
-                if (b_n[0] == 0) { if (LV_FLAG_LOAD()) rendezvous(); }
-                else {
-                    accumulate(b_on[0], b_li[0], b_r[0], b_g[0]);
-                    if (b_n[1] > 0) accumulate(b_on[1], b_li[1], b_r[1], b_g[1]);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < RPT; ++s) { cur_n[s] = nxt_n[s]; cur_r[s] = nxt_r[s]; cur_ib[s] = nxt_ib[s]; }
-        }
-        // leftovers in the ring
-        while (ng > 0 && lcount > 0) {
-            const int nb = lcount < 64 ? lcount : 64;
-            const bool on = lane < nb;
-            const uint32_t e = lst[(lhead + (on ? lane : 0)) & (LV_LIST - 1)];
-            const long long row = on ? ((long long)blockIdx.x + (long long)(e >> 16) * gstep) * LV_TILE + ((e >> 5) & 0x7FFu) : 0;
-            const uint4 br = recc[row]; const int2 bg = ghk[row];
-            lhead += nb; lcount -= nb;
-            accumulate(on, (int)(e & 31u), br, bg);
-        }
+        for (int q = 0; q < RPT; ++q) accumulate(nxt_n[q] != LV_INACTIVE, nxt_r[q], nxt_g[q]);
+        t += tstep;
     }
-    // epilogue rendezvous: leave only when every wave has finished its rows and no drain is pending
-    if (ng > 0) { while (rendezvous()) {} } else __syncthreads();
-    if (STREAM && c.pad0 != 0) return;   // timing experiment: results are discarded
-    // ---- flush this workgroup's partial histograms (plain stores: no global atomics, no zeroing)
-    for (int li = 0; li < ng; ++li) {
-        HistBin* dst = part + (((long long)k * c.gx + bx) * c.max_built + (g0 + li)) * c.totbins;
-        for (int b = tid; b < wb; b += LV_THREADS) {
-            const uint32_t ws = w_slot[b];
-            const int sh = (int)(ws >> 24), s0 = (int)(ws & 0xFFFFFFu);
-            long long tg = (long long)wide_g[li * wb + b] << LV_CARRY_SHIFT;
-            long long th = (long long)(unsigned long long)wide_h[li * wb + b] << LV_CARRY_SHIFT;
-            const unsigned long long* fb = fast + (size_t)li * spn + s0;
-            for (int r2 = 0; r2 < (1 << sh); ++r2) { const unsigned long long v = fb[r2]; tg += (long long)(int)(v >> 32); th += (long long)(unsigned int)(v & 0xFFFFFFFFull); }
+    __syncthreads();
+    // flush this workgroup's partial histogram (plain stores: no global atomics, no zeroing)
+    HistBin* dst = part + (((long long)k * c.gx + bx) * c.max_built) * c.totbins;
+    for (int j = 0; j < nfeat; ++j) {
+        const int shj = lv_cap_shift(fm[j].nbins) < s ? lv_cap_shift(fm[j].nbins) : s;
+        int fb = 0;
+        for (int q = 0; q < j; ++q) { const int cs = lv_cap_shift(fm[q].nbins); fb += fm[q].nbins << (s < cs ? s : cs); }
+        for (int b = tid; b < fm[j].nbins; b += LV_THREADS) {
+            long long tg = 0, th = 0;
+            const HistBin* src = hist + fb + (b << shj);
+            for (int r2 = 0; r2 < (1 << shj); ++r2) { tg += src[r2].g; th += src[r2].h; }
             HistBin o; o.g = tg; o.h = th;
-            dst[w_hoff[b]] = o;
-        }
-    }
-    if (writer) {
-        for (int ci = tid; ci < 2 * n_exp; ci += LV_THREADS) {
-            int tot = 0;
-            for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
-            if (tot) atomicAdd(&count[(long long)k * 256 + child_first + ci], tot);
-        }
-    }
-    if (STREAM && ch == 0) {   // exact row counts of the built children of this group (k_level_plan numbers the children of parent ei as child_first + 2 ei, + 1)
-        for (int ci = tid; ci < ng; ci += LV_THREADS) {
-            int tot = 0;
-            for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
-            const int ei = g0 + ci;
-            if (tot) atomicAdd(&count[(long long)k * 256 + child_first + 2 * ei + (pp->built_is_left[ei] ? 0 : 1)], tot);
+            dst[fm[j].hoff + b] = o;
         }
     }
 }
 
-#undef LV_FLAG_LOAD
-#undef LV_FLAG_STORE
-
-
 // ------------------------------------------------------------------------------------------------
-// k_level_route (split mode): DataPartition::Split of a whole level for ALL class trees of a row tile.
-// A lane owns 4 consecutive rows: their bin records are loaded ONCE and stay in registers while the
-// lane walks the class trees of its slice -- per class tree it reads one dword of node ids, looks the
-// (at most 64) nodes of the level up in an LDS route table and moves the rows to their children in place
-// (only changed dwords are stored).  No (g,h), no histogram, no counting: 1-2 B per (row, class tree) of
-// HBM traffic, ~40 VALU instructions per 64 (row, class tree) pairs (the fused pass spends ~100 on the
-// same routing).  k_level_pass<STREAM> then builds the histograms of the built children.
-// (A first cut also appended the built rows to per-class-tree lists here, for a gather-based accumulate:
-// the returning global atomic per (wave tile, class tree) cost 1.9 of its 2.4 ms and the gathers moved as
-// many HBM bytes as a full stream -- profiles/r02b_split_first_cut_profile.txt.)
-// grid (persistent, ceil(K / RT_KS)), block RT_THREADS.
+// k_level_mt: THE level pass -- DataPartition::Split of a level and ConstructHistograms of its built children, for T class trees
+// of a row block in ONE workgroup.
+//
+// A lane owns 4 consecutive rows; their bin records are loaded ONCE and stay in registers while the lane walks the T class trees of
+// its workgroup.  Per class tree it reads one dword of node ids and the rows' float32 (g, h) (two dwordx4, requested two class trees
+// ahead), looks the (<= 2^(L-1)) nodes of the level up in an LDS route table, moves the rows to their children IN PLACE (changed
+// dwords only) and appends the rows that fall into a BUILT child -- record, (g, h), histogram slot -- to its wave's LDS ring.  Whenever
+// 64 entries wait, they are taken out as one FULL wave of histogram updates: (g, h) go onto the fixed-point grid and into the built
+// child's LDS histogram with two 64-bit atomics per feature.  A wave instruction of LDS atomics costs the same for 6 active lanes as
+// for 64 (profiles/r01_lds_atomic_active_lanes.txt) and a built child holds ~12 % of the rows, hence the ring.
+//
+// What this replaces (rounds 1-2): a routing kernel + a streaming kernel per level that re-read the bin records of the built rows from
+// L2 / HBM per class tree (2.2-4.3 GB of 128-byte lines for 16-byte records at K = 64, profiles/r02q_hbm_traffic_pmc.txt), ~80 VALU
+// instructions per 64 (row, class tree) pairs between them.  Here the records cross the memory system once per T class trees and the
+// routing + ring append is one pass over registers.
+//
+// T is what the CU's LDS holds: T * (built nodes per class tree) histograms of the chunk + the rings.  The histograms of all class
+// trees of a workgroup share the LDS; batches mix the class trees a wave has walked, which spreads the atomics like replication does.
+//   launch = (chunk, built-slot window): the first launch of a level routes (mt_route) and builds chunk 0 / the first window of built
+//   slots; tables with more than 16 features and levels whose histograms exceed the LDS take further launches that find the rows of
+//   their built children by the (already final) node ids.
+//   grid: 1-D, mt_G * gx blocks; id -> xcd = id % 8, slot = id / 8, tree group = slot % G, row block = (slot / G) * 8 + xcd.
+// Algorithmic bytes: rows of built children x (F + 8); the pass also streams 1 + 8 B per (row, class tree) and writes <= 1 B.
 // ------------------------------------------------------------------------------------------------
-template <int NCH /* 1, 2: the row's one / two 16-byte records live in registers; 0: any number of chunks, the split byte is gathered */>
-__global__ __launch_bounds__(RT_THREADS) void k_level_route(const uint4* __restrict__ rec, uint8_t* __restrict__ node /* [K][NS], updated in place */,
-                                                            const LvPlan* __restrict__ plan, LevelConst c) {
-    __shared__ uint2 rt[RT_KS][64];
-    __shared__ int s_base[RT_KS], s_live[RT_KS];
+struct MtTree { int32_t base, nlev, rt_off, slot0, nb, live, child_first, k; };   // 32 B, one per class tree of the workgroup
+
+template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers), 0 = any number of chunks, the split byte is gathered */, bool BAG>
+__global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
+                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
+                                                            int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
+                                                            LevelConst c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned id = blockIdx.x;
+    const int xl = (int)(id & 7u), bslot = (int)(id >> 3);
+    const int grp = bslot % c.mt_G, rb = (bslot / c.mt_G) * 8 + xl;
+    const int k0 = grp * c.mt_T;
+    const int nk = (c.K - k0) < c.mt_T ? (c.K - k0) : c.mt_T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k0 = blockIdx.y * RT_KS;
-    const int nk = (c.K - k0) < RT_KS ? (c.K - k0) : RT_KS;
-    for (int i = tid; i < nk * 64; i += RT_THREADS) {
-        const int kk = i >> 6, j = i & 63;
-        const LvPlan* pp = &plan[k0 + kk];
-        const bool live = !pp->done && pp->n_exp > 0;
-        const int base = live ? (int)pp->exp[0] : 0;          // expanded parents are listed in ascending node id; a level has <= 64 nodes
-        const int n = base + j;
-        uint2 e = make_uint2(0u, 0u);
-        if (live && n < 256) e = make_uint2(pp->route0[n], pp->route1[n]);
-        rt[kk][j] = e;
-        if (j == 0) { s_base[kk] = base; s_live[kk] = live ? 1 : 0; }
+    const int ch = c.mt_ch;
+    const bool route = c.mt_route != 0;
+    const ChunkMeta cm = cmeta[ch];
+    const FeatMeta* fm = fmeta + cm.first_feat;
+    const int nfeat = cm.nfeat, wb = cm.wide_bins;
+
+    // ---- LDS carve-up
+    MtTree* ti = reinterpret_cast<MtTree*>(smem);                                              // [MT_MAX_T]
+    uint8_t* nd_tree = smem + MT_MAX_T * 32;                                                   // [MT_MAX_NODES] local node -> class tree of the workgroup
+    int32_t* scal = reinterpret_cast<int32_t*>(nd_tree + MT_MAX_NODES);                        // [4] total built nodes, replication shift, slots per node, any live class tree
+    uint2* rt = reinterpret_cast<uint2*>(scal + 4);                                            // [MT_MAX_RT] route entries / child -> slot entries
+    int32_t* cnt = reinterpret_cast<int32_t*>(rt + MT_MAX_RT);                                 // [MT_MAX_NODES][MT_CNT_REP]
+    uint4* ring_rec_all = reinterpret_cast<uint4*>(cnt + MT_MAX_NODES * MT_CNT_REP);           // [waves][MT_RING]
+    uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec_all + MT_WAVES * MT_RING);          // [waves][MT_RING]
+    uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + MT_WAVES * MT_RING);     // [waves][MT_RING]
+    uint32_t* w_slot = reinterpret_cast<uint32_t*>(ring_li_all + MT_WAVES * MT_RING);          // [wb] first slot of the bin | sh << 24
+    uint32_t* w_hoff = w_slot + wb;                                                            // [wb] offset of the bin inside a node histogram
+    size_t off = reinterpret_cast<unsigned char*>(w_hoff + wb) - smem;
+    off = (off + 15) & ~(size_t)15;
+    HistBin* hist = reinterpret_cast<HistBin*>(smem + off);
+    const long long avail = (long long)c.lds_bytes - (long long)off;
+
+    // ---- the class trees of this workgroup and their built slots inside this launch's window
+    if (tid < 64) {   // wave 0: lane kk reads the plan of class tree k0 + kk; exclusive prefix sums place its built slots and table entries
+        MtTree t; t.base = 0; t.nlev = 0; t.nb = 0; t.live = 0; t.child_first = 0; t.k = k0 + lane; t.slot0 = 0; t.rt_off = 0;
+        if (lane < nk) {
+            const LvPlan* pp = &plan[k0 + lane];
+            const bool live = !pp->done && pp->n_exp > 0;
+            t.live = live ? 1 : 0;
+            t.child_first = pp->child_first;
+            // routing launch: the table covers the nodes of the OLD level from the first expanded parent on; later launches: the children
+            t.base = live ? (route ? (int)pp->exp[0] : pp->child_first) : 0;
+            t.nlev = live ? (route ? pp->child_first - (int)pp->exp[0] : 2 * pp->n_exp) : 0;
+            int nb = live ? pp->n_built - c.mt_slot0 : 0;
+            if (nb > c.mt_nslots) nb = c.mt_nslots;
+            t.nb = nb < 0 ? 0 : nb;
+        }
+        int inc_nb = t.nb, inc_rt = t.nlev;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(inc_nb, o), b2 = __shfl_up(inc_rt, o); if (lane >= o) { inc_nb += a; inc_rt += b2; } }
+        t.slot0 = inc_nb - t.nb; t.rt_off = inc_rt - t.nlev;
+        const int total = __shfl(inc_nb, 63), rt_total = __shfl(inc_rt, 63);
+        const unsigned long long livem = __ballot(t.live != 0);
+        const bool ok = total <= MT_MAX_NODES && rt_total <= MT_MAX_RT;     // the host sizes T for the worst case: always true
+        if (!ok) { t.live = 0; t.nb = 0; t.nlev = 0; }
+        if (lane < nk) ti[lane] = t;
+        if (lane == 0) {
+            // replication: the largest uniform shift whose histograms fit
+            int s = 5;
+            const int tot = ok ? total : 0;
+            while (s > 0 && (long long)tot * lv_slots(fm, nfeat, s) * 16 > avail) --s;
+            scal[0] = tot; scal[1] = s; scal[2] = lv_slots(fm, nfeat, s); scal[3] = (ok && livem != 0ull) ? 1 : 0;
+        }
     }
     __syncthreads();
+    if (!scal[3]) return;
+    const int total = scal[0], s = scal[1], spn = scal[2];
+    if (!route && total == 0) return;
+    for (int kk = 0; kk < nk; ++kk) {
+        const MtTree t = ti[kk];
+        const LvPlan* pp = &plan[t.k];
+        for (int i = tid; i < t.nlev; i += LV_THREADS) {
+            const int n = t.base + i;
+            uint2 e;
+            if (route) {
+                // LDS copy of the route table, specialised: built slots become workgroup-local (0xFF = that child's histogram is not built
+                // in this launch) and an unexpanded node routes to itself
+                const uint32_t w0 = pp->route0[n]; const uint32_t w1 = pp->route1[n];
+                if (w0 & (1u << 24)) {
+                    const int ls = (int)((w1 >> 16) & 0xFFu) - c.mt_slot0, rs = (int)(w1 >> 24) - c.mt_slot0;
+                    const bool lb = ((w1 >> 16) & 0xFFu) != 0xFFu && ls >= 0 && ls < t.nb, rbb = (w1 >> 24) != 0xFFu && rs >= 0 && rs < t.nb;
+                    e = make_uint2(w0, (w1 & 0xFFFFu) | (lb ? (uint32_t)(t.slot0 + ls) : 0xFFu) << 16 | (rbb ? (uint32_t)(t.slot0 + rs) : 0xFFu) << 24);
+                } else e = make_uint2(0u, (uint32_t)n | (uint32_t)n << 8 | 0xFFFF0000u);
+            } else {
+                // children are numbered child_first + 2 ei (left), + 1 (right); one of the two is built, in slot ei
+                const int ei = i >> 1, ls = ei - c.mt_slot0;
+                const bool mine = (pp->built_is_left[ei] ? 0 : 1) == (i & 1) && ls >= 0 && ls < t.nb;
+                e = make_uint2(mine ? 1u : 0u, mine ? (uint32_t)(t.slot0 + ls) : 0xFFu);
+            }
+            rt[t.rt_off + i] = e;
+        }
+        for (int i = tid; i < t.nb; i += LV_THREADS) nd_tree[t.slot0 + i] = (uint8_t)kk;
+    }
+    for (int i = tid; i < total * MT_CNT_REP; i += LV_THREADS) cnt[i] = 0;
+    for (int i = tid; i < total * spn; i += LV_THREADS) { hist[i].g = 0; hist[i].h = 0; }
+    int sh[16], fbase[16];
+    {
+        int o = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < nfeat) { const int cs = lv_cap_shift(fm[j].nbins); sh[j] = s < cs ? s : cs; fbase[j] = o; o += fm[j].nbins << sh[j]; }
+            else { sh[j] = 0; fbase[j] = 0; }
+        }
+    }
+    for (int j = 0; j < nfeat; ++j) {
+        const int nb_ = fm[j].nbins, wo = fm[j].wide_off;
+        for (int b = tid; b < nb_; b += LV_THREADS) { w_slot[wo + b] = (uint32_t)(fbase[j] + (b << sh[j])) | ((uint32_t)sh[j] << 24); w_hoff[wo + b] = (uint32_t)(fm[j].hoff + b); }
+    }
+    int cj[16], sh4[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { sh4[j] = sh[j] + 4; cj[j] = (fbase[j] + (lane & ((1 << sh[j]) - 1))) * 16; }
+    __syncthreads();
+
+    uint4* ring_rec = ring_rec_all + wave * MT_RING;
+    uint2* ring_gh = ring_gh_all + wave * MT_RING;
+    uint16_t* ring_li = ring_li_all + wave * MT_RING;
+    int r_head = 0, r_cnt = 0;                                   // wave-uniform
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const unsigned spn16 = (unsigned)spn * 16u;
+
+    // one FULL (or final, partial) wave of histogram updates from the ring
+    auto run_batch = [&](int nb) __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ring entries are read by other lanes of this wave
+        const bool on = lane < nb;
+        const int pos = (r_head + lane) & (MT_RING - 1);
+        const uint4 r = ring_rec[pos]; const uint2 g = ring_gh[pos]; const unsigned li = ring_li[pos];
+        r_head = (r_head + nb) & (MT_RING - 1); r_cnt -= nb;
+        if (on) {
+            const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), c.sg), hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), c.sh);
+            if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], 1);
+            unsigned char* hb = reinterpret_cast<unsigned char*>(hist) + li * spn16;
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#define MT_ATOM(j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh4[j])); \
+                     atomicAdd(p_, gq); atomicAdd(p_ + 1, hq); }
+            if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
+                MT_ATOM(0); MT_ATOM(1); MT_ATOM(2); MT_ATOM(3); MT_ATOM(4); MT_ATOM(5); MT_ATOM(6); MT_ATOM(7);
+                MT_ATOM(8); MT_ATOM(9); MT_ATOM(10); MT_ATOM(11); MT_ATOM(12); MT_ATOM(13); MT_ATOM(14);
+                if (nfeat == 16) MT_ATOM(15);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 14; ++j) if (j < nfeat) MT_ATOM(j);
+            }
+#undef MT_ATOM
+        }
+    };
+
     const long long N = c.N, NS = c.NS;
-    const long long nwt = (N + RT_WT_ROWS - 1) / RT_WT_ROWS;
+    const long long nwt_all = (N + MT_WT_ROWS - 1) / MT_WT_ROWS;
+    const long long wt_lo = nwt_all * rb / c.gx, wt_hi = nwt_all * (rb + 1) / c.gx;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
-    for (long long wt = (long long)blockIdx.x * (RT_THREADS / 64) + wave; wt < nwt; wt += (long long)gridDim.x * (RT_THREADS / 64)) {
-        const long long row0 = wt * RT_WT_ROWS + lane * 4;
+    const uint4* rec_acc = rec + (long long)ch * N;                                  // the chunk whose features are accumulated
+    for (long long wt = wt_lo + wave; wt < wt_hi; wt += MT_WAVES) {
+        const long long row0 = wt * MT_WT_ROWS + lane * 4;
         const bool lane_on = row0 < N;
-        uint4 r[4], r2[4];
+        uint4 ra[4], r1[4];             // the accumulated chunk's records (a routing launch accumulates chunk 0: also the routing record); record 1 for routing
+        uint32_t rowmask = 0u;          // bit j: row0 + j exists (and is in the bag)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             long long rr = row0 + j; if (rr >= N) rr = N - 1;
-            if (NCH >= 1) r[j] = rec[rr]; else r[j] = make_uint4(0, 0, 0, 0);
-            if (NCH == 2) r2[j] = rec[N + rr]; else r2[j] = make_uint4(0, 0, 0, 0);
+            ra[j] = rec_acc[rr];
+            if (route && NCHR == 2) r1[j] = rec[N + rr]; else r1[j] = make_uint4(0, 0, 0, 0);
+            if (row0 + j < N) rowmask |= 1u << j;
         }
-        // rows past the end of the table never take part (their node bytes are uninitialised)
-        uint32_t rowmask = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (row0 + j < N) rowmask |= 0xFFu << (8 * j);
-        // node ids of the NEXT class tree are requested before this class tree's store is issued
-        uint32_t n4_next = 0xFFFFFFFFu;
-        if (lane_on) n4_next = *reinterpret_cast<const uint32_t*>(node + (long long)k0 * NS + row0);
+        uint32_t bagmask = 0xFu;
+        if (BAG) { bagmask = 0u; for (int j = 0; j < 4; ++j) if (row0 + j < N && inbag[row0 + j]) bagmask |= 1u << j; }
+        // (node ids, g, h) of the class trees are requested TWO class trees ahead
+        uint32_t n4_a = 0xFFFFFFFFu, n4_b = 0xFFFFFFFFu; float4 ga0, ga1, gb0, gb1;
+        ga0 = ga1 = gb0 = gb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto fetch_tree = [&](int kk, uint32_t& n4, float4& g0, float4& g1) __attribute__((always_inline)) {
+            if (kk < nk && lane_on) {
+                const long long kq = k0 + kk;
+                n4 = *reinterpret_cast<const uint32_t*>(node + kq * NS + row0);
+                const float2* gp = gh + kq * N + row0;
+                if (row0 + 3 < N && ((kq * N + row0) & 1ll) == 0) { g0 = *reinterpret_cast<const float4*>(gp); g1 = *reinterpret_cast<const float4*>(gp + 2); }
+                else {
+                    float2 v[4];
+                    for (int j = 0; j < 4; ++j) { long long rr = row0 + j; if (rr >= N) rr = N - 1; v[j] = gh[kq * N + rr]; }
+                    g0 = make_float4(v[0].x, v[0].y, v[1].x, v[1].y); g1 = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+                }
+            } else n4 = 0xFFFFFFFFu;
+        };
+        fetch_tree(0, n4_a, ga0, ga1);
+        fetch_tree(1, n4_b, gb0, gb1);
         for (int kk = 0; kk < nk; ++kk) {
-            uint32_t* np = reinterpret_cast<uint32_t*>(node + (long long)(k0 + kk) * NS + row0);
-            const uint32_t n4 = n4_next;
-            if (kk + 1 < nk && lane_on) n4_next = *reinterpret_cast<const uint32_t*>(node + (long long)(k0 + kk + 1) * NS + row0);
-            if (!s_live[kk]) continue;                                   // uniform
-            const uint32_t base = (uint32_t)s_base[kk];
+            const uint32_t n4 = n4_a; const float4 g0 = ga0, g1 = ga1;
+            n4_a = n4_b; ga0 = gb0; ga1 = gb1;
+            fetch_tree(kk + 2, n4_b, gb0, gb1);
+            const MtTree t = ti[kk];
+            if (!t.live) continue;                                   // uniform
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(t.base), nlev = (uint32_t)__builtin_amdgcn_readfirstlane(t.nlev);
+            const int rt_off = __builtin_amdgcn_readfirstlane(t.rt_off);
             uint32_t idx[4]; bool in[4]; bool any_in = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 idx[j] = ((n4 >> (8 * j)) & 0xFFu) - base;
-                in[j] = idx[j] < 64u && ((rowmask >> (8 * j)) & 1u);
+                in[j] = idx[j] < nlev && ((rowmask >> j) & 1u);
                 any_in |= in[j];
             }
-            if (__ballot(any_in) == 0ull) continue;                      // no row of this wave tile sits in a node of the level
+            if (__ballot(any_in) == 0ull) continue;                  // no row of this wave tile sits in a node of the level
             uint32_t out4 = n4;
+            const float gg[4] = {g0.x, g0.z, g1.x, g1.z}, hh[4] = {g0.y, g0.w, g1.y, g1.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint2 e = rt[kk][idx[j] & 63u];
-                const bool expd = in[j] && (e.x & (1u << 24)) != 0u;
-                const unsigned f = e.x & 0xFFu;
-                unsigned bin;
-                if (NCH == 0) {
-                    bin = 0u;
-                    if (expd) bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)];
+                const uint2 e = rt[rt_off + (in[j] ? (int)idx[j] : 0)];
+                unsigned li;
+                bool built;
+                if (route) {
+                    const bool expd = in[j] && (e.x & (1u << 24)) != 0u;
+                    const unsigned f = e.x & 0xFFu;
+                    unsigned bin;
+                    if (NCHR == 0) {
+                        bin = 0u;
+                        if (expd) bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)];
+                    } else {
+                        uint32_t rx = ra[j].x, ry = ra[j].y, rz = ra[j].z, rw = ra[j].w;
+                        if (NCHR == 2) { const bool second = (f >> 4) != 0u; rx = second ? r1[j].x : rx; ry = second ? r1[j].y : ry; rz = second ? r1[j].z : rz; rw = second ? r1[j].w : rw; }
+                        const bool hi = (f & 8u) != 0u;
+                        const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
+                        bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
+                    }
+                    const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
+                    const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, workgroup-local built slot in bits 16..23
+                    if (expd) out4 = (out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j));
+                    li = (sel >> 16) & 0xFFu;
+                    built = expd && li != 0xFFu;
                 } else {
-                    uint32_t rx = r[j].x, ry = r[j].y, rz = r[j].z, rw = r[j].w;
-                    if (NCH == 2) { const bool second = (f >> 4) != 0u; rx = second ? r2[j].x : rx; ry = second ? r2[j].y : ry; rz = second ? r2[j].z : rz; rw = second ? r2[j].w : rw; }
-                    const bool hi = (f & 8u) != 0u;
-                    const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
-                    bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
+                    li = e.y & 0xFFu;
+                    built = in[j] && e.x != 0u;
                 }
-                const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
-                const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7
-                if (expd) out4 = (out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j));
+                if (BAG) built = built && ((bagmask >> j) & 1u);
+                const unsigned long long m = __ballot(built);
+                if (m != 0ull) {                                      // uniform
+                    if (built) {
+                        const int pos = (r_head + r_cnt + (int)__popcll(m & lane_lt)) & (MT_RING - 1);
+                        ring_rec[pos] = ra[j]; ring_gh[pos] = make_uint2(__float_as_uint(gg[j]), __float_as_uint(hh[j])); ring_li[pos] = (uint16_t)li;
+                    }
+                    r_cnt += (int)__popcll(m);
+                    if (r_cnt >= 64) run_batch(64);
+                }
             }
-            if (out4 != n4) *np = out4;
+            if (route && out4 != n4) *reinterpret_cast<uint32_t*>(node + (long long)t.k * NS + row0) = out4;
+        }
+    }
+    while (r_cnt > 0) run_batch(r_cnt < 64 ? r_cnt : 64);
+    __syncthreads();
+    // ---- flush this workgroup's partial histograms (plain stores: no global atomics, no zeroing) and the built-row counts
+    for (int i = tid; i < total * wb; i += LV_THREADS) {
+        const int ln = i / wb, b = i - ln * wb;
+        const MtTree t = ti[nd_tree[ln]];
+        const uint32_t ws = w_slot[b];
+        const int shb = (int)(ws >> 24), s0 = (int)(ws & 0xFFFFFFu);
+        long long tg = 0, th = 0;
+        const HistBin* src = hist + (size_t)ln * spn + s0;
+        for (int r2 = 0; r2 < (1 << shb); ++r2) { tg += src[r2].g; th += src[r2].h; }
+        HistBin o; o.g = tg; o.h = th;
+        part[(((long long)t.k * c.gx + rb) * c.max_built + (c.mt_slot0 + ln - t.slot0)) * c.totbins + w_hoff[b]] = o;
+    }
+    if (ch == 0) {   // exact row counts of the built children (k_level_plan numbers the children of parent ei as child_first + 2 ei, + 1)
+        for (int ln = tid; ln < total; ln += LV_THREADS) {
+            int tot = 0;
+            for (int r2 = 0; r2 < MT_CNT_REP; ++r2) tot += cnt[ln * MT_CNT_REP + r2];
+            const MtTree t = ti[nd_tree[ln]];
+            const int ei = c.mt_slot0 + ln - t.slot0;
+            if (tot) atomicAdd(&count[(long long)t.k * 256 + t.child_first + 2 * ei + (plan[t.k].built_is_left[ei] ? 0 : 1)], tot);
         }
     }
 }
@@ -899,8 +686,8 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int b = lane * 4 + j; if (b < fm.nbins) { HistBin v; v.g = ag[j]; v.h = ah[j]; hm[b] = v; } }
     int nl = count[(long long)k * 256 + l], nr = count[(long long)k * 256 + r];
-    if (lc.split_mode) {
-        // only the built child was counted (k_level_pass<STREAM>); its sibling holds the rest of the parent's rows.  The derived
+    {
+        // only the built child was counted (k_level_mt); its sibling holds the rest of the parent's rows.  The derived
         // count is published for the leaf counts; row-sharded training sums the LOCAL arrays, so exactly one rank also
         // stores it there (lc.sib_local).
         const int nb = bl ? nl : nr, ns = P.count - nb;
@@ -927,9 +714,9 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
 // ------------------------------------------------------------------------------------------------
 // k_level_plan: one wave per class tree, before pass `level` (which routes depth level-1 -> level).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, LvLayout* __restrict__ layout, const LvLayout* __restrict__ lay_table, SNode* __restrict__ nodes,
+__global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, SNode* __restrict__ nodes,
                                                     const Cand* __restrict__ cand, const FeatMeta* __restrict__ fmeta,
-                                                    const ChunkMeta* __restrict__ cmeta, int level, TrainConst c, LevelConst lc) {
+                                                    int level, TrainConst c, LevelConst lc) {
     __shared__ double pm[256];
     const int k = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
     LvPlan* pp = &plan[k];
@@ -1003,29 +790,12 @@ __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, L
         const uint32_t ls = with_hist && built_left ? (uint32_t)ei : 0xFFu, rs = with_hist && !built_left ? (uint32_t)ei : 0xFFu;
         pp->route1[n] = (uint32_t)l | (uint32_t)r << 8 | ls << 16 | rs << 24;
     }
-    // 4. LDS layout of the pass
     const int n_built = with_hist ? n_exp : 0;
-    int npg = 1, n_groups = 1;
-    if (n_built > 0) {
-        npg = n_built;
-        for (int chn = 0; chn < c.nchunk; ++chn) {
-            const ChunkMeta cm = cmeta[chn]; const FeatMeta* fm = fmeta + cm.first_feat;
-            const long long avail = lc.lds_bytes - lv_fixed_bytes(cm, LV_MAX_EXP, fm);
-            long long fit = (avail - (long long)lv_slots(fm, cm.nfeat, 0) * 2) / lv_node_bytes(fm, cm, 0);
-            if (fit < 1) fit = 1;
-            if (fit < npg) npg = (int)fit;
-        }
-        n_groups = (n_built + npg - 1) / npg;
-    }
-    if (lane < c.nchunk) {
-        layout[(long long)k * c.nchunk + lane] = lay_table[lane * (LV_MAX_BUILT + 1) + (npg < 1 ? 1 : npg)];   // precomputed on the host (lv_choose_layout)
-    }
     if (lane == 0) {
-        pp->n_exp = n_exp; pp->n_built = n_built; pp->npg = npg; pp->n_groups = n_groups;
+        pp->n_exp = n_exp; pp->n_built = n_built;
         pp->child_first = child_first; pp->n_nodes = child_first + 2 * n_exp;
         pp->lvl_first = child_first; pp->lvl_end = child_first + 2 * n_exp;
         if (with_hist) pp->n_hslots = hs0 + 2 * n_exp;
-        pp->buf_in = pp->buf; pp->buf = 1 - pp->buf;
     }
 }
 
@@ -1140,8 +910,7 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
 // training row ends in its final speculative node, whose score delta the replay has tabulated.
 // grid (gx, K), block 256, 4 rows per thread.
 // ------------------------------------------------------------------------------------------------
-template <bool SCORE /* false: store the final node ids instead; the next k_grad_mc applies the deltas (lazy AddScore) */>
-__global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ rec, uint8_t* __restrict__ node_a, uint8_t* __restrict__ node_b,
+__global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ rec, const uint8_t* __restrict__ node_all,
                                                      const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, const TreeOut out,
                                                      const double* __restrict__ node_delta, double* __restrict__ score, int32_t* __restrict__ count,
                                                      const int32_t* __restrict__ itp, LevelConst c) {
@@ -1153,7 +922,6 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     if (out.L[(long long)it * c.K + k] <= 1) return;   // no split: no score change, nothing to count
     const LvPlan* pp = &plan[k];
     const bool route = !pp->done;                      // plan(max_depth) expanded at least one node
-    if (!SCORE && !route) return;                      // the ids in pp->buf are final already
     const int n_exp = route ? pp->n_exp : 0, child_first = pp->child_first;
     const int tid = threadIdx.x, lane = tid & 63;
     nd[tid] = node_delta[(long long)k * 256 + tid];
@@ -1161,8 +929,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     for (int i = tid; i < 2 * n_exp * LV_CNT_REP; i += 256) cnt[i] = 0;
     __syncthreads();
     const long long N = c.N;
-    const uint8_t* node = ((route ? pp->buf_in : pp->buf) ? node_b : node_a) + (long long)k * c.NS;
-    uint8_t* node_out = (pp->buf ? node_b : node_a) + (long long)k * c.NS;   // !SCORE: receives the routed ids
+    const uint8_t* node = node_all + (long long)k * c.NS;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
     double* sk = score + (long long)k * N;
     // 4 rows per thread; node ids and scores are loaded together (independent loads), then routed and written back
@@ -1170,15 +937,13 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     for (long long i = ((long long)blockIdx.x * 256 + tid) * 4; i < N; i += (long long)gridDim.x * 1024) {
         if (i + 3 < N && aligned16) {
             const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
-            double2 s01 = make_double2(0, 0), s23 = make_double2(0, 0);
-            if (SCORE) { s01 = *reinterpret_cast<const double2*>(sk + i); s23 = *reinterpret_cast<const double2*>(sk + i + 2); }
-            if (n4 == 0xFFFFFFFFu) { if (!SCORE) *reinterpret_cast<uint32_t*>(node_out + i) = n4; continue; }
+            double2 s01 = *reinterpret_cast<const double2*>(sk + i), s23 = *reinterpret_cast<const double2*>(sk + i + 2);
+            if (n4 == 0xFFFFFFFFu) continue;
             double sv[4] = {s01.x, s01.y, s23.x, s23.y};
-            uint32_t o4 = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int n = (int)((n4 >> (8 * j)) & 0xFFu);
-                if (n == LV_INACTIVE) { o4 |= 0xFFu << (8 * j); continue; }
+                if (n == LV_INACTIVE) continue;
                 const long long row = i + j;
                 const uint32_t w0 = route0[n];
                 if (w0 & (1u << 24)) {
@@ -1189,17 +954,15 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
                     n = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
                     if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
                 }
-                if (SCORE) sv[j] += nd[n]; else o4 |= (uint32_t)n << (8 * j);
+                sv[j] += nd[n];
             }
-            if (SCORE) {
-                s01.x = sv[0]; s01.y = sv[1]; s23.x = sv[2]; s23.y = sv[3];
-                *reinterpret_cast<double2*>(sk + i) = s01; *reinterpret_cast<double2*>(sk + i + 2) = s23;
-            } else *reinterpret_cast<uint32_t*>(node_out + i) = o4;
+            s01.x = sv[0]; s01.y = sv[1]; s23.x = sv[2]; s23.y = sv[3];
+            *reinterpret_cast<double2*>(sk + i) = s01; *reinterpret_cast<double2*>(sk + i + 2) = s23;
             continue;
         }
         for (long long row = i; row < N && row < i + 4; ++row) {
             int n = node[row];
-            if (n == LV_INACTIVE) { if (!SCORE) node_out[row] = (uint8_t)LV_INACTIVE; continue; }
+            if (n == LV_INACTIVE) continue;
             const uint32_t w0 = route0[n];
             if (w0 & (1u << 24)) {
                 const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
@@ -1209,7 +972,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
                 n = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
                 if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
             }
-            if (SCORE) sk[row] += nd[n]; else node_out[row] = (uint8_t)n;
+            sk[row] += nd[n];
         }
     }
     __syncthreads();

@@ -4,7 +4,7 @@
 // -ffp-contract=off for both the host (clang) and the gfx950 device pass, so the same IEEE
 // double operations run in the same order on the CPU and on the GPU:
 //   * rg_exp      own exp(): 2^k * P13(r), plain mul/add Horner (no libm/ocml dependence)
-//   * quantise    gradients/hessians -> fixed point (|gq| <= 2^20-1, 0 <= hq <= 2^21-1)
+//   * fx_from_f32 float32 gradient / hessian -> the model's fixed-point grid (exact integer histogram sums, numerics v2)
 //   * leaf_gain / leaf_output / threshold_l1   LightGBM feature_histogram.hpp formulas
 //     (GetLeafGain, CalculateSplittedLeafOutput, ThresholdL1) as reached from
 //     python/repair/train.py:102-115 (no max_delta_step, no path smoothing, no monotone).
@@ -20,10 +20,7 @@
 
 namespace rg {
 
-constexpr int GQ_MAX = (1 << 20) - 1;   // |quantised gradient|
-constexpr int HQ_MAX = (1 << 21) - 1;   // quantised hessian
-constexpr int TILE_ROWS = 2048;         // rows between two drains of the packed LDS histogram:
-                                        // 2048 * GQ_MAX < 2^31 and 2048 * HQ_MAX < 2^32
+constexpr int TILE_ROWS = 2048;         // rows per tile of the leaf-wise histogram kernel
 RG_HD double k_eps() { return (double)1e-15f; }   // LightGBM kEpsilon (a float literal)
 
 RG_HD double rg_exp(double x) {
@@ -71,34 +68,25 @@ RG_HD double leaf_gain(double G, double H, double l1, double l2) {
     return (sg * sg) / (H + l2);
 }
 
-RG_HD int quant_g(double g, double sg) {
-    double a = rint(g * sg);
-    if (a > (double)GQ_MAX) a = (double)GQ_MAX;
-    if (a < -(double)GQ_MAX) a = -(double)GQ_MAX;
-    return (int)a;
-}
-RG_HD int quant_h(double h, double sh) {
-    double b = rint(h * sh);
-    if (b > (double)HQ_MAX) b = (double)HQ_MAX;
-    return (int)b;
-}
 RG_HD long long round_int(double x) { return (long long)(x + 0.5); }
 
-// Numerics v1.02: the quantised hessian is a FUNCTION of the quantised gradient (and of the row's label and weight), not of
-// the unrounded probability.  For the binary / softmax objectives g = (p - [y is this class]) * w and h = factor * p * (1 - p) * w, so
-// p -- and with it h -- is recovered from g to within the gradient's own resolution (2^-20 of its bound, the same order as the
-// rounding of h itself).  This is what lets the level passes stream 4 bytes per (row, class tree) instead of 8: they carry g only
-// and recompute h for the rows they accumulate.  Regression: h = w, independent of g.
-//   obj 0: g = response * w, h = |response| (1 - |response|) w;  obj 1: as above;  obj 2: h = w.
-RG_HD int h_from_g(int gq, bool is_label_class, double w, double inv_w /* 1.0 / w, or 0 for w = 0 */, int obj, double inv_sg, double sh, double factor) {
-    if (obj == 2) return quant_h(w, sh);
-    const double a = ((double)gq * inv_sg) * inv_w;      // the reciprocal is taken once per label / row: no division per (row, class tree)
-    double h;
-    if (obj == 0) { const double r = fabs(a); h = r * (1.0 - r) * w; }
-    else { const double p = is_label_class ? a + 1.0 : a; h = factor * p * (1.0 - p) * w; }
-    if (!(h > 0.0)) h = 0.0;       // p rounded a hair outside [0, 1]; w = 0
-    return quant_h(h, sh);
+// Numerics v2.  The gradient and hessian of a (row, class tree) are LightGBM's own float32 values (score_t; *_objective.hpp
+// GetGradients: the double expression rounded once to float).  A histogram sum is the EXACT integer sum of those floats on a per-model
+// fixed-point grid: fx = rint(v * 2^e), with e chosen on the host so that |v * 2^e| <= 2^E, E = min(40, 62 - ceil_log2(training rows))
+// -- an int64 sum over every row cannot overflow.  Integer sums are associative, so a histogram does not depend on lanes, workgroups,
+// launch geometry or the number of GPUs; and because a double sum of float32 values is itself exact until it outgrows 53 bits, the
+// sums equal LightGBM's own wherever those did not have to round (tests/test_numerics_bound.py).
+//   rint by the 1.5 * 2^52 trick: one IEEE add rounds x to the nearest integer (ties to even) for |x| < 2^51, and the low mantissa bits
+//   of the sum are that integer in two's complement.  The oracle calls rint(): same value.
+RG_HD long long fx_from_f32(float v, double scale /* 2^e */) {
+    double x = (double)v * scale;
+    const double lim = 1125899906842624.0;           // 2^50 (never reached: |x| <= 2^40 by construction of e)
+    if (x > lim) x = lim;
+    if (x < -lim) x = -lim;
+    const double magic = 6755399441055744.0;         // 1.5 * 2^52
+    union { double d; long long i; } u, m;
+    u.d = x + magic; m.d = magic;
+    return u.i - m.i;
 }
-RG_HD double rg_inv_weight(double w) { return w > 0.0 ? 1.0 / w : 0.0; }
 
 }  // namespace rg

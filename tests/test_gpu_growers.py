@@ -1,9 +1,11 @@
-"""-m gpu: the three HIP tree growers (level-synchronous streaming grower, leaf-wise index-list grower, fused small-table
-grower) against the CPU oracle and against each other, bit-exact.
+"""-m gpu: the HIP tree growers (level-synchronous streaming grower, leaf-wise index-list grower) against the CPU oracle and
+against each other, bit-exact.
 
 The level grower (csrc/rgbm_level.h) is used for 1 <= max_depth <= 7 and F <= 255, everything else takes the leaf-wise grower
-(csrc/rgbm_kernels.h); the fused one-launch-per-tree grower (csrc/rgbm_small.h) is an opt-in.  RGBM_GROWER=level|small|leafwise
-forces one of them, which is how the same configuration is run through all of them here.
+(csrc/rgbm_kernels.h); RGBM_GROWER=level|leafwise forces one of them.  The level pass (k_level_mt) shares a workgroup between as
+many class trees as the LDS holds and takes further launches per level when it does not hold one class tree's built nodes; the
+switches RGBM_MT_TREES (cap on the class trees per workgroup), RGBM_LV_LDS (smaller LDS pool: several built-slot windows per level)
+and RGBM_MT_BLOCKS (row blocks) run the same configuration through those shapes here.
 """
 import os
 
@@ -15,17 +17,17 @@ from tests.synth import make_table, balanced_weights
 pytestmark = pytest.mark.gpu
 
 
-class _grower:
-    """level = the fused level pass; split = route + stream kernels (the default for large fits); leafwise; small = the fused
-    one-launch-per-tree grower (opt-in)."""
-
-    def __init__(self, name):
-        self.name = name
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
 
     def __enter__(self):
-        self.prev = {k: os.environ.get(k) for k in ("RGBM_GROWER", "RGBM_LEVEL_SPLIT")}
-        os.environ["RGBM_GROWER"] = {"level": "level", "split": "level", "leafwise": "leafwise", "small": "small"}[self.name]
-        os.environ["RGBM_LEVEL_SPLIT"] = "1" if self.name == "split" else "0"
+        self.prev = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
 
     def __exit__(self, *a):
         for k, v in self.prev.items():
@@ -35,26 +37,27 @@ class _grower:
                 os.environ[k] = v
 
 
+# the same fit through: the level grower as configured by default; one class tree per workgroup; a small LDS pool (several built-slot
+# windows per level) with odd row-block counts; the leaf-wise grower
+VARIANTS = [("level", dict(RGBM_GROWER="level")),
+            ("level, 1 class tree per workgroup", dict(RGBM_GROWER="level", RGBM_MT_TREES=1)),
+            ("level, 2 class trees, small LDS, 24 row blocks", dict(RGBM_GROWER="level", RGBM_MT_TREES=2, RGBM_LV_LDS=90000, RGBM_MT_BLOCKS=24, RGBM_LV_BLOCKS=24)),
+            ("leafwise", dict(RGBM_GROWER="leafwise"))]
+
+
 def _three_way(X, n_codes, y, K, obj, cw=None, yv=None, **kw):
     from oracle import oracle as O
     from repair import _native as N
     params = dict(objective=obj, num_class=max(K, 2), **kw)
     mo = O.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
-    with _grower("level"):
-        ml = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
-    with _grower("split"):
-        ms = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
-    with _grower("leafwise"):
-        mw = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
-    with _grower("small"):
-        mf = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
     bo = mo.save()
-    assert mf.save() == bo, "fused small-table grower differs from the oracle"
-    assert ml.save() == bo, "level grower (fused pass) differs from the oracle"
-    assert ms.save() == bo, "level grower (route + list passes) differs from the oracle"
-    assert mw.save() == bo, "leaf-wise grower differs from the oracle"
-    po = mo.predict(X)
-    assert np.array_equal(po, ml.predict(X))
+    first = None
+    for name, env in VARIANTS:
+        with _env(**env):
+            m = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
+        assert m.save() == bo, "%s: differs from the oracle" % name
+        first = first or m
+    assert np.array_equal(mo.predict(X), first.predict(X))
     return mo
 
 
@@ -158,32 +161,10 @@ def test_random_configurations_stress():
                   min_gain_to_split=float(rng.choice([0.0, 0.0, 0.05])), feature_fraction=float(rng.choice([1.0, 1.0, 0.6])))
         cw = balanced_weights(y, K)
         mo = O.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
-        for g in ("level", "small"):
-            with _grower(g):
+        for g, env in (VARIANTS[0], VARIANTS[1 + trial % 2]):
+            with _env(**env):
                 mg = N.train(X, cards.astype(np.int32), y, K, class_weight=cw, **kw)
-            assert mo.save() == mg.save(), "trial %d differs (%s grower): n=%d F=%d K=%d %r" % (trial, g, n, F, K, kw)
-
-
-@pytest.mark.parametrize("env", ["RGBM_LAZY_SCORE"])
-def test_opt_in_experiments_stay_bit_exact(env):
-    """Opt-in variants kept in the library (deferred AddScore inside the gradient kernel) must not change a bit either."""
-    from oracle import oracle as O
-    from repair import _native as N
-    X, nc, y, K = _xy(30000, 10, 7, seed=97)   # K = 24 -> multiclass
-    kw = dict(objective=1, num_class=K, n_estimators=9, learning_rate=0.2)
-    cw = balanced_weights(y, K)
-    mo = O.train(X, nc, y, K, class_weight=cw, **kw)
-    prev = os.environ.get(env)
-    os.environ[env] = "1"
-    try:
-        with _grower("level"):
-            mg = N.train(X, nc, y, K, class_weight=cw, **kw)
-    finally:
-        if prev is None:
-            os.environ.pop(env, None)
-        else:
-            os.environ[env] = prev
-    assert mo.save() == mg.save()
+            assert mo.save() == mg.save(), "trial %d differs (%s): n=%d F=%d K=%d %r" % (trial, g, n, F, K, kw)
 
 
 def test_random_configurations_stress_wide_and_sampled():
@@ -214,42 +195,21 @@ def test_random_configurations_stress_wide_and_sampled():
             y = np.where(rng.random(n) < 0.3, rng.integers(0, K, n), (z + X[2]) % K).astype(np.int32)
             args, kws = (X, cards.astype(np.int32), y, K), dict(class_weight=balanced_weights(y, K), objective=0 if K == 2 else 1, num_class=max(K, 2), **kw)
         mo = O.train(*args, **kws)
-        for g in ("level", "small"):
-            with _grower(g):
+        for g, env in (VARIANTS[0], VARIANTS[1 + trial % 2]):
+            with _env(**env):
                 mg = N.train(*args, **kws)
-            assert mo.save() == mg.save(), "trial %d differs (%s grower): n=%d F=%d %r" % (trial, g, n, F, kw)
+            assert mo.save() == mg.save(), "trial %d differs (%s): n=%d F=%d %r" % (trial, g, n, F, kw)
 
 
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.prev = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            os.environ[k] = str(v)
-
-    def __exit__(self, *a):
-        for k, v in self.prev.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
-@pytest.mark.parametrize("shift,lds", [(5, None), (9, None), (14, None), (9, 80000)])
-def test_forced_packed_slot_drains_stay_bit_exact(shift, lds):
-    """The 32+32-bit packed LDS slots are drained into carry words when a lane's |g| / h budget runs out; at test sizes
-    that never happens by itself.  RGBM_LV_DRAIN_SHIFT shrinks the budgets (here down to a drain per row step), so the
-    flag / rendezvous protocol of k_level_pass runs in every position: inside a tile, at the tile poll, in the epilogue.
-    RGBM_LV_LDS shrinks the LDS pool as well, so deep levels run several histogram groups per pass."""
+@pytest.mark.parametrize("lds,trees,blocks", [(None, None, None), (90000, None, 16), (88000, 1, 8), (None, 3, 40)])
+def test_level_pass_shapes_stay_bit_exact(lds, trees, blocks):
+    """Binary (the largest gradients), K = 24 and a two-chunk regression table through several shapes of the level pass: class trees
+    per workgroup, LDS pool (built-slot windows), row blocks."""
     from oracle import oracle as O
     from repair import _native as N
-    env = dict(RGBM_LV_DRAIN_SHIFT=shift)
-    if lds:
-        env["RGBM_LV_LDS"] = lds
+    env = dict(RGBM_GROWER="level", RGBM_LV_LDS=lds, RGBM_MT_TREES=trees, RGBM_MT_BLOCKS=blocks, RGBM_LV_BLOCKS=blocks)
     cases = []
-    X, nc, y, K = _xy(30000, 8, 0, seed=101)                       # binary: the largest quantised gradients
+    X, nc, y, K = _xy(30000, 8, 0, seed=101)                       # binary
     cases.append((X, nc, y, K, dict(objective=0, num_class=2, n_estimators=5, learning_rate=0.3), balanced_weights(y, K), None))
     X, nc, y, K = _xy(26000, 10, 7, seed=103, null_ratio=0.03)     # K = 24
     cases.append((X, nc, y, K, dict(objective=1, num_class=K, n_estimators=3, learning_rate=0.3, min_data_in_leaf=5), balanced_weights(y, K), None))
@@ -261,16 +221,15 @@ def test_forced_packed_slot_drains_stay_bit_exact(shift, lds):
                   dict(objective=2, num_class=2, n_estimators=4, learning_rate=0.2), None, vals))
     for X, nc, y, K, kw, cw, yv in cases:
         mo = O.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
-        for split in (0, 1):                                       # the fused level pass, and the route + stream passes
-            with _env(RGBM_LEVEL_SPLIT=split, RGBM_GROWER="level", **env):
-                mg = N.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
-            assert mo.save() == mg.save(), "objective %d differs with forced drains (split=%d)" % (kw["objective"], split)
+        with _env(**env):
+            mg = N.train(X, nc, y, K, y_value=yv, class_weight=cw, **kw)
+        assert mo.save() == mg.save(), "objective %d differs (lds=%r trees=%r blocks=%r)" % (kw["objective"], lds, trees, blocks)
 
 
 @pytest.mark.parametrize("tgt", [0, 3])
 def test_millions_of_rows_against_the_oracle(tgt):
-    """2.5M rows: every workgroup streams many tiles, lanes run out of drain budget on their own at the deep levels
-    (replication 1-2), and the per-workgroup partials are summed by k_level_reduce.  (100M rows: tools/big_rows_check.py.)"""
+    """2.5M rows: every workgroup streams many wave tiles, the rings wrap many times, and the per-workgroup partials are summed by
+    k_level_reduce.  (100M rows: tools/big_rows_check.py.)"""
     X, nc, y, K = _xy(2_500_000, 8, tgt, seed=109)
     from oracle import oracle as O
     from repair import _native as N

@@ -16,10 +16,13 @@ from tests.synth import make_table, balanced_weights
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fused", "split"], autouse=True)
+@pytest.fixture(params=["default", "one_tree_small_lds"], autouse=True)
 def level_pass_kind(request, monkeypatch):
-    """Every case runs with the fused level pass and with the route + list-accumulate kernels (the default for large fits)."""
-    monkeypatch.setenv("RGBM_LEVEL_SPLIT", "1" if request.param == "split" else "0")
+    """Every case runs with the level pass as configured by default and with one class tree per workgroup + a small LDS pool (several
+    launches per level)."""
+    if request.param == "one_tree_small_lds":
+        monkeypatch.setenv("RGBM_MT_TREES", "1")
+        monkeypatch.setenv("RGBM_LV_LDS", "90000")
     return request.param
 
 
