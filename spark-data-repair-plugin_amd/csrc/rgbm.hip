@@ -643,7 +643,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             for (int ch = 0; ch < nchunk; ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
                 const long long node_bytes = (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 16;
-                long long cap = (lc.lds_bytes - mt_fixed_bytes(cmeta[ch].wide_bins)) / std::max<long long>(node_bytes, 1);
+                long long cap = (lc.lds_bytes - mt_fixed_bytes()) / std::max<long long>(node_bytes, 1);
                 cap = std::min<long long>(cap, MT_MAX_NODES);
                 if (cap < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
                 const int win = (int)std::min<long long>(worst, cap);                    // built slots per launch

@@ -105,10 +105,10 @@ __host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int s) {
 // bytes the root pass needs besides the histogram: nothing but alignment slack
 constexpr int LV_ROOT_FIXED = 256;
 // bytes k_level_mt needs besides the histogram: tree table | node -> tree map | route entries | built-row counters | per-wave rings
-// (record 16 B + (g, h) 8 B + slot 2 B per entry) | wide-bin tables (8 B per bin of the chunk) | slack
-__host__ __device__ inline long long mt_fixed_bytes(int wide_bins) {
-    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
-           (long long)MT_WAVES * MT_RING * (16 + 8 + 2) + (long long)wide_bins * 8 + 512;
+// (record 16 B + (g, h) 8 B + slot 2 B per entry) | per-feature flush table | slack
+__host__ __device__ inline long long mt_fixed_bytes() {
+    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 256 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
+           (long long)MT_WAVES * MT_RING * (16 + 8 + 2) + 256;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -284,14 +284,13 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
     MtTree* ti = reinterpret_cast<MtTree*>(smem);                                              // [MT_MAX_T]
     uint8_t* nd_tree = smem + MT_MAX_T * 32;                                                   // [MT_MAX_NODES] local node -> class tree of the workgroup
     int32_t* scal = reinterpret_cast<int32_t*>(nd_tree + MT_MAX_NODES);                        // [4] total built nodes, replication shift, slots per node, any live class tree
-    uint2* rt = reinterpret_cast<uint2*>(scal + 4);                                            // [MT_MAX_RT] route entries / child -> slot entries
+    int32_t* ftab = scal + 4;                                                                  // [4][16] per feature: first wide bin | first slot | replication shift | histogram offset
+    uint2* rt = reinterpret_cast<uint2*>(ftab + 64);                                           // [MT_MAX_RT] route entries / child -> slot entries
     int32_t* cnt = reinterpret_cast<int32_t*>(rt + MT_MAX_RT);                                 // [MT_MAX_NODES][MT_CNT_REP]
     uint4* ring_rec_all = reinterpret_cast<uint4*>(cnt + MT_MAX_NODES * MT_CNT_REP);           // [waves][MT_RING]
     uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec_all + MT_WAVES * MT_RING);          // [waves][MT_RING]
     uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + MT_WAVES * MT_RING);     // [waves][MT_RING]
-    uint32_t* w_slot = reinterpret_cast<uint32_t*>(ring_li_all + MT_WAVES * MT_RING);          // [wb] first slot of the bin | sh << 24
-    uint32_t* w_hoff = w_slot + wb;                                                            // [wb] offset of the bin inside a node histogram
-    size_t off = reinterpret_cast<unsigned char*>(w_hoff + wb) - smem;
+    size_t off = reinterpret_cast<unsigned char*>(ring_li_all + MT_WAVES * MT_RING) - smem;
     off = (off + 15) & ~(size_t)15;
     HistBin* hist = reinterpret_cast<HistBin*>(smem + off);
     const long long avail = (long long)c.lds_bytes - (long long)off;
@@ -368,9 +367,12 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
             else { sh[j] = 0; fbase[j] = 0; }
         }
     }
-    for (int j = 0; j < nfeat; ++j) {
-        const int nb_ = fm[j].nbins, wo = fm[j].wide_off;
-        for (int b = tid; b < nb_; b += LV_THREADS) { w_slot[wo + b] = (uint32_t)(fbase[j] + (b << sh[j])) | ((uint32_t)sh[j] << 24); w_hoff[wo + b] = (uint32_t)(fm[j].hoff + b); }
+    if (tid < 16) {
+        const bool on = tid < nfeat;
+        int fb = 0, shj = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (j == tid) { fb = fbase[j]; shj = sh[j]; }
+        ftab[tid] = on ? fm[tid].wide_off : 0x7FFFFFFF; ftab[16 + tid] = fb; ftab[32 + tid] = shj; ftab[48 + tid] = on ? fm[tid].hoff - fm[tid].wide_off : 0;
     }
     int cj[16], sh4[16];
 #pragma unroll
@@ -513,13 +515,15 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
     for (int i = tid; i < total * wb; i += LV_THREADS) {
         const int ln = i / wb, b = i - ln * wb;
         const MtTree t = ti[nd_tree[ln]];
-        const uint32_t ws = w_slot[b];
-        const int shb = (int)(ws >> 24), s0 = (int)(ws & 0xFFFFFFu);
+        int j = 0;                                                  // feature of wide bin b: the last one whose first wide bin is <= b
+#pragma unroll
+        for (int q = 1; q < 16; ++q) j += (b >= ftab[q]) ? 1 : 0;
+        const int shb = ftab[32 + j], s0 = ftab[16 + j] + ((b - ftab[j]) << shb);
         long long tg = 0, th = 0;
         const HistBin* src = hist + (size_t)ln * spn + s0;
         for (int r2 = 0; r2 < (1 << shb); ++r2) { tg += src[r2].g; th += src[r2].h; }
         HistBin o; o.g = tg; o.h = th;
-        part[(((long long)t.k * c.gx + rb) * c.max_built + (c.mt_slot0 + ln - t.slot0)) * c.totbins + w_hoff[b]] = o;
+        part[(((long long)t.k * c.gx + rb) * c.max_built + (c.mt_slot0 + ln - t.slot0)) * c.totbins + ftab[48 + j] + b] = o;
     }
     if (ch == 0) {   // exact row counts of the built children (k_level_plan numbers the children of parent ei as child_first + 2 ei, + 1)
         for (int ln = tid; ln < total; ln += LV_THREADS) {

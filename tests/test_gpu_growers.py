@@ -45,14 +45,14 @@ VARIANTS = [("level", dict(RGBM_GROWER="level")),
             ("leafwise", dict(RGBM_GROWER="leafwise"))]
 
 
-def _three_way(X, n_codes, y, K, obj, cw=None, yv=None, **kw):
+def _three_way(X, n_codes, y, K, obj, cw=None, yv=None, variants=None, **kw):
     from oracle import oracle as O
     from repair import _native as N
     params = dict(objective=obj, num_class=max(K, 2), **kw)
     mo = O.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
     bo = mo.save()
     first = None
-    for name, env in VARIANTS:
+    for name, env in (variants or VARIANTS):
         with _env(**env):
             m = N.train(X, n_codes, y, K, y_value=yv, class_weight=cw, **params)
         assert m.save() == bo, "%s: differs from the oracle" % name
@@ -92,14 +92,16 @@ def test_binary_and_regression_three_way():
 
 
 def test_many_bins_force_histogram_groups():
-    """16 features x ~250 bins: one node's histogram is ~64 KB of LDS, so deep levels run several groups per pass."""
+    """16 features x ~250 bins: one node's histogram is ~64 KB of LDS, so every level beyond the first takes several launches
+    (windows of one built slot each) -- with the full LDS pool (a smaller one does not hold a node of this table at all)."""
     rng = np.random.default_rng(47)
     n = 60000
     z = rng.integers(0, 250, n)
     X = np.stack([((z * (j + 3) + rng.integers(0, 40, n)) % 250).astype(np.int32) for j in range(16)])
     X[3][rng.random(n) < 0.03] = -1
     y = ((z // 25 + (X[0] > 120)) % 6).astype(np.int32)
-    _three_way(np.ascontiguousarray(X), [250] * 16, y, 6, 1, cw=balanced_weights(y, 6), n_estimators=4, learning_rate=0.3, min_data_in_leaf=5)
+    _three_way(np.ascontiguousarray(X), [250] * 16, y, 6, 1, cw=balanced_weights(y, 6), variants=[VARIANTS[0], VARIANTS[1], VARIANTS[3]],
+               n_estimators=4, learning_rate=0.3, min_data_in_leaf=5)
 
 
 def test_two_chunks_with_many_bins():
