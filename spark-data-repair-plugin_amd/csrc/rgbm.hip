@@ -341,8 +341,9 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // Test / experiment switches, read from the environment at the start of every training call (tests flip them between calls); none
 // is needed in normal use.  RGBM_GROWER=leafwise|level, RGBM_TIMING=1 (host wall-clock of the phases to stderr), RGBM_LV_LDS=bytes
 // (shrinks the LDS pool of the level passes: more built-slot windows per level), RGBM_LV_BLOCKS / RGBM_MT_BLOCKS (row blocks per class
-// tree of the root / level passes), RGBM_MT_TREES (cap on the class trees per level-pass workgroup), RGBM_JOINT_ROOT=0.
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; bool joint_root = true; bool timing = false; };
+// tree of the root / level passes), RGBM_MT_TREES (cap on the class trees per level-pass workgroup), RGBM_MT_REP (LDS replication the
+// level passes are sized for, default 8), RGBM_JOINT_ROOT=0.
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -350,6 +351,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_LV_BLOCKS")) w.lv_blocks = atoll(e);
     if (const char* e = getenv("RGBM_MT_BLOCKS")) w.mt_blocks = atoll(e);
     if (const char* e = getenv("RGBM_MT_TREES")) w.mt_T = atoi(e);
+    if (const char* e = getenv("RGBM_MT_REP")) w.mt_rep = atoi(e);
     if (const char* e = getenv("RGBM_JOINT_ROOT")) w.joint_root = atoi(e) != 0;
     w.timing = getenv("RGBM_TIMING") != nullptr;
     return w;
@@ -647,7 +649,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 cap = std::min<long long>(cap, MT_MAX_NODES);
                 if (cap < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
                 const int win = (int)std::min<long long>(worst, cap);                    // built slots per launch
-                int T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(cap / win, MT_MAX_T), std::min<long long>(K, MT_MAX_RT / (2 * worst))));
+                // LDS left over after the T class trees' nodes becomes replication (2^s copies of every bin).  A batch of 64 built rows comes from
+                // one or two class trees (a wave walks them one after another) and, at the shallow levels, from one or two nodes: without
+                // replication its lanes pile up on a handful of addresses (measured at K = 64: 23-31 cycles per atomic instruction at
+                // replication 1 against 12.8 in the root pass).  So T is sized for `mt_rep` copies first; the records the extra workgroups
+                // re-read come out of the XCD's L2 (all class tree groups of a row block run on one XCD at the same time).
+                const long long rep_target = std::max(1, sw.mt_rep);
+                const long long t_nodes = std::max<long long>(win, cap / rep_target);
+                int T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(t_nodes / win, MT_MAX_T), std::min<long long>(K, MT_MAX_RT / (2 * worst))));
                 if (sw.mt_T >= 1) T = std::max(1, std::min(T, sw.mt_T));
                 const int G = (K + T - 1) / T;
                 if (ch == 0) G_first = G;
@@ -655,10 +664,17 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                     mt_plan[level].push_back(MtLaunch{ch, s0, win, (ch == 0 && s0 == 0) ? 1 : 0, T, G, 0});
             }
             const long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
-            long long gx = std::max<long long>(8, (256 / std::max(1, G_first)) / 8 * 8);
-            gx = std::max<long long>(gx, (gmin + 7) / 8 * 8);
+            // row blocks per class tree: a multiple of 8 (one XCD each); G * gx workgroups should fill whole rounds of 256 CUs (G = 24: 8 row
+            // blocks leave a quarter of the chip idle, 32 make three full rounds) without cutting the table into slivers
             const long long nwt = (N + MT_WT_ROWS - 1) / MT_WT_ROWS;
-            gx = std::min<long long>(gx, std::max<long long>(8, (nwt / MT_WAVES + 7) / 8 * 8));   // at least ~one wave tile per wave
+            const long long gx_lo = std::max<long long>(8, (gmin + 7) / 8 * 8), gx_hi = std::max<long long>(gx_lo, std::min<long long>(512, (nwt / (4 * MT_WAVES) + 7) / 8 * 8));
+            long long gx = gx_lo; double best = -1.0;
+            for (long long g = gx_lo; g <= gx_hi; g += 8) {
+                const long long tot = g * G_first, rounds = (tot + 255) / 256;
+                const double eff = (double)tot / (double)(rounds * 256) - 0.01 * (double)rounds;   // fuller rounds first, then fewer of them
+                if (eff > best + 1e-9) { best = eff; gx = g; }
+                if (tot >= 256 && (double)tot / (double)(rounds * 256) >= 0.97) break;
+            }
             if (sw.mt_blocks >= 1) gx = (sw.mt_blocks + 7) / 8 * 8;
             mt_gx[level] = (int)gx;
             for (auto& L : mt_plan[level]) L.gx = (int)gx;
@@ -720,12 +736,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             }
         }
         HIPCHK(hipFuncSetAttribute((const void*)k_level_root, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+#define RGBM_MT_ATTR(NCHR, BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
+                                HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
+        RGBM_MT_ATTR(0, false); RGBM_MT_ATTR(1, false); RGBM_MT_ATTR(2, false); RGBM_MT_ATTR(0, true); RGBM_MT_ATTR(1, true); RGBM_MT_ATTR(2, true);
+#undef RGBM_MT_ATTR
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
@@ -822,8 +836,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const dim3 grid((unsigned)L.G * (unsigned)L.gx), blk(LV_THREADS);
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
-#define RGBM_LAUNCH_MT(NCHR, BAG, INBAG) hipLaunchKernelGGL((k_level_mt<NCHR, BAG>), grid, blk, lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                            d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, l1)
+#define RGBM_LAUNCH_MT(NCHR, BAG, INBAG) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true>), grid, blk, lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, l1); \
+                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false>), grid, blk, lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, l1); } while (0)
                 if (use_bagging) { if (nchr == 1) RGBM_LAUNCH_MT(1, true, d_inbag.p); else if (nchr == 2) RGBM_LAUNCH_MT(2, true, d_inbag.p); else RGBM_LAUNCH_MT(0, true, d_inbag.p); }
                 else { if (nchr == 1) RGBM_LAUNCH_MT(1, false, nullptr); else if (nchr == 2) RGBM_LAUNCH_MT(2, false, nullptr); else RGBM_LAUNCH_MT(0, false, nullptr); }
 #undef RGBM_LAUNCH_MT

@@ -250,9 +250,10 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
     const TreeState st = state[k];
     if (!st.do_hist) return;
     const ChunkMeta cm = cmeta[ch];
-    HistBin* fast = reinterpret_cast<HistBin*>(smem);          // [fast_slots] replicated (g, h) sums
+    unsigned long long* fast_g = reinterpret_cast<unsigned long long*>(smem);   // [fast_slots] replicated gradient sums, then [fast_slots] hessian sums
+    unsigned long long* fast_h = fast_g + cm.fast_slots;                        // (separate arrays: a wave instruction of atomics spreads over all LDS banks)
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < cm.fast_slots; i += 256) { fast[i].g = 0; fast[i].h = 0; }
+    for (int i = tid; i < 2 * cm.fast_slots; i += 256) fast_g[i] = 0ull;
     __syncthreads();
 
     // per-feature slot bases / replication shifts of this chunk (uniform -> scalar registers)
@@ -286,8 +287,8 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
                         if (j < cm.nfeat) {
                             uint32_t bin = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                             int slot = fbase[j] + (int)(bin << fshift[j]) + (lane & ((1 << fshift[j]) - 1));
-                            atomicAdd(reinterpret_cast<unsigned long long*>(&fast[slot].g), gq);
-                            atomicAdd(reinterpret_cast<unsigned long long*>(&fast[slot].h), hq);
+                            atomicAdd(&fast_g[slot], gq);
+                            atomicAdd(&fast_h[slot], hq);
                         }
                     }
                 }
@@ -302,8 +303,8 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
         const int sh = fm[j].rep_shift;
         for (int b = tid; b < fm[j].nbins; b += 256) {
             long long tg = 0, th = 0;
-            const HistBin* src = fast + fm[j].fast_base + (b << sh);
-            for (int r2 = 0; r2 < (1 << sh); ++r2) { tg += src[r2].g; th += src[r2].h; }
+            const int s0 = fm[j].fast_base + (b << sh);
+            for (int r2 = 0; r2 < (1 << sh); ++r2) { tg += (long long)fast_g[s0 + r2]; th += (long long)fast_h[s0 + r2]; }
             HistBin* d = &dst[fm[j].hoff + b];
             if (tg) atomicAdd(reinterpret_cast<unsigned long long*>(&d->g), (unsigned long long)tg);
             if (th) atomicAdd(reinterpret_cast<unsigned long long*>(&d->h), (unsigned long long)th);

@@ -90,15 +90,24 @@ __device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS histogram layout of a chunk: a slot is a HistBin (16 B); feature j holds nbins << sh_j slots (bin-major, replica-minor) so
-// that lanes hitting the same bin spread over 2^sh_j addresses.  One uniform cap s for all features, limited per feature so that
-// nbins << sh <= 2048.
+// LDS histogram layout of a chunk: a slot is a pair of 8-byte sums; feature j holds nbins << sh_j slots (bin-major, replica-minor) so
+// that lanes hitting the same bin spread over 2^sh_j addresses.  The layout has ONE parameter q, the "slot exponent": every feature is
+// replicated until it holds about 2^q slots, sh_j = clamp(q - ceil_log2(nbins_j), 0, 5) -- few-bin features get many copies, many-bin
+// features few.  Same-address collisions inside one wave instruction of atomics serialise, and with 64 lanes on b bins x r copies the
+// expected pile-up is ~ 64 / (b r): equal slots per feature minimise the sum over the features for a given number of LDS bytes
+// (measured at K = 64, level 4: 20-30 cycles per atomic instruction with one uniform replication factor, 12.8 in the root pass).
+// q = 0 is the plain layout (one slot per bin).
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline int lv_cap_shift(int nbins) { int s = 0; while (s < 5 && (nbins << (s + 1)) <= 2048) ++s; return s; }
+constexpr int LV_MAX_Q = 11;
+__host__ __device__ inline int lv_shift(int nbins, int q) {
+    int l = 0; while ((1 << l) < nbins) ++l;          // ceil_log2(nbins)
+    int s = q - l;
+    return s < 0 ? 0 : (s > 5 ? 5 : s);
+}
 
-__host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int s) {
+__host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int q) {
     int t = 0;
-    for (int j = 0; j < nfeat; ++j) { int cs = lv_cap_shift(fm[j].nbins); t += fm[j].nbins << (s < cs ? s : cs); }
+    for (int j = 0; j < nfeat; ++j) t += fm[j].nbins << lv_shift(fm[j].nbins, q);
     return t;
 }
 
@@ -107,7 +116,7 @@ constexpr int LV_ROOT_FIXED = 256;
 // bytes k_level_mt needs besides the histogram: tree table | node -> tree map | route entries | built-row counters | per-wave rings
 // (record 16 B + (g, h) 8 B + slot 2 B per entry) | per-feature flush table | slack
 __host__ __device__ inline long long mt_fixed_bytes() {
-    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 256 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
+    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
            (long long)MT_WAVES * MT_RING * (16 + 8 + 2) + 256;
 }
 
@@ -152,19 +161,23 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
     const FeatMeta* fm = fmeta + cm.first_feat;
     const int tid = threadIdx.x, lane = tid & 63, nfeat = cm.nfeat;
     // layout: the largest uniform replication that fits
-    int s = 5;
+    int s = LV_MAX_Q;
     while (s > 0 && (long long)lv_slots(fm, nfeat, s) * 16 + LV_ROOT_FIXED > c.lds_bytes) --s;
     int sh[16], fbase[16], spn = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        if (j < nfeat) { const int cs = lv_cap_shift(fm[j].nbins); sh[j] = s < cs ? s : cs; fbase[j] = spn; spn += fm[j].nbins << sh[j]; }
+        if (j < nfeat) { sh[j] = lv_shift(fm[j].nbins, s); fbase[j] = spn; spn += fm[j].nbins << sh[j]; }
         else { sh[j] = 0; fbase[j] = 0; }
     }
-    HistBin* hist = reinterpret_cast<HistBin*>(smem);
-    for (int i = tid; i < spn; i += LV_THREADS) { hist[i].g = 0; hist[i].h = 0; }
-    int cj[16], sh4[16];
+    // gradient sums and hessian sums live in SEPARATE arrays of 8-byte slots: one wave instruction of 64-bit atomics then spreads over
+    // all 64 LDS banks (interleaved (g, h) pairs put every g on 16 of the 32 bank pairs: SQ_LDS_BANK_CONFLICT was 70 % of the LDS cycles)
+    unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* hist_h = hist_g + spn;
+    for (int i = tid; i < 2 * spn; i += LV_THREADS) hist_g[i] = 0ull;
+    int cj[16], sh3[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { sh4[j] = sh[j] + 4; cj[j] = (fbase[j] + (lane & ((1 << sh[j]) - 1))) * 16; }
+    for (int j = 0; j < 16; ++j) { sh3[j] = sh[j] + 3; cj[j] = (fbase[j] + (lane & ((1 << sh[j]) - 1))) * 8; }
+    const int hdelta = spn;      // elements between a slot's gradient sum and its hessian sum
     __syncthreads();
 
     const long long N = c.N;
@@ -197,10 +210,10 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
     auto accumulate = [&](bool on, const uint4& r, const float2& g) __attribute__((always_inline)) {
         if (on && (g.x != 0.0f || g.y != 0.0f)) {   // out-of-bag rows carry (0, 0)
             const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, c.sg), hq = (unsigned long long)fx_from_f32(g.y, c.sh);
-            unsigned char* hb = reinterpret_cast<unsigned char*>(hist);
+            unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g);
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#define LV_ATOM(j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh4[j])); \
-                     atomicAdd(p_, gq); atomicAdd(p_ + 1, hq); }
+#define LV_ATOM(j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[j])); \
+                     atomicAdd(p_, gq); atomicAdd(p_ + hdelta, hq); }
 #pragma unroll
             for (int j = 0; j < 16; ++j) if (j < nfeat) LV_ATOM(j);
 #undef LV_ATOM
@@ -222,13 +235,13 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
     // flush this workgroup's partial histogram (plain stores: no global atomics, no zeroing)
     HistBin* dst = part + (((long long)k * c.gx + bx) * c.max_built) * c.totbins;
     for (int j = 0; j < nfeat; ++j) {
-        const int shj = lv_cap_shift(fm[j].nbins) < s ? lv_cap_shift(fm[j].nbins) : s;
+        const int shj = lv_shift(fm[j].nbins, s);
         int fb = 0;
-        for (int q = 0; q < j; ++q) { const int cs = lv_cap_shift(fm[q].nbins); fb += fm[q].nbins << (s < cs ? s : cs); }
+        for (int q = 0; q < j; ++q) fb += fm[q].nbins << lv_shift(fm[q].nbins, s);
         for (int b = tid; b < fm[j].nbins; b += LV_THREADS) {
             long long tg = 0, th = 0;
-            const HistBin* src = hist + fb + (b << shj);
-            for (int r2 = 0; r2 < (1 << shj); ++r2) { tg += src[r2].g; th += src[r2].h; }
+            const unsigned long long* sg_ = hist_g + fb + (b << shj); const unsigned long long* sh_ = hist_h + fb + (b << shj);
+            for (int r2 = 0; r2 < (1 << shj); ++r2) { tg += (long long)sg_[r2]; th += (long long)sh_[r2]; }
             HistBin o; o.g = tg; o.h = th;
             dst[fm[j].hoff + b] = o;
         }
@@ -262,7 +275,8 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
 // ------------------------------------------------------------------------------------------------
 struct MtTree { int32_t base, nlev, rt_off, slot0, nb, live, child_first, k; };   // 32 B, one per class tree of the workgroup
 
-template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers), 0 = any number of chunks, the split byte is gathered */, bool BAG>
+template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers), 0 = any number of chunks, the split byte is gathered */, bool BAG,
+          bool ROUTE /* the first launch of a level: moves the rows to their children; later launches find the built rows by the final ids */>
 __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
                                                             const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                             int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
     const int nk = (c.K - k0) < c.mt_T ? (c.K - k0) : c.mt_T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ch = c.mt_ch;
-    const bool route = c.mt_route != 0;
+    constexpr bool route = ROUTE;
     const ChunkMeta cm = cmeta[ch];
     const FeatMeta* fm = fmeta + cm.first_feat;
     const int nfeat = cm.nfeat, wb = cm.wide_bins;
@@ -285,14 +299,15 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
     uint8_t* nd_tree = smem + MT_MAX_T * 32;                                                   // [MT_MAX_NODES] local node -> class tree of the workgroup
     int32_t* scal = reinterpret_cast<int32_t*>(nd_tree + MT_MAX_NODES);                        // [4] total built nodes, replication shift, slots per node, any live class tree
     int32_t* ftab = scal + 4;                                                                  // [4][16] per feature: first wide bin | first slot | replication shift | histogram offset
-    uint2* rt = reinterpret_cast<uint2*>(ftab + 64);                                           // [MT_MAX_RT] route entries / child -> slot entries
+    uint2* tpk = reinterpret_cast<uint2*>(ftab + 64);                                          // [MT_MAX_T + 2] what the row loop needs of a class tree: base | nlev << 8 | live << 31, rt_off | k << 16
+    uint2* rt = tpk + MT_MAX_T + 2;                                           // [MT_MAX_RT] route entries / child -> slot entries
     int32_t* cnt = reinterpret_cast<int32_t*>(rt + MT_MAX_RT);                                 // [MT_MAX_NODES][MT_CNT_REP]
     uint4* ring_rec_all = reinterpret_cast<uint4*>(cnt + MT_MAX_NODES * MT_CNT_REP);           // [waves][MT_RING]
     uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec_all + MT_WAVES * MT_RING);          // [waves][MT_RING]
     uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + MT_WAVES * MT_RING);     // [waves][MT_RING]
     size_t off = reinterpret_cast<unsigned char*>(ring_li_all + MT_WAVES * MT_RING) - smem;
     off = (off + 15) & ~(size_t)15;
-    HistBin* hist = reinterpret_cast<HistBin*>(smem + off);
+    unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem + off);     // [total][spn] gradient sums, then [total][spn] hessian sums (see k_level_root)
     const long long avail = (long long)c.lds_bytes - (long long)off;
 
     // ---- the class trees of this workgroup and their built slots inside this launch's window
@@ -319,9 +334,11 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
         const bool ok = total <= MT_MAX_NODES && rt_total <= MT_MAX_RT;     // the host sizes T for the worst case: always true
         if (!ok) { t.live = 0; t.nb = 0; t.nlev = 0; }
         if (lane < nk) ti[lane] = t;
+        tpk[lane] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
+        if (lane < 2) tpk[64 + lane] = make_uint2(0u, 0u);
         if (lane == 0) {
             // replication: the largest uniform shift whose histograms fit
-            int s = 5;
+            int s = LV_MAX_Q;
             const int tot = ok ? total : 0;
             while (s > 0 && (long long)tot * lv_slots(fm, nfeat, s) * 16 > avail) --s;
             scal[0] = tot; scal[1] = s; scal[2] = lv_slots(fm, nfeat, s); scal[3] = (ok && livem != 0ull) ? 1 : 0;
@@ -357,13 +374,14 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
         for (int i = tid; i < t.nb; i += LV_THREADS) nd_tree[t.slot0 + i] = (uint8_t)kk;
     }
     for (int i = tid; i < total * MT_CNT_REP; i += LV_THREADS) cnt[i] = 0;
-    for (int i = tid; i < total * spn; i += LV_THREADS) { hist[i].g = 0; hist[i].h = 0; }
+    unsigned long long* hist_h = hist_g + (size_t)total * spn;
+    for (int i = tid; i < 2 * total * spn; i += LV_THREADS) hist_g[i] = 0ull;
     int sh[16], fbase[16];
     {
         int o = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (j < nfeat) { const int cs = lv_cap_shift(fm[j].nbins); sh[j] = s < cs ? s : cs; fbase[j] = o; o += fm[j].nbins << sh[j]; }
+            if (j < nfeat) { sh[j] = lv_shift(fm[j].nbins, s); fbase[j] = o; o += fm[j].nbins << sh[j]; }
             else { sh[j] = 0; fbase[j] = 0; }
         }
     }
@@ -374,9 +392,10 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
         for (int j = 0; j < 16; ++j) if (j == tid) { fb = fbase[j]; shj = sh[j]; }
         ftab[tid] = on ? fm[tid].wide_off : 0x7FFFFFFF; ftab[16 + tid] = fb; ftab[32 + tid] = shj; ftab[48 + tid] = on ? fm[tid].hoff - fm[tid].wide_off : 0;
     }
-    int cj[16], sh4[16];
+    int cj[16], sh3[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { sh4[j] = sh[j] + 4; cj[j] = (fbase[j] + (lane & ((1 << sh[j]) - 1))) * 16; }
+    for (int j = 0; j < 16; ++j) { sh3[j] = sh[j] + 3; cj[j] = (fbase[j] + (lane & ((1 << sh[j]) - 1))) * 8; }
+    const int hdelta = total * spn;
     __syncthreads();
 
     uint4* ring_rec = ring_rec_all + wave * MT_RING;
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
     uint16_t* ring_li = ring_li_all + wave * MT_RING;
     int r_head = 0, r_cnt = 0;                                   // wave-uniform
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const unsigned spn16 = (unsigned)spn * 16u;
+    const unsigned spn8 = (unsigned)spn * 8u;
 
     // one FULL (or final, partial) wave of histogram updates from the ring
     auto run_batch = [&](int nb) __attribute__((always_inline)) {
@@ -396,10 +415,14 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
         if (on) {
             const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), c.sg), hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), c.sh);
             if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], 1);
-            unsigned char* hb = reinterpret_cast<unsigned char*>(hist) + li * spn16;
+            unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g) + li * spn8;
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#define MT_ATOM(j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh4[j])); \
-                     atomicAdd(p_, gq); atomicAdd(p_ + 1, hq); }
+#if defined(MT_DBG) && MT_DBG == 1   // timing experiment (make EXTRA=-DMT_DBG=1): everything but the LDS atomics; results are wrong
+#define MT_ATOM(j) asm volatile("" :: "v"(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[j])), "v"(gq), "v"(hq), "v"(hdelta))
+#else
+#define MT_ATOM(j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[j])); \
+                     atomicAdd(p_, gq); atomicAdd(p_ + hdelta, hq); }
+#endif
             if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
                 MT_ATOM(0); MT_ATOM(1); MT_ATOM(2); MT_ATOM(3); MT_ATOM(4); MT_ATOM(5); MT_ATOM(6); MT_ATOM(7);
                 MT_ATOM(8); MT_ATOM(9); MT_ATOM(10); MT_ATOM(11); MT_ATOM(12); MT_ATOM(13); MT_ATOM(14);
@@ -447,34 +470,51 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
                 }
             } else n4 = 0xFFFFFFFFu;
         };
+        // Software pipeline over the class trees, three stages deep, so that no row step waits for a memory or LDS round trip
+        // (the LDS queue is full of other waves' atomics: a dependent lookup inside the row loop cost hundreds of cycles):
+        //   stage A (tree kk + 2): global loads of the node ids and (g, h); LDS read of the tree's packed table entry
+        //   stage B (tree kk + 1): node ids have arrived -> table indices -> LDS reads of the four route entries
+        //   stage C (tree kk)    : route, append the built rows to the ring, run the batches
+        uint2 tq_a = tpk[0], tq_b = tpk[1];
         fetch_tree(0, n4_a, ga0, ga1);
         fetch_tree(1, n4_b, gb0, gb1);
-        for (int kk = 0; kk < nk; ++kk) {
-            const uint32_t n4 = n4_a; const float4 g0 = ga0, g1 = ga1;
-            n4_a = n4_b; ga0 = gb0; ga1 = gb1;
-            fetch_tree(kk + 2, n4_b, gb0, gb1);
-            const MtTree t = ti[kk];
-            if (!t.live) continue;                                   // uniform
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(t.base), nlev = (uint32_t)__builtin_amdgcn_readfirstlane(t.nlev);
-            const int rt_off = __builtin_amdgcn_readfirstlane(t.rt_off);
-            uint32_t idx[4]; bool in[4]; bool any_in = false;
+        uint2 e_a[4]; uint32_t in_a = 0u;
+        auto lookup = [&](uint32_t n4, const uint2 tq, uint2 (&e)[4], uint32_t& inm) __attribute__((always_inline)) {
+            const uint32_t tq0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tq.x), tq1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tq.y);
+            const uint32_t base = tq0 & 0xFFu, nlev = (tq0 >> 8) & 0x1FFu, rt_off = tq1 & 0xFFFFu;
+            inm = 0u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                idx[j] = ((n4 >> (8 * j)) & 0xFFu) - base;
-                in[j] = idx[j] < nlev && ((rowmask >> j) & 1u);
-                any_in |= in[j];
+                const uint32_t idx = ((n4 >> (8 * j)) & 0xFFu) - base;
+                const bool in = (tq0 >> 31) != 0u && idx < nlev && ((rowmask >> j) & 1u);
+                inm |= in ? (1u << j) : 0u;
+                e[j] = rt[rt_off + (in ? idx : 0u)];
             }
-            if (__ballot(any_in) == 0ull) continue;                  // no row of this wave tile sits in a node of the level
+        };
+        lookup(n4_a, tq_a, e_a, in_a);
+        for (int kk = 0; kk < nk; ++kk) {
+            // ---- rotate the pipeline
+            const uint32_t n4 = n4_a; const float4 g0 = ga0, g1 = ga1;
+            uint2 e[4]; const uint32_t inm = in_a; const uint2 tq = tq_a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = e_a[j];
+            n4_a = n4_b; ga0 = gb0; ga1 = gb1; tq_a = tq_b;
+            fetch_tree(kk + 2, n4_b, gb0, gb1);                     // stage A
+            tq_b = tpk[kk + 2];
+            lookup(n4_a, tq_a, e_a, in_a);                          // stage B (reads tpk / rt only: tables nobody writes during the row loop)
+            // ---- stage C
+            if (__ballot(inm != 0u) == 0ull) continue;               // no row of this wave tile sits in a node of the level (or the tree is finished)
             uint32_t out4 = n4;
             const float gg[4] = {g0.x, g0.z, g1.x, g1.z}, hh[4] = {g0.y, g0.w, g1.y, g1.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint2 e = rt[rt_off + (in[j] ? (int)idx[j] : 0)];
+                const bool in = ((inm >> j) & 1u) != 0u;
                 unsigned li;
                 bool built;
-                if (route) {
-                    const bool expd = in[j] && (e.x & (1u << 24)) != 0u;
-                    const unsigned f = e.x & 0xFFu;
+                if (ROUTE) {
+                    const uint32_t ex = e[j].x, ey = e[j].y;
+                    const bool expd = in && (ex & (1u << 24)) != 0u;
+                    const unsigned f = ex & 0xFFu;
                     unsigned bin;
                     if (NCHR == 0) {
                         bin = 0u;
@@ -486,16 +526,21 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
                         const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
                         bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
                     }
-                    const bool left = (bin == ((e.x >> 16) & 0xFFu)) ? ((e.x >> 25) & 1u) != 0u : (bin < ((e.x >> 8) & 0xFFu));
-                    const unsigned sel = left ? e.y : (e.y >> 8);          // child in bits 0..7, workgroup-local built slot in bits 16..23
-                    if (expd) out4 = (out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j));
+                    // left = (bin == nan bin) ? default-left : (bin < theta + 1), without a branch
+                    const uint32_t is_nan = (bin == ((ex >> 16) & 0xFFu)) ? 1u : 0u, lt = (bin < ((ex >> 8) & 0xFFu)) ? 1u : 0u;
+                    const uint32_t left = (is_nan & (ex >> 25)) | ((is_nan ^ 1u) & lt);
+                    const unsigned sel = (left & 1u) ? ey : (ey >> 8);     // child in bits 0..7, workgroup-local built slot in bits 16..23
+                    out4 = expd ? ((out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j))) : out4;
                     li = (sel >> 16) & 0xFFu;
                     built = expd && li != 0xFFu;
                 } else {
-                    li = e.y & 0xFFu;
-                    built = in[j] && e.x != 0u;
+                    li = e[j].y & 0xFFu;
+                    built = in && e[j].x != 0u;
                 }
                 if (BAG) built = built && ((bagmask >> j) & 1u);
+#if defined(MT_DBG) && MT_DBG == 2   // timing experiment: routing only, nothing is appended or accumulated
+                built = built && c.lds_bytes < 0;
+#endif
                 const unsigned long long m = __ballot(built);
                 if (m != 0ull) {                                      // uniform
                     if (built) {
@@ -506,7 +551,7 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
                     if (r_cnt >= 64) run_batch(64);
                 }
             }
-            if (route && out4 != n4) *reinterpret_cast<uint32_t*>(node + (long long)t.k * NS + row0) = out4;
+            if (ROUTE && out4 != n4) *reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0) = out4;
         }
     }
     while (r_cnt > 0) run_batch(r_cnt < 64 ? r_cnt : 64);
@@ -520,8 +565,8 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
         for (int q = 1; q < 16; ++q) j += (b >= ftab[q]) ? 1 : 0;
         const int shb = ftab[32 + j], s0 = ftab[16 + j] + ((b - ftab[j]) << shb);
         long long tg = 0, th = 0;
-        const HistBin* src = hist + (size_t)ln * spn + s0;
-        for (int r2 = 0; r2 < (1 << shb); ++r2) { tg += src[r2].g; th += src[r2].h; }
+        const unsigned long long* sg_ = hist_g + (size_t)ln * spn + s0; const unsigned long long* sh_ = hist_h + (size_t)ln * spn + s0;
+        for (int r2 = 0; r2 < (1 << shb); ++r2) { tg += (long long)sg_[r2]; th += (long long)sh_[r2]; }
         HistBin o; o.g = tg; o.h = th;
         part[(((long long)t.k * c.gx + rb) * c.max_built + (c.mt_slot0 + ln - t.slot0)) * c.totbins + ftab[48 + j] + b] = o;
     }
