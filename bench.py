@@ -130,14 +130,15 @@ def _spawn_ranks(a):
 
 
 def _load_traffic(config, world):
-    """Measured HBM bytes per launch of the histogram kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950
-    corrections applied as MI355X_MICROARCH.md prescribes): the counters cannot be read from inside the process, so the number comes
-    from the committed profile of the same command (profiles/traffic.json says which run)."""
+    """Measured HBM bytes per launch of the two histogram kernel classes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
+    calibrated on a kernel of known traffic as MI355X_MICROARCH.md prescribes): the counters cannot be read from inside the process,
+    so the numbers come from the committed profile of the same workload over ALL its target models (tools/make_traffic_json.py;
+    profiles/traffic.json says which run) -- the same set of launches the algorithmic bytes next to them describe."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         e = t.get(config)
-        if e and world == 1:
+        if e and "classes" in e and world == 1:
             return e
     except Exception:  # noqa: BLE001
         pass
@@ -268,6 +269,11 @@ def main():
                 row_tab = None
                 row_sharding_note = "disabled: the row-sharded warm-up model differed from the single-device one (or failed)"
 
+    def plan_of(row_sharding):
+        costs = [(t, (1 if int(cards[t]) <= 2 else int(cards[t])) * float(np.sum(label_counts[t])) * 1e-6) for t in targets]
+        pl = rdist.plan(costs, world, row_sharding, force=a.force_row_sharding)
+        return {k: ([round(x, 1) for x in v] if k == "target_sharded_units_per_rank" else (round(v, 2) if isinstance(v, float) else v)) for k, v in pl.items()}
+
     def timed_job(n_estimators, want_stats=False, concurrency=None):
         """One complete job of `n_estimators` boosting iterations per target model, bracketed as the contract says."""
         params = dict(BASE_PARAMS, n_estimators=n_estimators)
@@ -300,8 +306,8 @@ def main():
     def agg(key, r=res_roof):
         return rdist.sum_over_ranks(sum(s.get(key, 0) for s in r["stats"]))
     hist_ms_all, hist_bytes_all, launches_all = agg("hist_ms"), agg("hist_bytes"), agg("hist_launches")
-    route_ms_all, route_launches_all = agg("route_ms"), agg("route_launches")
     root_ms = sum(s["root_ms"] for s in res_roof["stats"]); root_bytes = sum(s["root_rows"] * (cols - 1 + 8) for s in res_roof["stats"])
+    n_root = rdist.sum_over_ranks(roof_steps * len(res_roof["stats"]))       # one root launch per boosting iteration and trained model (nchunk = 1 workloads)
     train_s = rdist.max_over_ranks(res["times"]["train"]); infer_s = rdist.max_over_ranks(res["times"]["infer"])
 
     out = None
@@ -314,12 +320,23 @@ def main():
             idx = np.searchsorted(dirty_pos, pos)
             fixed += int((labels[i][idx] == truth).sum())
         achieved = hist_bytes_all / max(hist_ms_all, 1e-9) * 1e-6
-        with_route = hist_bytes_all / max(hist_ms_all + route_ms_all, 1e-9) * 1e-6
         traffic = _load_traffic(a.config, world)
+        # the two kernel classes of the histogram build, each with its own algorithmic bytes, launch time and (from the committed PMC
+        # profile of the same target set) HBM-side bytes per launch
+        classes = {}
+        n_root_l = max(1, int(round(n_root)))
+        for name, ms, nbytes, nl in (("root", root_ms, root_bytes, n_root_l), ("level", hist_ms_all - root_ms, hist_bytes_all - root_bytes, max(1, int(launches_all) - n_root_l))):
+            c = {"kernel": "rg::k_level_root" if name == "root" else "rg::k_level_mt", "launches": int(nl), "avg_launch_us": ms * 1e3 / nl, "alg_bytes_per_launch": nbytes / nl,
+                 "achieved": nbytes / max(ms, 1e-9) * 1e-6, "frac": nbytes / max(ms, 1e-9) * 1e-6 / HBM_PEAK_GBS}
+            if traffic and name in traffic["classes"]:
+                tc = traffic["classes"][name]
+                c["traffic"] = {"fetch_bytes_per_launch": tc["fetch_bytes_per_launch"], "write_bytes_per_launch": tc["write_bytes_per_launch"],
+                                "ratio_to_algorithmic": tc["bytes_per_launch"] / max(nbytes / nl, 1e-9)}
+            classes[name] = c
         out = {
             "metric": "repaired cells/sec", "value": n_cells / elapsed, "unit": "cells/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed_k * 1e3 / a.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64 fixed-point histograms / f64 scores",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 gradients (LightGBM's score_t), exact int64 fixed-point histogram sums, f64 scores",
             "data": "synthetic",
             "value_basis": "complete job: n_estimators=%d per target model, %.2f s" % (job_steps, elapsed) +
                            ("" if job_steps == REF_N_ESTIMATORS else " (NOT the reference's 300-iteration job: --no-full-job)"),
@@ -329,22 +346,22 @@ def main():
                        "name": a.config, "rows": rows, "cols": cols, "targets": len(targets), "dirty_rows": int(dirty_rows.shape[1]),
                        "error_cells": n_cells,
                        "parallelism": ("hybrid x%d: targets %s row-sharded over all ranks (RCCL int64 all-reduce of histograms), rest target-sharded"
-                                       % (world, res["row_sharded_targets"])) if res["row_sharded_targets"] else "target-sharded x%d" % world},
+                                       % (world, res["row_sharded_targets"])) if res["row_sharded_targets"] else "target-sharded x%d" % world,
+                       # the schedule in cost units (class trees x training rows / 1e6), checkable without hardware: repair.dist.plan
+                       "plan": plan_of(row_tab is not None or a.force_row_sharding)},
             "steps_region_sec": elapsed_k, "job_steps": job_steps, "elapsed_sec": elapsed,
             "model_train_sec": train_s, "repair_sec": infer_s,
             "repair_accuracy_vs_clean": fixed / max(n_cells, 1),
             "upload": {"bytes": int(upload_bytes), "sec": t_up, "GBps": upload_bytes / max(t_up, 1e-9) * 1e-9, "generate_sec": t_gen},
             "roofline": {"bound": "hbm",
-                         "kernel": "rg::k_level_pass<ROOT> + rg::k_level_pass<STREAM> (histogram build of the level grower; rg::k_hist for the leaf-wise grower)",
+                         "kernel": "rg::k_level_root + rg::k_level_mt (histogram build of the level grower; a level pass also routes the rows of its level: DataPartition::Split is not a separate kernel)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                         "classes": classes,
                          "measured_on": "sequential pass (one target model at a time) of %d boosting iterations of the same job, %.2f s; HIP events per launch" % (roof_steps, elapsed_roof),
                          "launches": int(launches_all), "avg_launch_us": hist_ms_all * 1e3 / max(launches_all, 1),
                          "alg_bytes_per_launch": hist_bytes_all / max(launches_all, 1),
-                         "root_scan_GBps_rank0": root_bytes / max(root_ms, 1e-9) * 1e-6,
-                         # the row routing of a level (DataPartition::Split) runs in its own kernel in split mode; charged to the histogram
-                         # build as well, the path moves its algorithmic bytes at:
-                         "with_route": {"achieved": with_route, "frac": with_route / HBM_PEAK_GBS, "route_ms": route_ms_all, "route_launches": int(route_launches_all)}},
+                         "root_scan_GBps_rank0": root_bytes / max(root_ms, 1e-9) * 1e-6},
         }
         if row_sharding_note:
             out["config"]["row_sharding"] = row_sharding_note

@@ -174,24 +174,29 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
             stats.append(st)
         return res.save()
 
-    for t, _ in big:                      # collective: same order on every rank, identical model everywhere
-        shared[t] = one(t, row_table, engine.train_row_sharded)
-    # This rank's own targets train CONCURRENTLY: every training call owns a HIP stream and ctypes releases the GIL.  A few-class
-    # target is a chain of small dependent kernels (plan / split-find / replay at 10-40 us around 0.1 ms passes) that leaves the
-    # GPU idle two thirds of the time; next to a many-class target those kernels fill the gaps between its passes.  Largest first
-    # (LPT), a bounded number in flight (device memory: ~26 B per row and class tree each).  The models do not depend on it.
-    conc = _train_concurrency(engine, train_table, [c for c in costs if c[0] in set(mine)], train_concurrency)
-    if conc > 1 and len(mine) > 1:
+    # This rank's own (target-sharded) models train CONCURRENTLY, with each other and with the row-sharded ones: every training call
+    # owns a HIP stream and ctypes releases the GIL.  A few-class target is a chain of small dependent kernels (plan / split-find /
+    # replay at 10-40 us around 0.1 ms passes) that leaves the GPU idle two thirds of the time; next to a many-class target those
+    # kernels fill the gaps between its passes.  Largest first (LPT), a bounded number in flight (device memory: ~26 B per row and
+    # class tree each).  The row-sharded targets stay on THIS thread, one after another in the same order on every rank (the
+    # communicator belongs to the thread, and one collective sequence per process cannot dead-lock against another).  The models do
+    # not depend on any of this.
+    conc = _train_concurrency(engine, train_table, [c for c in costs if c[0] in set(mine)] + list(big), train_concurrency)
+    pool, futs = None, {}
+    if conc > 1 and len(mine) + len(big) > 1 and mine:
         from concurrent.futures import ThreadPoolExecutor
         cost_of = dict(costs)
         order = sorted(mine, key=lambda t: -cost_of[t])
-        with ThreadPoolExecutor(max_workers=conc) as pool:
-            futs = {t: pool.submit(one, t, train_tables.get(t, train_table), engine.train) for t in order}
-            for t in mine:
-                blobs[t] = futs[t].result()
-    else:
+        pool = ThreadPoolExecutor(max_workers=max(1, conc - (1 if big else 0)))
+        futs = {t: pool.submit(one, t, train_tables.get(t, train_table), engine.train) for t in order}
+    try:
+        for t, _ in big:                  # collective: same order on every rank, identical model everywhere
+            shared[t] = one(t, row_table, engine.train_row_sharded)
         for t in mine:
-            blobs[t] = one(t, train_tables.get(t, train_table), engine.train)
+            blobs[t] = futs[t].result() if pool is not None else one(t, train_tables.get(t, train_table), engine.train)
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
     t_train = time.perf_counter() - t0
     # C1: all-gather of the serialised models (Spark broadcast, model.py:1069)
     t0 = time.perf_counter()

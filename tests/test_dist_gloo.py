@@ -81,9 +81,19 @@ def test_two_rank_gloo_job_equals_single_process():
 def test_split_targets_rule():
     from repair import dist
     costs = [(0, 1), (1, 3), (2, 4), (3, 6), (4, 8), (5, 12), (6, 16), (7, 24), (8, 32), (9, 48), (10, 64)]
-    big, small = dist.split_targets(costs, 8, True)            # fair share 218/8, threshold half of it
-    assert [t for t, _ in big] == [6, 7, 8, 9, 10] and [t for t, _ in small] == [0, 1, 2, 3, 4, 5]
+    big, small = dist.split_targets(costs, 8, True)            # fair share 218/8, threshold a quarter of it (6.8 units)
+    assert [t for t, _ in big] == [4, 5, 6, 7, 8, 9, 10] and [t for t, _ in small] == [0, 1, 2, 3]
     assert dist.split_targets(costs, 8, False) == ([], costs) and dist.split_targets(costs, 1, True) == ([], costs)
+    # the north-star job (100M x 32, targets c0..c7: 1 + 3 + 4 + 6 + 8 + 12 + 16 + 24 = 74 class trees) on 8 ranks: only the binary
+    # target stays whole, the critical path is 73 / 8 + 1 units = 7.3x before collective and tail costs (>= 6x must be
+    # reachable on paper)
+    north = [(0, 1), (1, 3), (2, 4), (3, 6), (4, 8), (5, 12), (6, 16), (7, 24)]
+    pl = dist.plan(north, 8, True)
+    assert pl["row_sharded"] == [1, 2, 3, 4, 5, 6, 7] and abs(pl["critical_path_units"] - (73 / 8 + 1)) < 1e-9 and pl["ideal_speedup"] > 7.2
+    assert dist.plan(north, 1, True)["ideal_speedup"] == 1.0
+    ten = [(c, k if k > 2 else 1) for c, k in enumerate([2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 2, 3, 4, 6, 8])]     # the 10M x 16 job: 240 class trees
+    for ws in (2, 4, 8):
+        assert dist.plan(ten, ws, True)["ideal_speedup"] > 0.9 * ws
 
 
 def test_two_rank_gloo_hybrid_job_equals_single_process():

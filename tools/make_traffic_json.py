@@ -1,52 +1,91 @@
-"""profiles/traffic.json + profiles/<tag>_hbm_traffic_pmc.txt from the two rocprofv3 --pmc summaries of tools/probe.py
-(tools/pmc_summary.py output: FETCH_SIZE and WRITE_SIZE passes, KB as rocprofv3 reports them).
+"""profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes as MI355X_MICROARCH.md prescribes) over
 
-    python tools/make_traffic_json.py gpurun_out/r02q r02q
+    python tools/probe.py --iters 1 --targets 0,1,...,15 --stats 0        (every target model of the 10M x 16 workload, one after another)
 
-FETCH_SIZE is doubled (gfx950: wide coalesced reads are tallied at half their bytes; calibrated on k_grad_mc, whose reads are
-known exactly); WRITE_SIZE is taken as reported."""
-import json, os, re, sys
-src, tag = sys.argv[1], sys.argv[2]
+    python tools/make_traffic_json.py <fetch_dir> <write_dir> <tag> [--rows 10000000] [--cols 16]
+
+Per kernel class of the histogram build -- root = rg::k_level_root, level = rg::k_level_mt -- the HBM-side bytes per launch, summed
+over the SAME set of launches the bench line's algorithmic bytes describe (all 16 target models).  Both counters are calibrated on
+rg::k_grad_mc of the same run, whose reads (8 B of score per (row, class tree) + 4 B of label per row) and writes (8 B of (g, h) per
+(training row, class tree) + 1 B of node id per (row, class tree)) are known exactly: rocprofv3 reports KB, and on gfx950 tallies wide
+coalesced reads at half their bytes (the guide's x2), which the calibration factor absorbs.  bench.py puts these next to the
+algorithmic bytes it measures itself (`roofline.classes.<class>.traffic`)."""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N, K, F = 10_000_000, 64, 15
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spark-data-repair-plugin_amd"))
 
 
-def per_dispatch(path, counter):
-    root, levels = None, []
-    for line in open(path):
-        m = re.match(r"^(\d+) (.*) %s ([0-9.e+]+)$" % counter, line.strip())
-        if not m:
-            continue
-        name, v = m.group(2), float(m.group(3)) * 1024.0
-        is_root = "k_level_pass<true" in name
-        if is_root:
-            root = v
-        elif "k_level_pass<false" in name:
-            levels.append(v)
-    return root, levels
-
-
-fr, fl = per_dispatch(os.path.join(src, "pmc_fetch_summary.txt"), "FETCH_SIZE")
-wr, wl = per_dispatch(os.path.join(src, "pmc_write_summary.txt"), "WRITE_SIZE")
-fr, fl = fr * 2, [v * 2 for v in fl]
-launches = 1 + len(fl)
-out = {"10m16": {
-    "source": "profiles/%s_hbm_traffic_pmc.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over python tools/probe.py --iters 1 "
-              "--targets 10 (the K=64 target of the 10M x 16 workload, one boosting iteration = 1 root + %d level launches, each covering the 64 class trees); FETCH_SIZE x2 "
-              "(gfx950: wide coalesced reads are tallied at half their bytes; calibrated on k_grad_mc), WRITE_SIZE as reported (uncalibrated)" % (tag, len(fl)),
-    "bytes_per_launch": (fr + wr + sum(fl) + sum(wl)) / launches,
-    "root_pass": {"fetch_bytes": fr, "write_bytes": wr, "algorithmic_bytes": float(N) * K * (F + 8) * 0.99},
-    "level_pass_stream": {"fetch_bytes_avg": sum(fl) / len(fl), "write_bytes_avg": sum(wl) / len(wl), "fetch_bytes_per_launch": fl,
-                          "note": "gradient-only layout: a level pass streams node id (1 B) + g (4 B) of every row of every class tree = 3.2 GB whatever the share of built "
-                                  "rows; the rest is the bin records the batches re-read past L2"}}}
-json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-with open(os.path.join(ROOT, "profiles", "%s_hbm_traffic_pmc.txt" % tag), "w") as f:
-    f.write("# %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; KB as reported) -- python tools/probe.py --iters 1 --targets 10 --stats 0\n" % tag)
-    f.write("# K=64 target of the 10M x 16 workload, split level pass (k_level_route + k_level_pass<STREAM, GONLY>), one boosting iteration\n")
-    for name in ("pmc_fetch_summary.txt", "pmc_write_summary.txt"):
-        for line in open(os.path.join(src, name)):
-            if line.startswith("#") or not line.strip():
+def load(dirname, counter):
+    """{kernel class: [sum of counter over dispatches, dispatches]} in KB as rocprofv3 reports them."""
+    out = {}
+    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = {}
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
                 continue
-            if re.match(r"^\d+ ", line) or any(k in line for k in ("k_level_pass", "k_level_route", "k_grad_mc", "k_level_final")):
-                f.write(line)
-print(json.dumps(out, indent=1)[:1500])
+            per_dispatch[(r["Dispatch_Id"], r["Kernel_Name"])] = per_dispatch.get((r["Dispatch_Id"], r["Kernel_Name"]), 0.0) + float(r["Counter_Value"])
+        for (_, name), v in per_dispatch.items():
+            cls = "root" if "k_level_root" in name else "level" if "k_level_mt" in name else "grad_mc" if "k_grad_mc(" in name else None
+            if cls:
+                e = out.setdefault(cls, [0.0, 0])
+                e[0] += v; e[1] += 1
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir"); ap.add_argument("write_dir"); ap.add_argument("tag")
+    ap.add_argument("--rows", type=int, default=10_000_000); ap.add_argument("--cols", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=2, help="training calls per target in the profiled command (tools/probe.py runs every target twice)")
+    ap.add_argument("--iters", type=int, default=1)
+    a = ap.parse_args()
+    from repair.synth import CARDS
+    cards = [CARDS[c % len(CARDS)] for c in range(a.cols)]
+    fetch, write = load(a.fetch_dir, "FETCH_SIZE"), load(a.write_dir, "WRITE_SIZE")
+    # calibration on k_grad_mc: the multiclass targets with 16 <= K <= 112 use it, one launch per boosting iteration
+    ks = [k for k in cards if 16 <= k <= 112]
+    n_launch = len(ks) * a.reps * a.iters
+    exp_read = sum(8.0 * k * a.rows + 4.0 * a.rows for k in ks) * a.reps * a.iters
+    exp_write = sum(8.0 * k * a.rows * 0.99 + 1.0 * k * a.rows for k in ks) * a.reps * a.iters
+    assert fetch["grad_mc"][1] == n_launch == write["grad_mc"][1], ("k_grad_mc launches", fetch.get("grad_mc"), n_launch)
+    f_cal = exp_read / (fetch["grad_mc"][0] * 1024.0)
+    w_cal = exp_write / (write["grad_mc"][0] * 1024.0)
+    out = {"source": "profiles/%s_hbm_traffic_pmc.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over python tools/probe.py --iters %d "
+                     "--targets 0..%d --stats 0 (every target model of the %dM x %d workload, one after another); counters x calibration factor (FETCH %.3f, WRITE %.3f: known "
+                     "reads / writes of rg::k_grad_mc in the same run)" % (a.tag, a.iters, a.cols - 1, a.rows // 1_000_000, a.cols, f_cal, w_cal),
+           "calibration": {"fetch_factor": f_cal, "write_factor": w_cal, "kernel": "rg::k_grad_mc", "launches": n_launch}, "classes": {}}
+    for cls in ("root", "level"):
+        fb, fl = fetch[cls][0] * 1024.0 * f_cal, fetch[cls][1]
+        wb, wl = write[cls][0] * 1024.0 * w_cal, write[cls][1]
+        assert fl == wl
+        out["classes"][cls] = {"launches": fl, "fetch_bytes_per_launch": fb / fl, "write_bytes_per_launch": wb / wl, "bytes_per_launch": (fb + wb) / fl}
+    tot_l = sum(c["launches"] for c in out["classes"].values())
+    out["bytes_per_launch"] = sum(c["bytes_per_launch"] * c["launches"] for c in out["classes"].values()) / tot_l
+    name = "%dm%d" % (a.rows // 1_000_000, a.cols)
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    allj = {}
+    if os.path.exists(path):
+        try:
+            allj = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            allj = {}
+    allj = {k: v for k, v in allj.items() if isinstance(v, dict) and "classes" in v}   # drop entries of the old format
+    allj[name] = out
+    json.dump(allj, open(path, "w"), indent=1)
+    with open(os.path.join(ROOT, "profiles", "%s_hbm_traffic_pmc.txt" % a.tag), "w") as f:
+        f.write("# %s\n" % out["source"])
+        for label, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+            for cls, (v, n) in sorted(d.items()):
+                f.write("%-10s %-8s launches=%-5d sum_KB=%.6g per_launch_KB=%.6g\n" % (label, cls, n, v, v / max(n, 1)))
+        f.write(json.dumps(out, indent=1) + "\n")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
