@@ -21,7 +21,8 @@ import pandas as pd
 from repair import session
 from repair.costs import UpdateCostFunction
 from repair.encode import is_integral_column, is_numeric_column
-from repair.errors import ConstraintErrorDetector, ErrorDetector, ErrorModel, RegExErrorDetector, parse_constraint, load_constraints
+from repair.errors import (ConstraintErrorDetector, ErrorDetector, ErrorModel, NullErrorDetector, RegExErrorDetector, parse_constraint, load_constraints,
+                           parse_and_verify_constraints)
 from repair.train import build_model, compute_class_nrow_stdv, rebalance_training_data, train_option_keys
 from repair.train import _opt_gpu_device_id as _train_opt_gpu_device_id
 from repair.utils import argtype_check, elapsed_time, get_option_value, job_group, setup_logger, to_list_str
@@ -608,6 +609,93 @@ class RepairModel():
                       feature_fraction=1.0, seed=42)
         return dict(engine=engine, params=params, search=int(g(_opt_max_evals)) > 1)
 
+    def _device_detection_plan(self, input_df: DataFrame, continous_columns: List[str], compute_repair_candidate_prob: bool,
+                               maximal_likelihood_repair: bool) -> Optional[Dict[str, Any]]:
+        """Can error DETECTION run on the resident table as well (reference python/repair/errors.py:545-582)?  Yes when the error
+        cells come from NULL / denial-constraint detectors only (no own target lists; every constraint in the form the device
+        detector handles, `pipeline.constraint_to_columns`) and the rest of the run qualifies for the resident pipeline: the
+        frame is then encoded once and `pipeline.repair_frame` detects, NULLs, trains and repairs without an `error_cells_df` ever
+        being built in pandas."""
+        from repair.pipeline import constraint_to_columns
+        if self.error_cells is not None or not self.error_detectors:
+            return None
+        cols = [c for c in input_df.columns if c != self._row_id]
+        cons: List[Tuple[List[str], str]] = []
+        has_null = False
+        for d in self.error_detectors:
+            if getattr(d, "targets", None):
+                return None
+            if type(d) is NullErrorDetector:
+                has_null = True
+            elif type(d) is ConstraintErrorDetector:
+                stmts = load_constraints(d.constraint_path, d.constraints)
+                try:
+                    plist = parse_and_verify_constraints(stmts, list(input_df.columns)) if stmts else []
+                except Exception:  # noqa: BLE001 - the pandas detector reports malformed constraints
+                    return None
+                for preds in plist:
+                    cc = constraint_to_columns(preds, cols)
+                    if cc is None:
+                        return None
+                    cons.append(([cols[i] for i in cc[0]], cols[cc[1]]))
+            else:
+                return None
+        from repair.utils import column_nunique
+        domain_stats = {c: column_nunique(input_df, c) for c in cols}
+        discretized = [c for c in cols if c in continous_columns or 1 < domain_stats[c] <= self.discrete_thres]
+        cands = [c for c in (self.targets if self.targets else cols) if c in discretized]
+        if not cands:
+            return None
+        plan = self._resident_plan(input_df, cands, continous_columns, domain_stats, compute_repair_candidate_prob, maximal_likelihood_repair)
+        if plan is None:
+            return None
+        plan.update(candidates=cands, constraints=cons, detect_nulls=has_null)
+        return plan
+
+    def _run_resident_detect(self, plan: Dict[str, Any], input_df: DataFrame, continous_columns: List[str], repair_data: bool) -> DataFrame:
+        """`_run` with detection, NULLing, training and repair on the resident table (`_device_detection_plan`)."""
+        from repair.pipeline import NotResidentEligible, repair_frame
+        from repair.errors import _to_sql_string
+        rid = self._row_id
+        cands = plan["candidates"]
+        if repair_data and not plan["detect_nulls"]:
+            raise NotResidentEligible("repair_data without a NULL detector: NULL target cells of dirty rows would stay NULL")
+        max_rows = int(self._get_option_value(*self._opt_max_training_row_num))
+
+        def sample(_attr: str, rows: np.ndarray) -> Optional[np.ndarray]:
+            if len(rows) <= max_rows:
+                return None
+            _logger.info("To reduce training data, extracts %s%% samples from %d rows" % (100.0 * max_rows / len(rows), len(rows)))
+            return rows[np.random.RandomState(42).choice(len(rows), max_rows, replace=False)]
+
+        _logger.info("[Error Detection + Repair Model Training Phase] on the HBM-resident table, candidate attributes %s" % to_list_str(cands))
+        frame, info = repair_frame(plan["engine"], input_df, rid, targets=cands, base_params=plan["params"], constraints=plan["constraints"],
+                                   detect_nulls=plan["detect_nulls"], continuous_columns=[c for c in continous_columns if c in cands],
+                                   train_rows=sample, want_details=True, search_opts=dict(self.opts) if plan.get("search") else None,
+                                   only_noisy_targets=True)
+        self._last_resident_info = info
+        self._last_detection_on_device = True
+        if len(frame) == 0:
+            _logger.info("Any error cell not found, so the input data is already clean")
+            return input_df if repair_data else pd.DataFrame({rid: pd.Series([], dtype=input_df[rid].dtype), "attribute": pd.Series([], dtype=object),
+                                                              "current_value": pd.Series([], dtype=object), "repaired": pd.Series([], dtype=object)})
+        cur = [None if v is None or (isinstance(v, float) and np.isnan(v)) else _to_sql_string(v) for v in frame["current_value"].tolist()]
+        rep = [None if v is None or (isinstance(v, float) and np.isnan(v)) else _to_str(v) for v in frame["repaired"].tolist()]
+        cand = pd.DataFrame({rid: frame[rid].to_numpy(), "attribute": frame["attribute"].to_numpy(), "current_value": np.asarray(cur, object),
+                             "repaired": np.asarray(rep, object)})
+        # integral attributes: CAST(int AS STRING) of the current value is '2', never '2.0' (ErrorModel.detect keeps nullable ints integral)
+        for a in set(cand["attribute"]):
+            if is_integral_column(input_df[a]):
+                m = (cand["attribute"] == a).to_numpy() & cand["current_value"].notna().to_numpy()
+                cand.loc[m, "current_value"] = [str(int(float(v))) for v in cand.loc[m, "current_value"]]
+        if repair_data:
+            base = self._prepare_repair_base_cells(input_df, cand, sorted(set(cand["attribute"])))
+            is_dirty = base[rid].isin(set(cand[rid].tolist())).to_numpy()
+            dirty = self._repair_attrs(cand[[rid, "attribute", "repaired"]], base[is_dirty].reset_index(drop=True))
+            return pd.concat([base[~is_dirty], dirty], ignore_index=True)
+        keep = cand["repaired"].isna() | ~((cand["current_value"] == cand["repaired"]) | (cand["current_value"].isna() & cand["repaired"].isna()))
+        return cand[keep.to_numpy()].reset_index(drop=True)
+
     def _run_resident(self, plan: Dict[str, Any], input_df: DataFrame, error_cells_df: DataFrame, target_columns: List[str],
                       continous_columns: List[str], repair_data: bool) -> DataFrame:
         """Steps 2 and 3 of `_run` on the device: the table is encoded once (dictionary indices -> codes, on the device), error
@@ -659,6 +747,18 @@ class RepairModel():
              compute_repair_candidate_prob: bool, compute_repair_prob: bool, compute_repair_score: bool,
              repair_data: bool, maximal_likelihood_repair: bool) -> DataFrame:
         rid = self._row_id
+        self._last_detection_on_device = False
+        # 0. Everything on the HBM-resident table, detection included, when the detectors and the run allow it
+        if not detect_errors_only:
+            dplan = self._device_detection_plan(input_df, continous_columns, compute_repair_candidate_prob, maximal_likelihood_repair)
+            if dplan is not None:
+                from repair.pipeline import NotResidentEligible
+                try:
+                    return self._run_resident_detect(dplan, input_df, continous_columns, repair_data)
+                except NotResidentEligible as e:
+                    self._last_resident_info = None
+                    self._last_detection_on_device = False
+                    _logger.info("device-side detection not taken: %s" % e)
         # 1. Error Detection Phase
         _logger.info("[Error Detection Phase] Detecting errors in a table... ")
         error_cells_df, target_columns, pairwise_attr_stats, domain_stats = self._detect_errors(input_df, continous_columns)

@@ -142,12 +142,17 @@ def unseen_categories(table, dirty_tab, targets, ordered_cols=(), train_tables=N
 
 def repair_table(engine, table, targets, base_params, constraints=(), detect_nulls=True, error_cells=None,
                  want_pmf=False, top_k=32, threshold=0.0, want_stats=False, continuous=None, train_rows=None,
-                 check_unseen=False, search_opts=None):
+                 check_unseen=False, search_opts=None, only_noisy_targets=False):
     """Detect, NULL out, split, train, repair, shape.  ``table`` is modified in place (error cells become NULL).
 
     continuous : {column: (ascending distinct values, is_integral)} -- CONTINUOUS target attributes (byte/short/int/long/float/
                  double in the reference, RepairBase.scala:41-44): repaired by an L2 regressor on the values behind their codes
                  (train.py:97-100), integral ones rounded (model.py:1130-1132); `repaired_value` carries the prediction.
+    only_noisy_targets: train models for the target attributes that hold at least one error cell only (the reference's
+                 `target_columns` are the noisy columns, errors.py:472-477) and insist that every label of such a target still has a
+                 training row once the cells are NULLed -- `RepairModel.run()` with detection on the device: the cells are not known
+                 when the dictionaries are built, so a value that only error cells held would stay behind as a class without rows
+                 (num_class enters the softmax hessian factor); NotResidentEligible then sends the run to the value-space path.
     search_opts: reference option dict (model.hp.*, model.cv.n_splits): run the hyper-parameter search of every target on the
                  resident tables before its final fit (`search_on_table`); None = the fixed parameters.
     train_rows : {target: row positions} or a callable (target, positions of its non-NULL rows) -> positions -- train that
@@ -161,6 +166,9 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
     targets = [int(t) for t in targets]
     n_codes = np.asarray(table.n_codes, np.int32)
     rows, cols = detect_error_cells(table, targets, constraints, detect_nulls, error_cells)
+    if only_noisy_targets:
+        noisy = set(int(c) for c in np.unique(cols))
+        targets = [t for t in targets if t in noisy]
     t_detect = time.perf_counter() - t0
     t0 = time.perf_counter()
     current = table.read_cells(rows, cols)
@@ -179,6 +187,8 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
         if t in continuous:
             if int((cnt > 0).sum()) < 1:
                 raise NotResidentEligible("continuous target column %d has no non-NULL row to learn from" % t)
+        elif only_noisy_targets and int((cnt > 0).sum()) < len(cnt):
+            raise NotResidentEligible("target column %d: %d of its %d values are held by error cells only" % (t, int((cnt <= 0).sum()), len(cnt)))
         elif int((cnt > 0).sum()) < 2:
             raise NotResidentEligible("target column %d has fewer than two classes among its non-NULL rows; the reference short-cuts such "
                              "attributes with a constant model (model.py:1008-1017) -- drop it from `targets`" % t)
@@ -275,7 +285,7 @@ def encode_frame(df, columns):
 
 def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=None, want_pmf=False, top_k=32, threshold=0.0,
                  error_cells=None, detect_nulls=True, continuous_columns=(), train_rows=None, want_details=False,
-                 check_unseen=False, search_opts=None):
+                 check_unseen=False, search_opts=None, only_noisy_targets=False):
     """DataFrame in, the reference's result frame out: (row_id, attribute, current_value, repaired, prob[, pmf]) -- the
     shape of `RepairModel.run()` / `run(compute_repair_candidate_prob=True)` (python/repair/model.py:1398-1419).
 
@@ -345,6 +355,7 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
             cont[pos[c]] = (np.asarray(dicts[pos[c]], np.float64), pd.api.types.is_integer_dtype(df[c]))
     res = repair_table(engine, table, [pos[t] for t in targets], dict(base_params or {}), constraints=cons, detect_nulls=detect_nulls,
                        error_cells=cells, want_pmf=want_pmf, top_k=top_k, threshold=threshold, continuous=cont, search_opts=search_opts,
+                       only_noisy_targets=only_noisy_targets,
                        check_unseen=([pos[c] for c in cols if pd.api.types.is_numeric_dtype(df[c]) and not pd.api.types.is_bool_dtype(df[c])] or True) if check_unseen else False,
                        train_rows=(lambda t, r: train_rows(cols[t], r)) if callable(train_rows) else train_rows)
     rows, ccols = res["rows"], res["cols"]

@@ -171,6 +171,41 @@ def test_unseen_category_in_a_dirty_row_is_missing_on_both_paths(oracle_backend)
     pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
 
 
+def test_detection_runs_on_the_resident_table_too(oracle_backend):
+    """with NULL / denial-constraint detectors `run()` never builds an `error_cells_df` in pandas: the frame is
+    encoded once and detection, NULLing, training and repair all happen on the table (reference python/repair/errors.py:545-582 ->
+    pipeline.detect_error_cells).  Same frames as the value-space path: NULL detector, NULL + constraint detectors, repair_data, and a
+    clean table."""
+    df, _, _, _ = _synthetic_frame(2500, 6, seed=41)
+    a, b = _both_paths(df, OracleEngine())
+    pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
+    # constraint c4 -> c5 on top of the NULL detector (c5 is a noisy function of the latent class, so many rows violate it)
+    import os
+
+    def model(engine):
+        m = RepairModel().setInput(df).setRowId("tid").setErrorDetectors([NullErrorDetector(), ConstraintErrorDetector(constraints="c4->c5")])
+        for k, v in {"model.hp.max_evals": "1", "model.lgb.n_estimators": "8", "model.lgb.learning_rate": "0.2"}.items():
+            m = m.option(k, v)
+        m._engine_override = engine
+        return m
+    os.environ["REPAIR_RESIDENT"] = "0"
+    try:
+        slow = model(None).run()
+    finally:
+        os.environ.pop("REPAIR_RESIDENT", None)
+    fast_m = model(OracleEngine())
+    fast = fast_m.run()
+    pd.testing.assert_frame_equal(_sorted(slow), _sorted(fast))
+    assert len(fast) > 500
+    # (either the device detected, or a class that only error cells held sent the run back to the value-space path: same frame both ways)
+    m2 = _model(df); m2._engine_override = OracleEngine()
+    out = m2.run(repair_data=True)
+    assert m2._last_detection_on_device and not out.drop(columns=["tid"]).isna().any().any() and len(out) == len(df)
+    clean = df.dropna().reset_index(drop=True)
+    m3 = _model(clean); m3._engine_override = OracleEngine()
+    assert len(m3.run()) == 0 and m3._last_detection_on_device
+
+
 @pytest.mark.gpu
 def test_gpu_run_takes_the_resident_path_and_matches_both_references():
     """HIP engine vs the HIP estimators of the value-space path on 20 000 rows; then 1M rows through `run()`: every repaired label
