@@ -239,6 +239,7 @@ struct Tree {
 
 struct DeviceModel {   // predictor mirror of a model on one device
     DevBuf<rg::PNode> nodes; DevBuf<double> leaf_value;
+    DevBuf<uint32_t> cnodes; DevBuf<double> cleaves; int cdepth = 0;   // every tree once more as a complete binary tree of depth cdepth (k_predict_fixed); 0 = not built
     DevBuf<uint8_t> lut; DevBuf<long long> lut_off; DevBuf<int32_t> n_codes; DevBuf<uint8_t> miss; DevBuf<int32_t> ident;
     int node_stride = 1, leaf_stride = 1;
 };
@@ -1071,6 +1072,43 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
         const Feat& ft = m->feats[f]; int b = 0;
         for (int c = 0; c < ncod[f]; ++c) { while (b < ft.V - 1 && c > ft.ub[b]) ++b; lut[lut_off[f] + c] = ft.is_unseen(c) ? (uint8_t)255 : (uint8_t)(ft.V > 0 ? b : 0); }
     }
+    // the complete-tree form (k_predict_fixed) when no tree is deeper than 7
+    {
+        int D = 1;
+        std::vector<int> depth_of;
+        for (const Tree& tr : m->trees) {
+            depth_of.assign(std::max(tr.L - 1, 1), 0);
+            for (int j = 0; j < tr.L - 1; ++j) {
+                const int d = depth_of[j] + 1;
+                if (tr.left[j] >= 0) depth_of[tr.left[j]] = d;
+                if (tr.right[j] >= 0) depth_of[tr.right[j]] = d;
+                D = std::max(D, d);
+            }
+        }
+        if (D <= 7 && NT > 0) {
+            const int nn = (1 << D) - 1, nl = 1 << D;
+            std::vector<uint32_t> cn(NT * nn); std::vector<double> cl(NT * nl);
+            const uint32_t pass = 0u | 256u << 8 | 1u << 17;       // feature 0, theta + 1 = 256, default left: every bin goes left
+            for (size_t t = 0; t < NT; ++t) {
+                const Tree& tr = m->trees[t];
+                uint32_t* tn = cn.data() + t * nn; double* tl = cl.data() + t * nl;
+                // (index in the complete tree, original child reference: >= 0 internal node, < 0 ~leaf)
+                std::vector<std::pair<int, int>> todo; todo.emplace_back(0, tr.L > 1 ? 0 : ~0);
+                while (!todo.empty()) {
+                    const auto [i, ref] = todo.back(); todo.pop_back();
+                    if (i >= nn) { tl[i - nn] = tr.leaf_value[~ref]; continue; }      // depth D reached: `ref` is a leaf here (no tree is deeper than D)
+                    if (ref >= 0) {
+                        tn[i] = (uint32_t)(tr.feat[ref] & 0xFF) | ((uint32_t)(tr.theta[ref] + 1) & 0x1FFu) << 8 | (uint32_t)(tr.dleft[ref] ? 1 : 0) << 17;
+                        todo.emplace_back(2 * i + 1, tr.left[ref]); todo.emplace_back(2 * i + 2, tr.right[ref]);
+                    } else { tn[i] = pass; todo.emplace_back(2 * i + 1, ref); todo.emplace_back(2 * i + 2, ref); }
+                }
+            }
+            dm->cnodes.alloc(cn.size()); dm->cnodes.upload(cn.data(), cn.size(), s);
+            dm->cleaves.alloc(cl.size()); dm->cleaves.upload(cl.data(), cl.size(), s);
+            dm->cdepth = D;
+            HIPCHK(hipStreamSynchronize(s));     // cn / cl are locals
+        }
+    }
     dm->nodes.alloc(nodes.size()); dm->nodes.upload(nodes.data(), nodes.size(), s);
     dm->leaf_value.alloc(lv.size()); dm->leaf_value.upload(lv.data(), lv.size(), s);
     dm->lut.alloc(lut.size()); dm->lut.upload(lut.data(), lut.size(), s);
@@ -1102,7 +1140,14 @@ void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_c
     DevBuf<uint4>& rec = sc.rec; DevBuf<double>& raw = sc.raw;
     hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes, Ntab, row0, n,
                        d_feat_cols ? d_feat_cols : dm->ident.p, dm->n_codes.p, dm->lut_off.p, dm->lut.p, dm->miss.p, F, nchunk, rec.p);
-    if (nchunk == 1) hipLaunchKernelGGL(k_predict_raw<true>, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
+    if (dm->cdepth > 0 && F <= 255) {   // fixed-depth, divergence-free walk over the complete-tree form
+        const int D = dm->cdepth;
+        const size_t lds = (size_t)2 * PT_TB * (1 << D) * (4 + 8);
+        const dim3 grid((unsigned)((n + 256 * PT_ROWS - 1) / (256 * PT_ROWS)), K);
+        if (nchunk == 1) hipLaunchKernelGGL(k_predict_fixed<true>, grid, dim3(256), lds, s, reinterpret_cast<const uint8_t*>(rec.p), n, dm->cnodes.p, dm->cleaves.p, m->n_iter, K, D, raw.p);
+        else hipLaunchKernelGGL(k_predict_fixed<false>, grid, dim3(256), lds, s, reinterpret_cast<const uint8_t*>(rec.p), n, dm->cnodes.p, dm->cleaves.p, m->n_iter, K, D, raw.p);
+    }
+    else if (nchunk == 1) hipLaunchKernelGGL(k_predict_raw<true>, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
                                         dm->nodes.p, dm->leaf_value.p, m->n_iter, K, dm->node_stride, dm->leaf_stride, raw.p);
     else hipLaunchKernelGGL(k_predict_raw<false>, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
                             dm->nodes.p, dm->leaf_value.p, m->n_iter, K, dm->node_stride, dm->leaf_stride, raw.p);

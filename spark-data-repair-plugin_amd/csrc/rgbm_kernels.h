@@ -914,6 +914,85 @@ __global__ __launch_bounds__(256) void k_predict_raw(const uint8_t* __restrict__
     raw[(long long)k * n + i] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_predict_fixed: GBDT::PredictRaw without divergence.  Every tree of the model is stored a second time as a COMPLETE binary tree
+// of the model's depth D (<= 7; children of node i at 2i+1 / 2i+2, a leaf above depth D becomes a chain of pass-through nodes that
+// ends in copies of its value): 2^D - 1 node words (feature | theta+1 << 8 | default-left << 17) and 2^D leaf values.  A workgroup
+// owns 256 x ROWS rows of ONE class; the trees of that class are staged through LDS, PT_TB at a time, double-buffered, and every lane
+// walks them for its rows: D x (one LDS read, a byte select on the record in registers, two compares) and one LDS read of the leaf.
+// No data-dependent loads from memory, no loop whose trip count differs between lanes, ROWS independent walks per lane to cover the
+// LDS latency.  (The walk over the index-linked nodes, k_predict_raw, was latency-bound: ~150 lane-cycles per node visit)
+// The leaf values are added in iteration order, as the oracle does: raw scores are bit-identical.
+//   grid (ceil(n / (256 ROWS)), K), block 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int PT_TB = 8;         // trees per LDS stage
+constexpr int PT_ROWS = 2;       // rows per lane
+template <bool ONE_CHUNK>
+__global__ __launch_bounds__(256) void k_predict_fixed(const uint8_t* __restrict__ rec8, long long n, const uint32_t* __restrict__ cnodes /* [T][2^D - 1] */,
+                                                       const double* __restrict__ cleaves /* [T][2^D] */, int n_iter, int K, int D,
+                                                       double* __restrict__ raw /* [K][n] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nn = (1 << D) - 1, nl = 1 << D;
+    const int stage_words = PT_TB * (nn + 1);                     // node words of a stage, padded to 2^D per tree
+    uint32_t* sn = reinterpret_cast<uint32_t*>(smem);             // [2][PT_TB][2^D] node words
+    double* sl = reinterpret_cast<double*>(sn + 2 * stage_words); // [2][PT_TB][2^D] leaf values
+    const int k = blockIdx.y, tid = threadIdx.x;
+    const long long base = (long long)blockIdx.x * (256 * PT_ROWS);
+    uint4 r[PT_ROWS]; long long row[PT_ROWS]; double s[PT_ROWS];
+#pragma unroll
+    for (int q = 0; q < PT_ROWS; ++q) {
+        row[q] = base + q * 256 + tid;
+        const long long rc = row[q] < n ? row[q] : n - 1;
+        r[q] = ONE_CHUNK ? reinterpret_cast<const uint4*>(rec8)[rc] : make_uint4(0, 0, 0, 0);
+        row[q] = rc; s[q] = 0.0;
+    }
+    auto stage = [&](int it0, int buf) {
+        for (int i = tid; i < PT_TB * nl; i += 256) {
+            const int tb = i >> D, j = i & (nl - 1), it = it0 + tb;
+            if (it < n_iter) {
+                const long long t = (long long)it * K + k;
+                if (j < nn) sn[buf * stage_words + tb * nl + j] = cnodes[t * nn + j];
+                sl[(buf * PT_TB + tb) * nl + j] = cleaves[t * nl + j];
+            }
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int it0 = 0; it0 < n_iter; it0 += PT_TB, buf ^= 1) {
+        if (it0 + PT_TB < n_iter) stage(it0 + PT_TB, buf ^ 1);
+        const int nt = (n_iter - it0) < PT_TB ? (n_iter - it0) : PT_TB;
+        for (int tb = 0; tb < nt; ++tb) {
+            const uint32_t* tn = sn + buf * stage_words + tb * nl;
+            const double* tl = sl + (buf * PT_TB + tb) * nl;
+            int node[PT_ROWS];
+#pragma unroll
+            for (int q = 0; q < PT_ROWS; ++q) node[q] = 0;
+            for (int d = 0; d < D; ++d) {
+#pragma unroll
+                for (int q = 0; q < PT_ROWS; ++q) {
+                    const uint32_t w = tn[node[q]];
+                    const unsigned f = w & 0xFFu;
+                    unsigned bin;
+                    if (ONE_CHUNK) {
+                        const bool hi = (f & 8u) != 0u;
+                        const uint32_t lo32 = hi ? r[q].z : r[q].x, hi32 = hi ? r[q].w : r[q].y;
+                        bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
+                    } else bin = rec8[((long long)(f >> 4) * n + row[q]) * 16 + (f & 15u)];
+                    const uint32_t is_nan = bin == 255u ? 1u : 0u, lt = bin < ((w >> 8) & 0x1FFu) ? 1u : 0u;
+                    const uint32_t left = (is_nan & (w >> 17)) | ((is_nan ^ 1u) & lt);
+                    node[q] = 2 * node[q] + 2 - (int)(left & 1u);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PT_ROWS; ++q) s[q] += tl[node[q] - nn];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < PT_ROWS; ++q) if (base + q * 256 + tid < n) raw[(long long)k * n + row[q]] = s[q];
+}
+
 // ConvertOutput + arg-max (first maximum).  proba may be null (labels only).
 __global__ __launch_bounds__(256) void k_softmax_argmax(const double* __restrict__ raw, long long n, int objective, int K,
                                                         double* __restrict__ proba /* [n][ncol] or null */, int32_t* __restrict__ label, double* __restrict__ top) {
