@@ -24,6 +24,7 @@ ones are target-sharded (LPT), the chained repair is row-sharded.  --mode target
 parallel mode).
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -162,6 +163,7 @@ def main():
     ap.add_argument("--train-rows", type=int, default=0,
                     help="train every model on a seeded sample of this many rows (the reference's DEFAULT behaviour is "
                          "model.max_training_row_num = 10000, model.py:755-766); 0 = all rows, which is what BASELINE's metric is quoted on")
+    ap.add_argument("--dump-labels", default="", help="debug: np.save the repaired labels / probabilities of the job here")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -313,6 +315,11 @@ def main():
     out = None
     if rank == 0:
         labels = res["labels"]
+        if a.dump_labels:
+            np.save(a.dump_labels + "_labels.npy", labels); np.save(a.dump_labels + "_probs.npy", res["probs"])
+            for t in targets:
+                with open(a.dump_labels + "_model_%d.bin" % t, "wb") as f:
+                    f.write(res["models"][t])
         fixed = 0
         for i, t in enumerate(targets):
             pos, truth = null_truth[t]
@@ -352,6 +359,8 @@ def main():
             "steps_region_sec": elapsed_k, "job_steps": job_steps, "elapsed_sec": elapsed,
             "model_train_sec": train_s, "repair_sec": infer_s,
             "repair_accuracy_vs_clean": fixed / max(n_cells, 1),
+            # digest of every trained model of the job, in target order: two runs of the same build must print the same value
+            "models_md5": hashlib.md5(b"".join(res["models"][t] for t in targets)).hexdigest(),
             "upload": {"bytes": int(upload_bytes), "sec": t_up, "GBps": upload_bytes / max(t_up, 1e-9) * 1e-9, "generate_sec": t_gen},
             "roofline": {"bound": "hbm",
                          "kernel": "rg::k_level_root + rg::k_level_mt (histogram build of the level grower; a level pass also routes the rows of its level: DataPartition::Split is not a separate kernel)",

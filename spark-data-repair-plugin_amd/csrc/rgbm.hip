@@ -68,7 +68,59 @@ struct DevPool {
 DevPool& pool() { static DevPool* p = new DevPool(); return *p; }
 }  // namespace
 
+// RGBM_GUARD=1 (debugging): every buffer sits between two 2 MB guard zones filled with 0xC3, and so is the slack between the bytes asked
+// for and the end of the pool block; pool_free checks that nobody wrote there and says so on stderr.  A kernel that READS out of
+// bounds sees the same 0xC3 bytes in every process instead of a neighbour's live data.
+namespace {
+constexpr size_t GUARD = 2u << 20;
+bool guard_on() { static const bool g = getenv("RGBM_GUARD") != nullptr; return g; }
+std::mutex g_guard_mu; std::map<void*, size_t> g_guard_bytes;
+__global__ void k_guard_check(const unsigned char* p, size_t n, unsigned long long* bad /* [0] count, [1] first offset */) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (p[i] != 0xC3) { atomicAdd(&bad[0], 1ull); atomicMin(&bad[1], (unsigned long long)i); }
+}
+// RGBM_TRACE (debugging): wrapping 64-bit sum of a buffer's words
+__global__ void k_trace_sum(const unsigned long long* p, size_t nwords, unsigned long long* out) {
+    unsigned long long a = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) a += p[i] * (2 * (unsigned long long)i + 1);
+    atomicAdd(out, a);
+}
+void* pool_alloc_raw(size_t bytes, size_t* block_bytes, int* device);
+void pool_free_raw(void* p, size_t block_bytes, int device);
+}  // namespace
+
 void* rgh::pool_alloc(size_t bytes, size_t* block_bytes, int* device) {
+    if (!guard_on()) return pool_alloc_raw(bytes, block_bytes, device);
+    unsigned char* raw = static_cast<unsigned char*>(pool_alloc_raw(bytes + 2 * GUARD, block_bytes, device));
+    if (hipMemset(raw, 0xC3, GUARD) != hipSuccess || hipMemset(raw + GUARD + bytes, 0xC3, *block_bytes - GUARD - bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+        throw std::runtime_error("RGBM_GUARD: hipMemset failed");
+    { std::lock_guard<std::mutex> lk(g_guard_mu); g_guard_bytes[raw + GUARD] = bytes; }
+    return raw + GUARD;
+}
+
+void rgh::pool_free(void* p, size_t block_bytes, int device) {
+    if (!p) return;
+    if (!guard_on()) { pool_free_raw(p, block_bytes, device); return; }
+    size_t bytes = 0;
+    { std::lock_guard<std::mutex> lk(g_guard_mu); auto it = g_guard_bytes.find(p); if (it != g_guard_bytes.end()) { bytes = it->second; g_guard_bytes.erase(it); } }
+    unsigned char* raw = static_cast<unsigned char*>(p) - GUARD;
+    static thread_local unsigned long long* d_bad = nullptr;
+    if (!d_bad) (void)hipMalloc(&d_bad, 16);
+    const size_t tail = block_bytes - GUARD - bytes;
+    const struct { const unsigned char* q; size_t n; const char* what; } zones[2] = {{raw, GUARD, "front guard"}, {raw + GUARD + bytes, tail, "slack + back guard"}};
+    for (const auto& z : zones) {
+        unsigned long long h[2] = {0ull, ~0ull};
+        (void)hipMemcpy(d_bad, h, 16, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_guard_check, dim3(1024), dim3(256), 0, nullptr, z.q, z.n, d_bad);
+        (void)hipMemcpy(h, d_bad, 16, hipMemcpyDeviceToHost);
+        if (h[0]) fprintf(stderr, "[rgbm guard] buffer of %zu bytes (block %zu): %llu byte(s) of the %s were overwritten, first at offset %lld from the buffer's %s\n",
+                          bytes, block_bytes, h[0], z.what, z.q == raw ? (long long)h[1] - (long long)GUARD : (long long)h[1], z.q == raw ? "start" : "end");
+    }
+    pool_free_raw(raw, block_bytes, device);
+}
+
+namespace {
+void* pool_alloc_raw(size_t bytes, size_t* block_bytes, int* device) {
     int dev = 0; (void)hipGetDevice(&dev);
     *device = dev;
     DevPool& P = pool();
@@ -97,7 +149,7 @@ void* rgh::pool_alloc(size_t bytes, size_t* block_bytes, int* device) {
     return p;
 }
 
-void rgh::pool_free(void* p, size_t block_bytes, int device) {
+void pool_free_raw(void* p, size_t block_bytes, int device) {
     if (!p) return;
     DevPool& P = pool();
     if (P.cap() == 0 || block_bytes > P.cap()) {
@@ -112,6 +164,8 @@ void rgh::pool_free(void* p, size_t block_bytes, int device) {
     P.cached += block_bytes;
     if (P.cached > P.cap()) P.trim_locked(P.cap());
 }
+
+}  // namespace
 
 void rgh::pool_trim(size_t keep_bytes) { DevPool& P = pool(); std::lock_guard<std::mutex> lk(P.mu); P.trim_locked(keep_bytes); }
 namespace {
@@ -239,7 +293,8 @@ struct Tree {
 
 struct DeviceModel {   // predictor mirror of a model on one device
     DevBuf<rg::PNode> nodes; DevBuf<double> leaf_value;
-    DevBuf<uint32_t> cnodes; DevBuf<double> cleaves; int cdepth = 0;   // every tree once more as a complete binary tree of depth cdepth (k_predict_fixed); 0 = not built
+    // bit-vector scoring tables (k_predict_qs): per tree the AND-masks of every (feature, bin) and the leaf values in left-to-right order
+    DevBuf<uint32_t> qs_masks; DevBuf<double> qs_leaves; DevBuf<int32_t> qs_foff; int qs_S = 0, qs_MW = 0;   // qs_MW = 0: not built
     DevBuf<uint8_t> lut; DevBuf<long long> lut_off; DevBuf<int32_t> n_codes; DevBuf<uint8_t> miss; DevBuf<int32_t> ident;
     int node_stride = 1, leaf_stride = 1;
 };
@@ -850,10 +905,37 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     };
 
     DevBuf<int32_t> d_it(1); d_it.zero(s);   // device-side iteration counter (k_next_iteration)
+    // RGBM_TRACE=<dir> (debugging; with RGBM_TRACE_K=<class trees> and RGBM_TRACE_ITERS=lo:hi): snapshots of the grower's state after every
+    // level of the iterations lo..hi and a checksum of (score, g/h, node ids) after every iteration, written to <dir>/target<col>.{bin,idx}
+    const char* trace_dir = getenv("RGBM_TRACE");
+    const bool trace_on = trace_dir && level_mode && (!getenv("RGBM_TRACE_K") || atoi(getenv("RGBM_TRACE_K")) == K);
+    int trace_lo = 44, trace_hi = 44, cur_it = 0;
+    if (trace_on && getenv("RGBM_TRACE_ITERS")) sscanf(getenv("RGBM_TRACE_ITERS"), "%d:%d", &trace_lo, &trace_hi);
+    struct TraceRec { std::string name; int it, level; size_t off, bytes; };
+    std::vector<TraceRec> trace_idx; size_t trace_used = 0;
+    DevBuf<unsigned char> d_trace;
+    if (trace_on) d_trace.alloc(((size_t)K * n_hnodes * tc.totbins * 16 + (size_t)K * 256 * (sizeof(SNode) + 4) + (size_t)K * sizeof(LvPlan) + 4096) * (size_t)(p.max_depth + 1) * (size_t)(trace_hi - trace_lo + 1) + (size_t)NE * 64 + 4096);
+    auto trace_copy = [&](const char* name, int level, const void* src, size_t bytes) {
+        if (!trace_on || cur_it < trace_lo || cur_it > trace_hi) return;
+        if (trace_used + bytes > d_trace.n) return;
+        HIPCHK(hipMemcpyAsync(d_trace.p + trace_used, src, bytes, hipMemcpyDeviceToDevice, s));
+        trace_idx.push_back({name, cur_it, level, trace_used, bytes}); trace_used += (bytes + 15) & ~(size_t)15;
+    };
+    auto trace_sum = [&](const char* name, const void* src, size_t bytes) {
+        if (!trace_on || trace_used + 16 > d_trace.n) return;
+        HIPCHK(hipMemsetAsync(d_trace.p + trace_used, 0, 8, s));
+        hipLaunchKernelGGL(k_trace_sum, dim3(2048), dim3(256), 0, s, (const unsigned long long*)src, bytes / 8, (unsigned long long*)(d_trace.p + trace_used));
+        trace_idx.push_back({name, cur_it, -1, trace_used, 8}); trace_used += 16;
+    };
+    auto trace_level = [&](int level) {
+        trace_copy("count", level, d_count.p, (size_t)K * 256 * 4);
+        trace_copy("plan", level, d_plan.p, (size_t)K * sizeof(LvPlan));
+        trace_copy("snodes", level, d_snodes.p, (size_t)K * 256 * sizeof(SNode));
+        trace_copy("lpool", level, d_lpool.p, (size_t)K * n_hnodes * tc.totbins * 16);
+    };
     // one boosting iteration of the level grower after the gradients: an iteration-invariant launch sequence
     auto enqueue_level_growth = [&]() {
-            d_count.zero(s);
-            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, n_in_ptr, (long long)n_train, lc);
+            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, n_in_ptr, (long long)n_train, lc);
             int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
             // partials of this rank -> compact buffer (-> integer all-reduce when row-sharded); the split kernel then sees ONE partial
             auto exchange = [&](bool root, int nb, const LevelConst& lp) -> std::pair<const HistBin*, LevelConst> {
@@ -876,6 +958,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 auto ex = exchange(true, 1, lc);
                 hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p, cntg, d_count.p, d_fmeta.p,
                                    d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
+                trace_level(0);
             }
             for (int level = 1; level < p.max_depth; ++level) {
                 hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_snodes.p, d_lcand.p, d_fmeta.p, level, tc, lc);
@@ -883,6 +966,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 auto ex = exchange(false, 1 << (level - 1), lp);
                 hipLaunchKernelGGL(k_level_split<false>, dim3((F + 1) / 2, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
                                    cntg, d_count.p, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
+                trace_level(level);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
             hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_snodes.p, d_lcand.p, d_fmeta.p, p.max_depth, tc, lc);
@@ -891,6 +975,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
             if (dp) { HIPCHK(hipMemcpyAsync(d_count_g.p, d_count.p, (size_t)K * 256 * 4, hipMemcpyDeviceToDevice, s)); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
             hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, d_it.p, tc);
+            trace_level(p.max_depth);
+            trace_sum("score", d_score.p, (size_t)K * N * 8); trace_sum("node", d_node.p, (size_t)K * lc.NS);
     };
 
     auto enqueue_grad = [&]() {
@@ -921,7 +1007,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     };
     for (int it = 0; it < NE; ++it) {
         if (use_bagging && it % p.bagging_freq == 0) enqueue_bagging();
+        cur_it = it;
         enqueue_grad();
+        trace_sum("gh", d_gh.p, (size_t)K * N * 8);
         const uint8_t* usedp = d_used.p + (size_t)it * K * F;
         if (level_mode) {
             enqueue_level_growth();
@@ -957,6 +1045,15 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     HIPCHK(hipEventRecord(ev_end, s));
     if (dp) stream_sync_watchdog(s); else HIPCHK(hipStreamSynchronize(s));
     if (timing) fprintf(stderr, "[rgbm] target %d K=%d: count+bins %.1f ms, alloc+pack %.1f ms, enqueue %.1f ms, drain+download %.1f ms\n", target_col, K, t_bins - t_start, t_setup - t_bins, t_enq - t_setup, now() - t_enq);
+    if (trace_on && trace_used) {
+        std::vector<unsigned char> h(trace_used);
+        HIPCHK(hipMemcpy(h.data(), d_trace.p, trace_used, hipMemcpyDeviceToHost));
+        char path[512];
+        snprintf(path, sizeof(path), "%s/target%d.bin", trace_dir, target_col);
+        if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 1, h.size(), f); fclose(f); }
+        snprintf(path, sizeof(path), "%s/target%d.idx", trace_dir, target_col);
+        if (FILE* f = fopen(path, "w")) { for (const auto& r : trace_idx) fprintf(f, "%s %d %d %zu %zu\n", r.name.c_str(), r.it, r.level, r.off, r.bytes); fclose(f); }
+    }
     if (h_err) throw std::runtime_error("level grower: a node outside the speculative expansion was selected (expansion bound violated)");
 
     int n_iter = NE;
@@ -1072,41 +1169,48 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
         const Feat& ft = m->feats[f]; int b = 0;
         for (int c = 0; c < ncod[f]; ++c) { while (b < ft.V - 1 && c > ft.ub[b]) ++b; lut[lut_off[f] + c] = ft.is_unseen(c) ? (uint8_t)255 : (uint8_t)(ft.V > 0 ? b : 0); }
     }
-    // the complete-tree form (k_predict_fixed) when no tree is deeper than 7
+    // the bit-vector scoring tables (k_predict_qs) when no tree has more than 64 leaves and the model has at most 32 features
     {
-        int D = 1;
-        std::vector<int> depth_of;
-        for (const Tree& tr : m->trees) {
-            depth_of.assign(std::max(tr.L - 1, 1), 0);
-            for (int j = 0; j < tr.L - 1; ++j) {
-                const int d = depth_of[j] + 1;
-                if (tr.left[j] >= 0) depth_of[tr.left[j]] = d;
-                if (tr.right[j] >= 0) depth_of[tr.right[j]] = d;
-                D = std::max(D, d);
-            }
-        }
-        if (D <= 7 && NT > 0) {
-            const int nn = (1 << D) - 1, nl = 1 << D;
-            std::vector<uint32_t> cn(NT * nn); std::vector<double> cl(NT * nl);
-            const uint32_t pass = 0u | 256u << 8 | 1u << 17;       // feature 0, theta + 1 = 256, default left: every bin goes left
+        int maxLeaves = 1;
+        for (const Tree& tr : m->trees) maxLeaves = std::max(maxLeaves, tr.L);
+        const int F_ = m->F;
+        if (maxLeaves <= 64 && F_ <= 32 && NT > 0) {
+            const int MW = maxLeaves <= 32 ? 1 : 2, LP = 32 * MW;
+            std::vector<int32_t> foff(F_ + 1, 0);
+            for (int f = 0; f < F_; ++f) foff[f + 1] = foff[f] + std::max(m->feats[f].V, 1) + 1;       // value bins + the missing entry
+            const int S = foff[F_];
+            std::vector<uint32_t> mk((size_t)NT * S * MW, 0xFFFFFFFFu); std::vector<double> lv2((size_t)NT * LP, 0.0);
+            std::vector<int> lo, mid;                                // per internal node: in-order ids [lo, mid) of the leaves of its left subtree
             for (size_t t = 0; t < NT; ++t) {
                 const Tree& tr = m->trees[t];
-                uint32_t* tn = cn.data() + t * nn; double* tl = cl.data() + t * nl;
-                // (index in the complete tree, original child reference: >= 0 internal node, < 0 ~leaf)
-                std::vector<std::pair<int, int>> todo; todo.emplace_back(0, tr.L > 1 ? 0 : ~0);
-                while (!todo.empty()) {
-                    const auto [i, ref] = todo.back(); todo.pop_back();
-                    if (i >= nn) { tl[i - nn] = tr.leaf_value[~ref]; continue; }      // depth D reached: `ref` is a leaf here (no tree is deeper than D)
-                    if (ref >= 0) {
-                        tn[i] = (uint32_t)(tr.feat[ref] & 0xFF) | ((uint32_t)(tr.theta[ref] + 1) & 0x1FFu) << 8 | (uint32_t)(tr.dleft[ref] ? 1 : 0) << 17;
-                        todo.emplace_back(2 * i + 1, tr.left[ref]); todo.emplace_back(2 * i + 2, tr.right[ref]);
-                    } else { tn[i] = pass; todo.emplace_back(2 * i + 1, ref); todo.emplace_back(2 * i + 2, ref); }
+                uint32_t* tm = mk.data() + t * S * MW; double* tl = lv2.data() + t * LP;
+                if (tr.L <= 1) { tl[0] = tr.leaf_value.empty() ? 0.0 : tr.leaf_value[0]; continue; }
+                lo.assign(tr.L - 1, 0); mid.assign(tr.L - 1, 0);
+                // iterative in-order traversal: (ref, state) with state 0 = enter, 1 = left subtree done
+                int next_leaf = 0;
+                std::vector<std::pair<int, int>> st; st.emplace_back(0, 0);
+                while (!st.empty()) {
+                    auto& top = st.back();
+                    const int ref = top.first;
+                    if (ref < 0) { tl[next_leaf++] = tr.leaf_value[~ref]; st.pop_back(); continue; }
+                    if (top.second == 0) { top.second = 1; lo[ref] = next_leaf; st.emplace_back(tr.left[ref], 0); }
+                    else { mid[ref] = next_leaf; const int r = tr.right[ref]; st.pop_back(); st.emplace_back(r, 0); }
+                }
+                for (int j = 0; j < tr.L - 1; ++j) {
+                    // mask of node j: zeros for the leaves of its left subtree
+                    uint32_t w[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                    for (int b = lo[j]; b < mid[j]; ++b) w[b >> 5] &= ~(1u << (b & 31));
+                    const int f = tr.feat[j], nb = foff[f + 1] - foff[f] - 1;
+                    // the test of node j is FALSE (the row goes right) for bins above its threshold, and for a missing value unless it defaults left
+                    for (int b = std::max(tr.theta[j] + 1, 0); b < nb; ++b) for (int q = 0; q < MW; ++q) tm[(size_t)(foff[f] + b) * MW + q] &= w[q];
+                    if (!tr.dleft[j]) for (int q = 0; q < MW; ++q) tm[(size_t)(foff[f] + nb) * MW + q] &= w[q];
                 }
             }
-            dm->cnodes.alloc(cn.size()); dm->cnodes.upload(cn.data(), cn.size(), s);
-            dm->cleaves.alloc(cl.size()); dm->cleaves.upload(cl.data(), cl.size(), s);
-            dm->cdepth = D;
-            HIPCHK(hipStreamSynchronize(s));     // cn / cl are locals
+            dm->qs_masks.alloc(mk.size()); dm->qs_masks.upload(mk.data(), mk.size(), s);
+            dm->qs_leaves.alloc(lv2.size()); dm->qs_leaves.upload(lv2.data(), lv2.size(), s);
+            dm->qs_foff.alloc(foff.size()); dm->qs_foff.upload(foff.data(), foff.size(), s);
+            dm->qs_S = S; dm->qs_MW = MW;
+            HIPCHK(hipStreamSynchronize(s));     // the vectors are locals
         }
     }
     dm->nodes.alloc(nodes.size()); dm->nodes.upload(nodes.data(), nodes.size(), s);
@@ -1140,12 +1244,22 @@ void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_c
     DevBuf<uint4>& rec = sc.rec; DevBuf<double>& raw = sc.raw;
     hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes, Ntab, row0, n,
                        d_feat_cols ? d_feat_cols : dm->ident.p, dm->n_codes.p, dm->lut_off.p, dm->lut.p, dm->miss.p, F, nchunk, rec.p);
-    if (dm->cdepth > 0 && F <= 255) {   // fixed-depth, divergence-free walk over the complete-tree form
-        const int D = dm->cdepth;
-        const size_t lds = (size_t)2 * PT_TB * (1 << D) * (4 + 8);
-        const dim3 grid((unsigned)((n + 256 * PT_ROWS - 1) / (256 * PT_ROWS)), K);
-        if (nchunk == 1) hipLaunchKernelGGL(k_predict_fixed<true>, grid, dim3(256), lds, s, reinterpret_cast<const uint8_t*>(rec.p), n, dm->cnodes.p, dm->cleaves.p, m->n_iter, K, D, raw.p);
-        else hipLaunchKernelGGL(k_predict_fixed<false>, grid, dim3(256), lds, s, reinterpret_cast<const uint8_t*>(rec.p), n, dm->cnodes.p, dm->cleaves.p, m->n_iter, K, D, raw.p);
+    const char* pe = getenv("RGBM_PREDICTOR"); const bool force_walk = pe && strcmp(pe, "walk") == 0;   // tests: the index-linked walk
+    bool qs = dm->qs_MW > 0 && !force_walk;
+    int qs_tb = 8;
+    if (qs) {   // trees per LDS stage: two stages of (masks + leaves) within 48 KB
+        const size_t per_tree = (size_t)dm->qs_S * dm->qs_MW * 4 + (size_t)32 * dm->qs_MW * 8;
+        while (qs_tb > 1 && 2 * qs_tb * per_tree + 16 > 48 * 1024) --qs_tb;
+        if (2 * qs_tb * per_tree + 16 > 48 * 1024) qs = false;
+    }
+    if (qs) {   // bit-vector scoring: no tree walk at all
+        const size_t lds = (size_t)2 * qs_tb * ((size_t)dm->qs_S * dm->qs_MW * 4 + (size_t)32 * dm->qs_MW * 8) + 16;
+        const dim3 grid((unsigned)((n + 256 * QS_ROWS - 1) / (256 * QS_ROWS)), K);
+        const uint8_t* r8 = reinterpret_cast<const uint8_t*>(rec.p);
+#define RGBM_QS(MW, FM) hipLaunchKernelGGL((k_predict_qs<MW, FM>), grid, dim3(256), lds, s, r8, n, dm->qs_masks.p, dm->qs_leaves.p, dm->qs_foff.p, F, dm->qs_S, qs_tb, m->n_iter, K, raw.p)
+        if (dm->qs_MW == 1) { if (F <= 16) RGBM_QS(1, 16); else RGBM_QS(1, 32); }
+        else { if (F <= 16) RGBM_QS(2, 16); else RGBM_QS(2, 32); }
+#undef RGBM_QS
     }
     else if (nchunk == 1) hipLaunchKernelGGL(k_predict_raw<true>, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,
                                         dm->nodes.p, dm->leaf_value.p, m->n_iter, K, dm->node_stride, dm->leaf_stride, raw.p);

@@ -915,82 +915,86 @@ __global__ __launch_bounds__(256) void k_predict_raw(const uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_predict_fixed: GBDT::PredictRaw without divergence.  Every tree of the model is stored a second time as a COMPLETE binary tree
-// of the model's depth D (<= 7; children of node i at 2i+1 / 2i+2, a leaf above depth D becomes a chain of pass-through nodes that
-// ends in copies of its value): 2^D - 1 node words (feature | theta+1 << 8 | default-left << 17) and 2^D leaf values.  A workgroup
-// owns 256 x ROWS rows of ONE class; the trees of that class are staged through LDS, PT_TB at a time, double-buffered, and every lane
-// walks them for its rows: D x (one LDS read, a byte select on the record in registers, two compares) and one LDS read of the leaf.
-// No data-dependent loads from memory, no loop whose trip count differs between lanes, ROWS independent walks per lane to cover the
-// LDS latency.  (The walk over the index-linked nodes, k_predict_raw, was latency-bound: ~150 lane-cycles per node visit)
-// The leaf values are added in iteration order, as the oracle does: raw scores are bit-identical.
-//   grid (ceil(n / (256 ROWS)), K), block 256.
+// k_predict_qs: GBDT::PredictRaw without walking the trees (bit-vector scoring over BINNED features, after QuickScorer, Lucchese et
+// al., SIGIR 2015).  Number the leaves of a tree from left to right.  Every internal node owns a bit mask with zeros for the leaves
+// of its LEFT subtree; a row's exit leaf is the lowest set bit of the AND of the masks of all nodes whose test is FALSE for the row.
+// Features are bin codes here, so per tree and feature the AND over "all false nodes on this feature" is a function of the bin alone
+// and is tabulated on the host: M[tree][feature][bin] (one more entry per feature for a missing / unseen value, which goes the node's
+// default direction).  Scoring a (row, tree) pair is then F independent LDS lookups, F ANDs, one find-first-bit and one leaf-value
+// lookup: no data-dependent chain, no divergence, ~2 instructions per feature.  (The walk over index-linked nodes, k_predict_raw, is
+// latency-bound at ~150 lane-cycles per node visit; a fixed-depth walk over complete-tree copies was built first in round 3 and was
+// SLOWER -- 7 visits of ~22 instructions against ~5 data-dependent ones.)
+//   A workgroup owns 256 x QS_ROWS rows of ONE class; a row's table offsets (feature base + bin) are computed once and stay in
+//   registers; the tables of that class's trees are staged through LDS, `tb` at a time, double-buffered.  The leaf values are added
+//   in iteration order, as the oracle does: raw scores are bit-identical.
+//   grid (ceil(n / (256 QS_ROWS)), K), block 256.  MW = mask words (1: <= 32 leaves, 2: <= 64), FMAX = 16 | 32 features.
 // ------------------------------------------------------------------------------------------------
-constexpr int PT_TB = 8;         // trees per LDS stage
-constexpr int PT_ROWS = 2;       // rows per lane
-template <bool ONE_CHUNK>
-__global__ __launch_bounds__(256) void k_predict_fixed(const uint8_t* __restrict__ rec8, long long n, const uint32_t* __restrict__ cnodes /* [T][2^D - 1] */,
-                                                       const double* __restrict__ cleaves /* [T][2^D] */, int n_iter, int K, int D,
-                                                       double* __restrict__ raw /* [K][n] */) {
+constexpr int QS_ROWS = 2;
+template <int MW, int FMAX>
+__global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ rec8, long long n, const uint32_t* __restrict__ masks /* [T][S * MW] */,
+                                                    const double* __restrict__ leaves /* [T][32 * MW] */, const int32_t* __restrict__ foff /* [F + 1] */,
+                                                    int F, int S, int tb_n /* trees per LDS stage */, int n_iter, int K, double* __restrict__ raw /* [K][n] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nn = (1 << D) - 1, nl = 1 << D;
-    const int stage_words = PT_TB * (nn + 1);                     // node words of a stage, padded to 2^D per tree
-    uint32_t* sn = reinterpret_cast<uint32_t*>(smem);             // [2][PT_TB][2^D] node words
-    double* sl = reinterpret_cast<double*>(sn + 2 * stage_words); // [2][PT_TB][2^D] leaf values
+    constexpr int LP = 32 * MW;
+    const int tree_words = S * MW;                                   // mask words of a tree
+    uint32_t* sm = reinterpret_cast<uint32_t*>(smem);                // [2][tb_n][S * MW]
+    double* sl = reinterpret_cast<double*>(sm + 2 * tb_n * tree_words + ((2 * tb_n * tree_words) & 1));   // [2][tb_n][LP], 8-byte aligned
     const int k = blockIdx.y, tid = threadIdx.x;
-    const long long base = (long long)blockIdx.x * (256 * PT_ROWS);
-    uint4 r[PT_ROWS]; long long row[PT_ROWS]; double s[PT_ROWS];
+    const long long base = (long long)blockIdx.x * (256 * QS_ROWS);
+    int off[QS_ROWS][FMAX]; long long row[QS_ROWS]; double s[QS_ROWS];
 #pragma unroll
-    for (int q = 0; q < PT_ROWS; ++q) {
-        row[q] = base + q * 256 + tid;
-        const long long rc = row[q] < n ? row[q] : n - 1;
-        r[q] = ONE_CHUNK ? reinterpret_cast<const uint4*>(rec8)[rc] : make_uint4(0, 0, 0, 0);
-        row[q] = rc; s[q] = 0.0;
+    for (int q = 0; q < QS_ROWS; ++q) {
+        const long long r0 = base + q * 256 + tid;
+        row[q] = r0 < n ? r0 : n - 1; s[q] = 0.0;
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) {
+            int o = 0;
+            if (f < F) {
+                const int fb = foff[f], nb = foff[f + 1] - fb - 1;                                   // nb value bins, entry nb = missing
+                const unsigned bin = rec8[((long long)(f >> 4) * n + row[q]) * 16 + (f & 15)];
+                o = (fb + (int)(bin < (unsigned)nb ? bin : (unsigned)nb)) * MW * 4;                 // byte offset inside a tree's table
+            }
+            off[q][f] = o;
+        }
     }
     auto stage = [&](int it0, int buf) {
-        for (int i = tid; i < PT_TB * nl; i += 256) {
-            const int tb = i >> D, j = i & (nl - 1), it = it0 + tb;
-            if (it < n_iter) {
-                const long long t = (long long)it * K + k;
-                if (j < nn) sn[buf * stage_words + tb * nl + j] = cnodes[t * nn + j];
-                sl[(buf * PT_TB + tb) * nl + j] = cleaves[t * nl + j];
-            }
+        for (int tb = 0; tb < tb_n; ++tb) {
+            const int it = it0 + tb;
+            if (it >= n_iter) break;
+            const long long t = (long long)it * K + k;
+            for (int i = tid; i < tree_words; i += 256) sm[(buf * tb_n + tb) * tree_words + i] = masks[t * tree_words + i];
+            if (tid < LP) sl[(buf * tb_n + tb) * LP + tid] = leaves[t * LP + tid];
         }
     };
     stage(0, 0);
     __syncthreads();
     int buf = 0;
-    for (int it0 = 0; it0 < n_iter; it0 += PT_TB, buf ^= 1) {
-        if (it0 + PT_TB < n_iter) stage(it0 + PT_TB, buf ^ 1);
-        const int nt = (n_iter - it0) < PT_TB ? (n_iter - it0) : PT_TB;
+    for (int it0 = 0; it0 < n_iter; it0 += tb_n, buf ^= 1) {
+        if (it0 + tb_n < n_iter) stage(it0 + tb_n, buf ^ 1);
+        const int nt = (n_iter - it0) < tb_n ? (n_iter - it0) : tb_n;
         for (int tb = 0; tb < nt; ++tb) {
-            const uint32_t* tn = sn + buf * stage_words + tb * nl;
-            const double* tl = sl + (buf * PT_TB + tb) * nl;
-            int node[PT_ROWS];
+            const unsigned char* tm = reinterpret_cast<const unsigned char*>(sm + (buf * tb_n + tb) * tree_words);
+            const double* tl = sl + (buf * tb_n + tb) * LP;
 #pragma unroll
-            for (int q = 0; q < PT_ROWS; ++q) node[q] = 0;
-            for (int d = 0; d < D; ++d) {
+            for (int q = 0; q < QS_ROWS; ++q) {
+                uint32_t v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
 #pragma unroll
-                for (int q = 0; q < PT_ROWS; ++q) {
-                    const uint32_t w = tn[node[q]];
-                    const unsigned f = w & 0xFFu;
-                    unsigned bin;
-                    if (ONE_CHUNK) {
-                        const bool hi = (f & 8u) != 0u;
-                        const uint32_t lo32 = hi ? r[q].z : r[q].x, hi32 = hi ? r[q].w : r[q].y;
-                        bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);
-                    } else bin = rec8[((long long)(f >> 4) * n + row[q]) * 16 + (f & 15u)];
-                    const uint32_t is_nan = bin == 255u ? 1u : 0u, lt = bin < ((w >> 8) & 0x1FFu) ? 1u : 0u;
-                    const uint32_t left = (is_nan & (w >> 17)) | ((is_nan ^ 1u) & lt);
-                    node[q] = 2 * node[q] + 2 - (int)(left & 1u);
+                for (int f = 0; f < FMAX; ++f) {
+                    if (f < F) {                                       // uniform
+                        if (MW == 1) v0 &= *reinterpret_cast<const uint32_t*>(tm + off[q][f]);
+                        else { const uint2 m2 = *reinterpret_cast<const uint2*>(tm + off[q][f]); v0 &= m2.x; v1 &= m2.y; }
+                    }
                 }
+                int leaf;
+                if (MW == 1) leaf = __ffs((int)v0) - 1;
+                else leaf = v0 ? __ffs((int)v0) - 1 : 32 + __ffs((int)v1) - 1;
+                s[q] += tl[leaf];
             }
-#pragma unroll
-            for (int q = 0; q < PT_ROWS; ++q) s[q] += tl[node[q] - nn];
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int q = 0; q < PT_ROWS; ++q) if (base + q * 256 + tid < n) raw[(long long)k * n + row[q]] = s[q];
+    for (int q = 0; q < QS_ROWS; ++q) if (base + q * 256 + tid < n) raw[(long long)k * n + row[q]] = s[q];
 }
 
 // ConvertOutput + arg-max (first maximum).  proba may be null (labels only).

@@ -123,12 +123,13 @@ __host__ __device__ inline long long mt_fixed_bytes() {
 // ------------------------------------------------------------------------------------------------
 // k_level_init: per class tree, start of a boosting iteration
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, SNode* __restrict__ nodes,
+__global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, SNode* __restrict__ nodes, int32_t* __restrict__ count,
                                                    const unsigned int* __restrict__ n_in_ptr, long long n_train, LevelConst c) {
     const int k = blockIdx.x, lane = lane_id();
     LvPlan* pp = &plan[k];
     const long long n_in = n_in_ptr ? (long long)n_in_ptr[0] : n_train;
-    for (int i = lane; i < 256; i += 64) { pp->route0[i] = 0; pp->route1[i] = 0xFFFFFFFFu; }
+    // the child row counts of the new tree start at zero (here rather than in a hipMemsetAsync: the boosting loop is kernels only)
+    for (int i = lane; i < 256; i += 64) { pp->route0[i] = 0; pp->route1[i] = 0xFFFFFFFFu; count[(long long)k * 256 + i] = 0; }
     if (lane == 0) {
         pp->n_nodes = 1; pp->lvl_first = 0; pp->lvl_end = 1; pp->n_exp = 0; pp->n_built = 1;
         pp->error = 0; pp->child_first = 1; pp->n_hslots = 1; pp->n_in = n_in;

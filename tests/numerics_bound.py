@@ -43,8 +43,9 @@ def parse_trees(blob):
         t = {}
         for name in ("feat", "theta", "dleft", "left", "right"):
             t[name] = np.frombuffer(blob, np.int32, n, p); p += 4 * n
-        p += 8 * n
-        t["leaf_value"] = np.frombuffer(blob, np.float64, L, p); p += 8 * L + 4 * L
+        t["gain"] = np.frombuffer(blob, np.float64, n, p); p += 8 * n
+        t["leaf_value"] = np.frombuffer(blob, np.float64, L, p); p += 8 * L
+        t["leaf_count"] = np.frombuffer(blob, np.int32, L, p); p += 4 * L
         trees.append(t)
     return K, n_iter, trees
 
