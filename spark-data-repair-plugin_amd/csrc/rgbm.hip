@@ -791,11 +791,20 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 }
             }
         }
-        HIPCHK(hipFuncSetAttribute((const void*)k_level_root, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+        // once per process and device: the attribute belongs to the function, not to the call, and other threads are launching these
+        // kernels while a new training call sets up
+        {
+            static std::mutex attr_mu; static std::vector<char> attr_done(64, 0);
+            std::lock_guard<std::mutex> lk(attr_mu);
+            if (!attr_done[tab.device & 63]) {
+                HIPCHK(hipFuncSetAttribute((const void*)k_level_root, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
 #define RGBM_MT_ATTR(NCHR, BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
                                 HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
-        RGBM_MT_ATTR(0, false); RGBM_MT_ATTR(1, false); RGBM_MT_ATTR(2, false); RGBM_MT_ATTR(0, true); RGBM_MT_ATTR(1, true); RGBM_MT_ATTR(2, true);
+                RGBM_MT_ATTR(0, false); RGBM_MT_ATTR(1, false); RGBM_MT_ATTR(2, false); RGBM_MT_ATTR(0, true); RGBM_MT_ATTR(1, true); RGBM_MT_ATTR(2, true);
 #undef RGBM_MT_ATTR
+                attr_done[tab.device & 63] = 1;
+            }
+        }
     }
     const size_t NT = (size_t)NE * K;
     DevBuf<int32_t> t_L(NT), t_feat(NT * (NL - 1)), t_theta(NT * (NL - 1)), t_dleft(NT * (NL - 1)), t_left(NT * (NL - 1)), t_right(NT * (NL - 1)), t_cnt(NT * NL);
