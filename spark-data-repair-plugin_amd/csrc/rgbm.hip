@@ -982,7 +982,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
             hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
-            if (dp) { HIPCHK(hipMemcpyAsync(d_count_g.p, d_count.p, (size_t)K * 256 * 4, hipMemcpyDeviceToDevice, s)); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
+            if (dp) { hipLaunchKernelGGL(k_copy_i32, dim3(K), dim3(256), 0, s, d_count.p, d_count_g.p, (long long)K * 256); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
             hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, d_it.p, tc);
             trace_level(p.max_depth);
             trace_sum("score", d_score.p, (size_t)K * N * 8); trace_sum("node", d_node.p, (size_t)K * lc.NS);
@@ -1010,8 +1010,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     // other threads train fail or replay wrongly (20 bad models in 150) even with every graph call behind one mutex.
     auto enqueue_bagging = [&]() {
         const long long nrb = (n_train + 1023) / 1024;
-        d_bagcnt.zero(s);
-        hipLaunchKernelGGL(k_bagging, dim3((unsigned)((nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, (long long)n_train, p.bagging_fraction, d_sorted_rows.p, d_inbag.p);
+        hipLaunchKernelGGL(k_bagging, dim3((unsigned)((nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, (long long)n_train, p.bagging_fraction, d_sorted_rows.p, d_inbag.p, d_bagcnt.p);
         hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((n_train + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, (long long)n_train, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
     };
     for (int it = 0; it < NE; ++it) {

@@ -826,8 +826,9 @@ __global__ __launch_bounds__(256) void k_stable_compact(const int32_t* __restric
 }
 
 __global__ void k_bagging(unsigned int* __restrict__ rand_state, long long n_train, double fraction, const int32_t* __restrict__ sorted_rows,
-                          uint8_t* __restrict__ row_in_bag /* [N], only training rows are written */) {
+                          uint8_t* __restrict__ row_in_bag /* [N], only training rows are written */, unsigned int* __restrict__ counters /* [2], reset for k_bag_lists */) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) { counters[0] = 0u; counters[1] = 0u; }
     const long long p0 = b * 1024;
     if (p0 >= n_train) return;
     unsigned int x = rand_state[b];
@@ -838,6 +839,12 @@ __global__ void k_bagging(unsigned int* __restrict__ rand_state, long long n_tra
         row_in_bag[sorted_rows[p]] = ((double)f < fraction) ? 1 : 0;
     }
     rand_state[b] = x;
+}
+
+// d_count -> the all-reduce buffer of the row-sharded trainer (a kernel, like everything else in the boosting loop)
+__global__ __launch_bounds__(256) void k_copy_i32(const int32_t* __restrict__ src, int32_t* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 // unstable split of the training rows into the bag list and the out-of-bag list
