@@ -218,7 +218,8 @@ int rgbm_table_shape(const rgbm_table* t, int64_t* n_out, int32_t* c_out, int32_
  * order; inside, the code counts, the per-level histograms and the child row counts are summed with
  * integer all-reduces (RCCL over xGMI, enqueued on the training stream).  All sums are exact integers,
  * so every rank ends with the same model, bit-identical to single-GPU training on the whole table.
- * The communicator belongs to the calling thread.  Level grower only, no bagging / per-row weights. */
+ * The communicator belongs to the calling thread.  Level grower only, no per-row weights; bagging draws per global training-row
+ * position (the shards must hold consecutive row ranges in rank order), so the model is the single-device one. */
 #define RGBM_COMM_ID_BYTES 128
 #define RGBM_FLAG_ROW_SHARDED 1 /* rgbm_params.reserved: this call is one rank of a row-sharded training */
 int rgbm_comm_unique_id(void* id_out /* [RGBM_COMM_ID_BYTES], call on one rank, hand to all */);

@@ -624,8 +624,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     // index-list grower (both are HIP; they produce identical models)
     const bool use_bagging = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
     const bool level_mode = p.max_depth >= 1 && p.max_depth <= LV_MAX_DEPTH && F <= 255 && sw.grower != 2;
-    if (dp && (!level_mode || use_bagging || sample_weight_host))
-        throw std::invalid_argument("row-sharded training supports the level grower (1 <= max_depth <= 7) without bagging / per-row weights");
+    if (dp && (!level_mode || sample_weight_host))
+        throw std::invalid_argument("row-sharded training supports the level grower (1 <= max_depth <= 7) without per-row weights");
     DevBuf<int32_t> d_base; DevBuf<unsigned int> d_counter(1); d_counter.zero(s);
     if (!level_mode || use_bagging) {
         d_base.alloc(n_train);
@@ -835,22 +835,38 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint8_t> d_used(used.size()); d_used.upload(used.data(), used.size(), s);
 
     // bagging state (GBDT::Bagging): stable training-row order, one LCG per 1024 positions
-    DevBuf<int32_t> d_sorted_rows, d_oob; DevBuf<unsigned int> d_blk, d_rand, d_bagcnt; DevBuf<uint8_t> d_inbag;
+    DevBuf<int32_t> d_sorted_rows, d_oob; DevBuf<unsigned int> d_blk, d_rand, d_bagcnt, d_bagcnt_g; DevBuf<uint8_t> d_inbag;
+    long long bag_off = 0, bag_local = 0, bag_nrb = 1;
     if (use_bagging) {
         const long long nblk = (N + 1023) / 1024;
         d_blk.alloc(nblk); d_sorted_rows.alloc(n_train); d_oob.alloc(n_train); d_inbag.alloc(N); d_bagcnt.alloc(2);
         hipLaunchKernelGGL(k_block_count, dim3((unsigned)nblk), dim3(256), 0, s, d_ycol, (long long)N, d_blk.p);
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, d_blk.p, nblk);
         hipLaunchKernelGGL(k_stable_compact, dim3((unsigned)nblk), dim3(256), 0, s, d_ycol, (long long)N, d_blk.p, d_sorted_rows.p);
-        const long long nrb = (n_train + 1023) / 1024;
+        if (dp) {
+            // GBDT::Bagging draws per training-row POSITION (ascending row order over the whole table): this rank's rows hold the positions
+            // [bag_off, bag_off + bag_local), bag_off = training rows of the ranks before it (one all-reduce of a per-rank count vector)
+            unsigned int h_local = 0; d_counter.download(&h_local, 1, s); stream_sync_watchdog(s);
+            bag_local = (long long)h_local;
+            std::vector<long long> rc((size_t)g_comm.nranks, 0); rc[(size_t)g_comm.rank] = bag_local;
+            DevBuf<long long> d_rc(rc.size()); d_rc.upload(rc.data(), rc.size(), s);
+            all_reduce(d_rc.p, rc.size(), AR_I64, s);
+            d_rc.download(rc.data(), rc.size(), s); stream_sync_watchdog(s);
+            long long tot = 0;
+            for (int r = 0; r < g_comm.nranks; ++r) { if (r < g_comm.rank) bag_off += rc[(size_t)r]; tot += rc[(size_t)r]; }
+            if (tot != n_train) throw std::runtime_error("row-sharded bagging: the ranks' training-row counts do not add up");
+            d_bagcnt_g.alloc(2);
+        } else bag_local = n_train;
+        bag_nrb = std::max<long long>(1, (bag_off + bag_local + 1023) / 1024 - bag_off / 1024);
         LgbRand sr2((uint32_t)p.seed); sr2.rnd16();
         const int bagging_seed = sr2.rnd16();
-        std::vector<unsigned int> st(nrb);
-        for (long long b = 0; b < nrb; ++b) st[b] = (unsigned int)(bagging_seed + b);
-        d_rand.alloc(nrb); d_rand.upload(st.data(), nrb, s);
+        std::vector<unsigned int> st(bag_nrb);
+        for (long long b = 0; b < bag_nrb; ++b) st[b] = (unsigned int)(bagging_seed + bag_off / 1024 + b);
+        d_rand.alloc(bag_nrb); d_rand.upload(st.data(), bag_nrb, s);
         HIPCHK(hipStreamSynchronize(s));
     }
-    const unsigned int* n_in_ptr = use_bagging ? d_bagcnt.p : nullptr;
+    // rows in the bag of the current iteration, over ALL ranks when row-sharded (the root count of every tree)
+    const unsigned int* n_in_ptr = use_bagging ? (dp ? d_bagcnt_g.p : d_bagcnt.p) : nullptr;
 
     if (!level_mode) {
         if (lds_hist > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
@@ -1009,9 +1025,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     // the host launches), 24 concurrent host threads gain nothing (8.8 vs 9.2 ms per 60-iteration fit), and captures made while
     // other threads train fail or replay wrongly (20 bad models in 150) even with every graph call behind one mutex.
     auto enqueue_bagging = [&]() {
-        const long long nrb = (n_train + 1023) / 1024;
-        hipLaunchKernelGGL(k_bagging, dim3((unsigned)((nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, (long long)n_train, p.bagging_fraction, d_sorted_rows.p, d_inbag.p, d_bagcnt.p);
-        hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((n_train + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, (long long)n_train, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
+        hipLaunchKernelGGL(k_bagging, dim3((unsigned)((bag_nrb + 63) / 64)), dim3(64), 0, s, d_rand.p, bag_local, p.bagging_fraction, d_sorted_rows.p, d_inbag.p, d_bagcnt.p,
+                           bag_off, (long long)n_train);
+        hipLaunchKernelGGL(k_bag_lists, dim3((unsigned)((std::max<long long>(bag_local, 1) + 255) / 256)), dim3(256), 0, s, d_sorted_rows.p, bag_local, d_inbag.p, d_base.p, d_oob.p, d_bagcnt.p);
+        if (dp) {
+            hipLaunchKernelGGL(k_copy_i32, dim3(1), dim3(256), 0, s, reinterpret_cast<const int32_t*>(d_bagcnt.p), reinterpret_cast<int32_t*>(d_bagcnt_g.p), 2ll);
+            all_reduce(d_bagcnt_g.p, 2, AR_U32, s);
+        }
     };
     for (int it = 0; it < NE; ++it) {
         if (use_bagging && it % p.bagging_freq == 0) enqueue_bagging();

@@ -825,18 +825,22 @@ __global__ __launch_bounds__(256) void k_stable_compact(const int32_t* __restric
     }
 }
 
-__global__ void k_bagging(unsigned int* __restrict__ rand_state, long long n_train, double fraction, const int32_t* __restrict__ sorted_rows,
-                          uint8_t* __restrict__ row_in_bag /* [N], only training rows are written */, unsigned int* __restrict__ counters /* [2], reset for k_bag_lists */) {
+__global__ void k_bagging(unsigned int* __restrict__ rand_state, long long n_local, double fraction, const int32_t* __restrict__ sorted_rows,
+                          uint8_t* __restrict__ row_in_bag /* [N], only training rows are written */, unsigned int* __restrict__ counters /* [2], reset for k_bag_lists */,
+                          long long off /* global position of this rank's first training row (row-sharded; else 0) */, long long n_global) {
+    // LightGBM draws one number per training-row POSITION, from one LCG per 1024 positions (seed = bagging_seed + block).  A row shard
+    // holds the positions [off, off + n_local): it walks the blocks that overlap them from their first position on (a block that
+    // straddles two ranks is advanced by both), so that every rank keeps the stream of every block it touches in step.
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) { counters[0] = 0u; counters[1] = 0u; }
-    const long long p0 = b * 1024;
-    if (p0 >= n_train) return;
+    const long long g0 = (off / 1024 + b) * 1024;
+    if (g0 >= off + n_local || g0 >= n_global) return;
     unsigned int x = rand_state[b];
-    const long long p1 = p0 + 1024 < n_train ? p0 + 1024 : n_train;
-    for (long long p = p0; p < p1; ++p) {
+    const long long g1 = g0 + 1024 < n_global ? g0 + 1024 : n_global;
+    for (long long g = g0; g < g1; ++g) {
         x = 214013u * x + 2531011u;
         float f = (float)((x >> 16) & 0x7FFF) / 32768.0f;
-        row_in_bag[sorted_rows[p]] = ((double)f < fraction) ? 1 : 0;
+        if (g >= off && g < off + n_local) row_in_bag[sorted_rows[g - off]] = ((double)f < fraction) ? 1 : 0;
     }
     rand_state[b] = x;
 }

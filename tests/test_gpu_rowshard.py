@@ -106,7 +106,7 @@ def test_rccl_world_of_one():
     assert N.comm_info()["kind"] == 0
 
 
-def test_row_sharded_rejects_bagging_and_leafwise():
+def test_row_sharded_rejects_the_leafwise_grower():
     from repair import _native as N
     dirty, clean, cards = make_table(4000, 5, seed=83)
     group = N.LocalGroup(1)
@@ -114,11 +114,29 @@ def test_row_sharded_rejects_bagging_and_leafwise():
     try:
         tab = N.Table(dirty, cards)
         with pytest.raises(N.RepairGbmError):
-            tab.train(1, [0, 2, 3, 4], objective=1, num_class=int(cards[1]), n_estimators=2, bagging_fraction=0.5, bagging_freq=1, row_sharded=True)
-        with pytest.raises(N.RepairGbmError):
             tab.train(1, [0, 2, 3, 4], objective=1, num_class=int(cards[1]), n_estimators=2, max_depth=-1, row_sharded=True)
     finally:
         N.comm_finalize()
+
+
+@pytest.mark.parametrize("target,bounds,kw", [
+    (4, [0, 9000, 20000], dict(bagging_fraction=0.6, bagging_freq=2)),
+    (5, [0, 3000, 3500, 14000, 20000], dict(bagging_fraction=0.5, bagging_freq=1, feature_fraction=0.7)),   # shard borders inside a 1024-position block
+    (0, [0, 1, 20000], dict(bagging_fraction=0.8, bagging_freq=3)),
+    (2, [0, 700, 20000], dict(bagging_fraction=0.55, bagging_freq=1)),                                       # a shard smaller than one block
+])
+def test_bagging_under_row_sharding(target, bounds, kw):
+    """GBDT::Bagging draws per training-row position over the WHOLE table: every rank walks the LCG blocks that overlap its positions
+    and the bag size is summed over the ranks -- same model as on one device (and, by the grower tests, as the oracle)."""
+    from repair import _native as N
+    dirty, clean, cards = make_table(20000, 8, seed=89, null_ratio=0.03)
+    feats = [c for c in range(8) if c != target]
+    K = int(cards[target])
+    cw = balanced_weights(dirty[target], K)
+    kw = dict(kw, objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=7, learning_rate=0.2)
+    single = N.Table(dirty, cards).train(target, feats, class_weight=cw, **kw).save()
+    for r, b in enumerate(_train_sharded(dirty, cards, bounds, target, feats, cw, kw)):
+        assert b == single, "rank %d of %d differs from the single-device model" % (r, len(bounds) - 1)
 
 
 # ---- real multi-process RCCL (needs two GPUs: skipped on the one-GPU test box, run by whoever has the 8-GPU node) ------------
