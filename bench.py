@@ -91,7 +91,9 @@ def cpu_baseline(cols, seed, targets, steps_full, budget_s=25.0):
     out = dict(value=cells / max((t_train + t_infer) * scale, 1e-9), unit="repaired cells/sec", cores=min(nproc, par * per_fit), kind="port",
                nproc=nproc,
                sample="%d-row sample x %d cols, %d targets: %d fits in parallel x %d OpenMP threads each (feature-parallel histograms), "
-                      "%d of %d boosting iterations timed (train %.2fs + single-threaded chained repair %.2fs), time scaled x%.1f"
+                      "%d of %d boosting iterations timed (train %.2fs + single-threaded chained repair %.2fs), time scaled x%.1f; "
+                      "cells/s of the sample stands for the full table only as far as cost is linear in rows (histogram build and repair are; "
+                      "the per-node split search is not and is amortised better on the full table)"
                       % (n, cols, len(targets), par, per_fit, iters, steps_full, t_train, t_infer, scale))
     # ---- B2: sklearn HGB on the same sample, all cores, as many targets as the time budget allows (cost-weighted scale-up)
     try:
