@@ -117,16 +117,20 @@ def chained_repair(engine, table, models, targets, feats_l, row_begin, n_rows, y
     return labels, probs, values
 
 
-def _train_concurrency(engine, table, costs, requested):
+def _train_concurrency(engine, table, costs, requested, search_fits=0):
     """How many target models train at once: `requested` (or RGBM_TARGET_CONCURRENCY, default 6: measured on the 10M x 16 job,
     60 iterations: 79.7 ms per step with 4 in flight, 76.2-76.6 with 6, 76.3-76.7 with 8), capped so that the largest `n` models
-    together stay within half of the device memory."""
+    together stay within half of the device memory.  A target with a hyper-parameter search in front of its final fit keeps
+    `search_fits` fold fits in flight of its own (run_search), each on two thirds of the rows next to its two gathered fold tables
+    (4 B per cell): they are charged to the target."""
     import os
     n = int(requested if requested is not None else os.environ.get("RGBM_TARGET_CONCURRENCY", "6"))
     if n <= 1 or getattr(engine, "name", "") != "hip":
         return 1
     budget = 0.5 * getattr(engine, "device_memory_bytes", lambda: 256e9)()
-    need = sorted((26.0 * c for _, c in costs), reverse=True)       # cost = class trees x rows
+    per_unit = 26.0 * (1.0 + 0.67 * max(0, int(search_fits)))
+    fold_tables = 4.0 * float(getattr(table, "n", 0)) * float(getattr(table, "c", 0)) * max(0, int(search_fits))
+    need = sorted((per_unit * c + fold_tables for _, c in costs), reverse=True)       # cost = class trees x rows
     while n > 1 and sum(need[:n]) > budget:
         n -= 1
     return n
@@ -181,7 +185,8 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     # class tree each).  The row-sharded targets stay on THIS thread, one after another in the same order on every rank (the
     # communicator belongs to the thread, and one collective sequence per process cannot dead-lock against another).  The models do
     # not depend on any of this.
-    conc = _train_concurrency(engine, train_table, [c for c in costs if c[0] in set(mine)] + list(big), train_concurrency)
+    conc = _train_concurrency(engine, train_table, [c for c in costs if c[0] in set(mine)] + list(big), train_concurrency,
+                              search_fits=getattr(param_search, "fits_in_flight", 0) if param_search is not None else 0)
     pool, futs = None, {}
     if conc > 1 and len(mine) + len(big) > 1 and mine:
         from concurrent.futures import ThreadPoolExecutor

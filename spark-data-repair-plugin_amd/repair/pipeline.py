@@ -217,6 +217,10 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
     if search_opts is not None:
         def search(t, tab):
             return search_on_table(engine, tab, t, n_codes, base_params, search_opts, y_value=y_values.get(t))
+        # fold fits a search keeps in flight per target (run_search: model.hp.batch_size evaluations x model.cv.n_splits folds): run_job
+        # budgets device memory with it
+        from repair.train import search_fits_in_flight
+        search.fits_in_flight = search_fits_in_flight(search_opts)
     res = run_job(engine, table, dirty_tab, n_codes, targets, label_counts, base_params, want_stats=want_stats,
                   y_values=y_values, integral=integral, train_tables=train_tables, param_search=search)
     # flatten + join with the error cells (RepairMiscApi.scala:41-49, model.py:1398-1401)

@@ -99,6 +99,12 @@ def _cv_loss(model: Any, X: pd.DataFrame, y: pd.Series, is_discrete: bool, n_spl
     return -float(np.mean(scores))
 
 
+def search_fits_in_flight(opts: Dict[str, str]) -> int:
+    """Fold fits `run_search` keeps in flight at once: `model.hp.batch_size` evaluations x `model.cv.n_splits` folds."""
+    g = lambda o: get_option_value(opts, *o)  # noqa: E731
+    return max(1, int(g(_opt_batch_size))) * int(g(_opt_n_splits))
+
+
 def run_search(opts: Dict[str, str], n_folds_of: Any, fold_score: Any) -> Tuple[Dict[str, Any], float, int]:
     """The hyper-parameter search loop of train.py:133-209, independent of WHERE a fit runs.
 
