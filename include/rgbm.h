@@ -80,8 +80,8 @@ typedef struct {
     int64_t root_rows;       /* of which full-table (root) scans */
     double root_ms;          /* hist_build time spent in root scans */
     int64_t trees;           /* trees grown */
-    double route_ms;         /* level grower, split mode: time of the k_level_route launches (DataPartition::Split of a level) */
-    int64_t route_launches;
+    double route_ms;         /* always 0 since numerics version 200: DataPartition::Split of a level is part of the level pass (k_level_mt), */
+    int64_t route_launches;  /* whose time is in hist_ms; the fields keep the struct layout of version 102 */
 } rgbm_train_stats;
 
 /* Number of usable HIP devices (0 if none). */

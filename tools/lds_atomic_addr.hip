@@ -4,7 +4,7 @@
 //              addr = c_j(lane) + half_j(record)                                                 -> 1 VALU (SDWA add) per atomic
 //   variant 2  no atomics at all (loads + the arithmetic of variant 0 folded into a checksum): the streaming floor
 // Each workgroup (1024 threads, one per CU) streams `rows` synthetic records from HBM with a one-tile prefetch, like
-// k_level_pass.  Build: hipcc --offload-arch=gfx950 -O3 tools/lds_atomic_addr.hip -o tools/lds_atomic_addr
+// k_level_mt.  Build: hipcc --offload-arch=gfx950 -O3 tools/lds_atomic_addr.hip -o tools/lds_atomic_addr
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -35,6 +35,6 @@ for t in [int(x) for x in a.targets.split(",")]:
             print("target %d K=%d: %.3fs wall, %.1f ms/iter, %.2f ms/tree" % (t, K, dt, dt * 1e3 / a.iters, dt * 1e3 / a.iters / ktrees), flush=True)
             continue
         m, st = res
-        print("target %d K=%d: %.3fs wall, %.1f ms/iter, %.2f ms/tree | hist %.1f ms (%d launches) root %.1f ms route %.1f ms (%d) | rows %.3g bytes %.3g -> hist %.1f GB/s, root %.1f GB/s" % (
-            t, K, dt, dt * 1e3 / a.iters, dt * 1e3 / a.iters / ktrees, st["hist_ms"], st["hist_launches"], st["root_ms"], st.get("route_ms", 0.0), st.get("route_launches", 0), st["hist_rows"], st["hist_bytes"],
+        print("target %d K=%d: %.3fs wall, %.1f ms/iter, %.2f ms/tree | hist %.1f ms (%d launches) root %.1f ms | rows %.3g bytes %.3g -> hist %.1f GB/s, root %.1f GB/s" % (
+            t, K, dt, dt * 1e3 / a.iters, dt * 1e3 / a.iters / ktrees, st["hist_ms"], st["hist_launches"], st["root_ms"], st["hist_rows"], st["hist_bytes"],
             st["hist_bytes"] / max(st["hist_ms"], 1e-9) * 1e-6, st["root_rows"] * (len(feats) + 8) / max(st["root_ms"], 1e-9) * 1e-6), flush=True)
