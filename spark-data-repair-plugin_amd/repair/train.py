@@ -204,22 +204,117 @@ def compute_class_nrow_stdv(y: pd.Series, is_discrete: bool) -> Optional[float]:
     return float(np.std(list(Counter(y).values()))) if is_discrete else None
 
 
+def _ordinal_codes(col: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """OrdinalEncoder of one column: (codes, sorted categories)."""
+    try:
+        cats, codes = np.unique(col, return_inverse=True)
+    except TypeError:      # mixed types: order by the string form
+        keys = np.asarray([str(v) for v in col], dtype=object)
+        _, first, codes = np.unique(keys, return_index=True, return_inverse=True)
+        cats = col[first]
+    return codes.astype(np.int64), cats
+
+
+def smoten_resample(X: pd.DataFrame, y: pd.Series, targets: Dict[Any, int], k_neighbors: int = 5, random_state: int = 42) -> Tuple[pd.DataFrame, pd.Series]:
+    """Restatement of imbalanced-learn 0.8.0's `SMOTEN(random_state, sampling_strategy=dict, k_neighbors).fit_resample` (the
+    reference pins imbalanced-learn==0.8.0, bin/requirements.txt:10, and calls it at train.py:271-274; the package is not installed
+    here, so this follows the published algorithm, Chawla et al. 2002 section 6.2, as that release implements it):
+
+      * every column is nominal: ordinal codes of its sorted distinct values;
+      * Value Difference Metric fitted on ALL rows: p_f(c | v) = share of class c among the rows with value v in feature f;
+        d(a, b) = sum over features of (sum over classes |p_f(c | a_f) - p_f(c | b_f)|) ** 2   (k = 1, r = 2);
+      * per class to grow (`targets`: class -> number of rows it should end up with), in the order given: the k nearest neighbours of
+        every row of the class AMONG the rows of the class (the row itself excluded); a fresh RandomState(random_state) draws, with
+        replacement, the rows to grow from; a new row takes, feature by feature, the most common value among the drawn row's
+        neighbours (ties: the smallest code);
+      * the new rows are appended class by class.
+    Neighbour ties are broken by row position (scikit-learn's brute-force k-neighbours leaves their order to an unstable sort)."""
+    cols = list(X.columns)
+    Xv = X.to_numpy(dtype=object)
+    yv = y.to_numpy()
+    n, F = Xv.shape
+    codes = np.empty((n, F), np.int64)
+    cats = []
+    for j in range(F):
+        codes[:, j], c = _ordinal_codes(Xv[:, j])
+        cats.append(c)
+    classes, y_idx = np.unique(yv, return_inverse=True)
+    proba = []
+    for j in range(F):
+        cnt = np.zeros((len(cats[j]), len(classes)), np.float64)
+        np.add.at(cnt, (codes[:, j], y_idx), 1.0)
+        proba.append(cnt / cnt.sum(axis=1, keepdims=True))
+    new_X, new_y = [], []
+    for klass, n_target in targets.items():
+        rows = np.flatnonzero(yv == klass)
+        n_new = int(n_target) - len(rows)
+        if n_new <= 0 or len(rows) <= k_neighbors:
+            continue
+        Xc = codes[rows]
+        dist = np.zeros((len(rows), len(rows)), np.float64)
+        for j in range(F):
+            pj = proba[j][Xc[:, j]]
+            dist += np.abs(pj[:, None, :] - pj[None, :, :]).sum(axis=2) ** 2
+        np.fill_diagonal(dist, -1.0)          # the row itself comes first and is dropped
+        nn = np.argsort(dist, axis=1, kind="stable")[:, 1:k_neighbors + 1]
+        rs = np.random.RandomState(random_state)
+        picks = rs.choice(np.arange(len(rows)), size=n_new, replace=True)
+        neigh = Xc[nn[picks]]                 # [n_new][k][F]
+        out = np.empty((n_new, F), dtype=object)
+        for j in range(F):
+            counts = np.zeros((n_new, len(cats[j])), np.int64)
+            np.add.at(counts, (np.repeat(np.arange(n_new), k_neighbors), neigh[:, :, j].ravel()), 1)
+            out[:, j] = cats[j][counts.argmax(axis=1)]      # argmax: first maximum = smallest code
+        new_X.append(out); new_y.append(np.full(n_new, klass, dtype=yv.dtype))
+    if not new_X:
+        return X, y
+    Xn = pd.DataFrame(np.concatenate(new_X), columns=cols).astype(X.dtypes.to_dict(), errors="ignore")
+    return pd.concat([X, Xn], ignore_index=True), pd.concat([y, pd.Series(np.concatenate(new_y), name=y.name)], ignore_index=True)
+
+
+def random_under_sample(X: pd.DataFrame, y: pd.Series, targets: Dict[Any, int], random_state: int = 42) -> Tuple[pd.DataFrame, pd.Series]:
+    """imbalanced-learn 0.8.0's `RandomUnderSampler(random_state, sampling_strategy=dict).fit_resample` (reference train.py:284-286): one
+    RandomState, the classes in sorted order, `targets[c]` rows of class c drawn without replacement, the other classes whole."""
+    rs = np.random.RandomState(random_state)
+    yv = y.to_numpy()
+    keep = []
+    for klass in np.unique(yv):
+        rows = np.flatnonzero(yv == klass)
+        if klass in targets:
+            rows = rows[rs.choice(np.arange(len(rows)), size=int(targets[klass]), replace=False)]
+        keep.append(rows)
+    idx = np.concatenate(keep)
+    return X.iloc[idx].reset_index(drop=True), y.iloc[idx].reset_index(drop=True)
+
+
 def rebalance_training_data(X: pd.DataFrame, y: pd.Series, target: str) -> Tuple[pd.DataFrame, pd.Series]:
-    """reference train.py:242-293 uses imbalanced-learn's SMOTEN + RandomUnderSampler (not installed here and
-    default-off: model.py:180).  This keeps the reference's intent -- every class resampled to the median
-    class size -- with seeded duplication / sub-sampling."""
+    """reference train.py:242-293: every class is resampled to the MEDIAN class size -- SMOTEN over the rows without NULLs for the
+    classes below it (those with more than k = 5 clean rows; the others are left alone with a warning), RandomUnderSampler for the
+    classes above it.  imbalanced-learn is not installed here: `smoten_resample` / `random_under_sample` restate the two samplers."""
     from collections import Counter
-    rs = np.random.RandomState(42)
-    hist = Counter(y)
+    prev_nrows, prev_stdv = len(X), compute_class_nrow_stdv(y, is_discrete=True)
+    hist = dict(Counter(y).items())
     median = int(np.median(list(hist.values())))
-    parts = []
-    for label, cnt in hist.items():
-        idx = np.flatnonzero((y == label).to_numpy())
-        if cnt > median:
-            idx = rs.choice(idx, median, replace=False)
-        elif cnt < median and cnt > 5:
-            idx = np.concatenate([idx, rs.choice(idx, median - cnt, replace=True)])
-        parts.append(idx)
-    sel = np.sort(np.concatenate(parts))
-    _logger.info("Rebalanced training data (y=%s, median=%d): #rows=%d -> #rows=%d" % (target, median, len(X), len(sel)))
-    return X.iloc[sel], y.iloc[sel]
+    X = X.reset_index(drop=True); y = y.reset_index(drop=True)
+    has_na = X.isnull().any(axis=1).to_numpy()
+    X_notna, y_notna, X_na, y_na = X[~has_na], y[~has_na], X[has_na], y[has_na]
+    hist_na = dict(Counter(y_na).items())
+    kn = 5
+    smote_targets: Dict[Any, int] = {}
+    for key, count in hist.items():
+        if count < median:
+            nna = hist_na.get(key, 0)
+            if count - nna > kn:
+                smote_targets[key] = median - nna
+            else:
+                _logger.warning("Over-sampling of '%s' in y='%s' failed because the number of the clean rows is too small: %d" % (key, target, count - nna))
+    if smote_targets:
+        X_notna, y_notna = smoten_resample(X_notna.reset_index(drop=True), y_notna.reset_index(drop=True), smote_targets, k_neighbors=kn, random_state=42)
+    X = pd.concat([X_notna, X_na], ignore_index=True)
+    y = pd.concat([y_notna, y_na], ignore_index=True)
+    rus_targets = {k: median for k, c in hist.items() if c > median}
+    if rus_targets:
+        X, y = random_under_sample(X, y, rus_targets, random_state=42)
+    _logger.info("Rebalanced training data (y=%s, median=%d): #rows=%d(stdv=%s) -> #rows=%d(stdv=%s)" % (
+        target, median, prev_nrows, prev_stdv, len(X), compute_class_nrow_stdv(y, is_discrete=True)))
+    return X, y
