@@ -461,9 +461,15 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
         auto fetch_tree = [&](int kk, uint32_t& n4, float4& g0, float4& g1) __attribute__((always_inline)) {
             if (kk < nk && lane_on) {
                 const long long kq = k0 + kk;
-                n4 = *reinterpret_cast<const uint32_t*>(node + kq * NS + row0);
+                // node ids and (g, h) are read once per level: non-temporal, so that they do not push the records -- which the other class
+                // tree groups of the row block re-read -- out of the XCD's L2
+                n4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(node + kq * NS + row0));
                 const float2* gp = gh + kq * N + row0;
-                if (row0 + 3 < N && ((kq * N + row0) & 1ll) == 0) { g0 = *reinterpret_cast<const float4*>(gp); g1 = *reinterpret_cast<const float4*>(gp + 2); }
+                if (row0 + 3 < N && ((kq * N + row0) & 1ll) == 0) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp)), b2 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp + 2));
+                    g0 = make_float4(a.x, a.y, a.z, a.w); g1 = make_float4(b2.x, b2.y, b2.z, b2.w);
+                }
                 else {
                     float2 v[4];
                     for (int j = 0; j < 4; ++j) { long long rr = row0 + j; if (rr >= N) rr = N - 1; v[j] = gh[kq * N + rr]; }
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
                     if (r_cnt >= 64) run_batch(64);
                 }
             }
-            if (ROUTE && out4 != n4) *reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0) = out4;
+            if (ROUTE && out4 != n4) __builtin_nontemporal_store(out4, reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0));
         }
     }
     while (r_cnt > 0) run_batch(r_cnt < 64 ? r_cnt : 64);
