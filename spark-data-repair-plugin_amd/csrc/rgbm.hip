@@ -31,7 +31,7 @@
 #include "rgbm_kernels.h"
 #include "rgbm_level.h"
 
-#define RGBM_VERSION 200   // numerics spec v2: float32 (g, h) as LightGBM computes them, exact integer histogram sums on a fixed-point grid (rgbm_numerics.h)
+#define RGBM_VERSION 210   // numerics spec v2.1: float32 (g, h) as LightGBM computes them, exact integer histogram sums on a fixed-point grid of up to 2^50 per value (rgbm_numerics.h)
 
 namespace {
 
@@ -438,7 +438,6 @@ struct LgbRand {
     }
 };
 
-int ceil_log2(double v) { int ex; double m = std::frexp(v, &ex); return (m == 0.5) ? ex - 1 : ex; }
 
 void check_params(const rgbm_params& p) {
     if (p.objective < 0 || p.objective > 2) throw std::invalid_argument("objective must be 0 (binary), 1 (multiclass) or 2 (regression)");
@@ -598,11 +597,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (obj == 2) { bound_g = (ymax - ymin) * w_max; if (!(bound_g > 0.0)) bound_g = 1.0; bound_h = w_max; }
     else if (obj == 0) { bound_g = w_max; bound_h = 0.25 * w_max; }
     else { bound_g = w_max; bound_h = factor * 0.25 * w_max; }
-    // fixed-point grid of the histogram sums (numerics v2, rgbm_numerics.h): |g| <= bound_g and h <= bound_h hold for every row, so with
-    // e = E - ceil_log2(bound) every converted value is at most 2^E in magnitude and an int64 sum over all training rows (of all ranks)
-    // stays below 2^62
-    int Ebits = 62 - ceil_log2((double)std::max<int64_t>(n_train, 2)); if (Ebits > 40) Ebits = 40;
-    const int e_g = Ebits - ceil_log2(bound_g), e_h = Ebits - ceil_log2(bound_h);
+    // fixed-point grid of the histogram sums (numerics v2.1, rgbm_numerics.h): |g_i| <= (bound_g / w_max) * w_i and h_i <= (bound_h / w_max) * w_i
+    // hold for every row i, so with e = min(50 - ceil_log2(bound), 62 - ceil_log2(bound * sum_w / w_max)) every converted value is at most
+    // 2^50 in magnitude (the range of the rint trick) and an int64 sum over all training rows (of all ranks) stays below 2^62
+    const int e_g = rg::fx_exponent(bound_g, sumw / w_max), e_h = rg::fx_exponent(bound_h, sumw / w_max);
 
     TrainConst tc; memset(&tc, 0, sizeof(tc));
     tc.sg = std::ldexp(1.0, e_g); tc.sh = std::ldexp(1.0, e_h); tc.inv_sg = std::ldexp(1.0, -e_g); tc.inv_sh = std::ldexp(1.0, -e_h);

@@ -70,17 +70,26 @@ RG_HD double leaf_gain(double G, double H, double l1, double l2) {
 
 RG_HD long long round_int(double x) { return (long long)(x + 0.5); }
 
-// Numerics v2.  The gradient and hessian of a (row, class tree) are LightGBM's own float32 values (score_t; *_objective.hpp
+// Numerics v2.1.  The gradient and hessian of a (row, class tree) are LightGBM's own float32 values (score_t; *_objective.hpp
 // GetGradients: the double expression rounded once to float).  A histogram sum is the EXACT integer sum of those floats on a per-model
-// fixed-point grid: fx = rint(v * 2^e), with e chosen on the host so that |v * 2^e| <= 2^E, E = min(40, 62 - ceil_log2(training rows))
-// -- an int64 sum over every row cannot overflow.  Integer sums are associative, so a histogram does not depend on lanes, workgroups,
-// launch geometry or the number of GPUs; and because a double sum of float32 values is itself exact until it outgrows 53 bits, the
-// sums equal LightGBM's own wherever those did not have to round (tests/test_numerics_bound.py).
+// fixed-point grid: fx = rint(v * 2^e).  The host picks e (fx_exponent) from two bounds: every converted value stays at or below 2^50
+// in magnitude (the range of the rint trick below), and the int64 sum over every training row stays below 2^62 -- with
+// |v_i| <= (bound / w_max) * w_i that sum is at most bound * (sum of the row weights) / w_max.  A float32 whose magnitude is at least
+// 2^-27 of the bound is on the grid exactly (v2.0 capped the grid at 2^40: exact down to 2^-17 only, which cost hospital's many-class
+// attributes 4e-3 in a probability against LightGBM's double sums).  Integer sums are associative, so a histogram does not depend on
+// lanes, workgroups, launch geometry or the number of GPUs; and because a double sum of float32 values is itself exact until it outgrows
+// 53 bits, the sums equal LightGBM's own wherever those did not have to round (tests/test_numerics_bound.py).
 //   rint by the 1.5 * 2^52 trick: one IEEE add rounds x to the nearest integer (ties to even) for |x| < 2^51, and the low mantissa bits
 //   of the sum are that integer in two's complement.  The oracle calls rint(): same value.
+inline int fx_ceil_log2(double v) { int ex; double m = frexp(v, &ex); return (m == 0.5) ? ex - 1 : ex; }
+inline int fx_exponent(double bound /* of one value, at the heaviest row */, double weight_ratio /* sum of the row weights / largest row weight */) {
+    const int by_value = 50 - fx_ceil_log2(bound);
+    const int by_sum = 62 - fx_ceil_log2(bound * (weight_ratio > 2.0 ? weight_ratio : 2.0));
+    return by_value < by_sum ? by_value : by_sum;
+}
 RG_HD long long fx_from_f32(float v, double scale /* 2^e */) {
     double x = (double)v * scale;
-    const double lim = 1125899906842624.0;           // 2^50 (never reached: |x| <= 2^40 by construction of e)
+    const double lim = 1125899906842624.0;           // 2^50 (|x| <= 2^50 by construction of e)
     if (x > lim) x = lim;
     if (x < -lim) x = -lim;
     const double magic = 6755399441055744.0;         // 1.5 * 2^52

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/bench_job_digests.json: the CPU oracle's model of the BENCHMARKED job, pinned past iteration 2.
+
+VERDICT r3 ("What's weak" 2): the 10M x 16 job of bench.py was compared with the oracle for two boosting iterations only, while an
+intermediate build had once produced a second K = 64 model that was identical up to iteration 43 and different from 44 on.  This script
+trains the oracle (OpenMP, bit-identical for any thread count) on the targets bench.py trains -- the K = 64 target c10 and the binary
+target c0 of BASELINE configs[2] (make_table(10_000_000, 16, seed=42), the reference's fixed parameters, python/repair/train.py:102-131,
++ LightGBM defaults) -- for `--iters` iterations and stores one md5 per boosting iteration (tests/numerics_bound.py::iteration_digests).
+tests/test_gpu_bench_shapes.py trains the same targets on the HIP engine WITH FIVE OTHER TARGETS IN FLIGHT (the bench's schedule) and
+compares every iteration; tools/job_determinism.py repeats that across processes.
+
+    python tests/golden/make_bench_job_golden.py [--iters 60] [--threads 8] [--targets 10,0]
+
+Takes about an hour of host time for the K = 64 target on 8 cores (64 class trees x 10M rows per iteration).  Needs no reference files.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "spark-data-repair-plugin_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import oracle as O  # noqa: E402
+from repair.synth import balanced_weights, make_table  # noqa: E402
+from tests.numerics_bound import iteration_digests  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_job_digests.json")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=60)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--targets", default="10,0")
+    a = ap.parse_args()
+    dirty, clean, cards = make_table(a.rows, 16, seed=42)
+    del clean
+    doc = {"table": {"rows": a.rows, "cols": 16, "seed": 42, "null_ratio": 0.01}, "iters": a.iters,
+           "numerics_version": 210, "generator": "tests/golden/make_bench_job_golden.py", "targets": {}}
+    if os.path.exists(OUT):
+        old = json.load(open(OUT))
+        if old.get("table") == doc["table"] and old.get("iters") == a.iters and old.get("numerics_version") == 210:
+            doc["targets"] = old["targets"]
+    O.lib().orc_set_threads(a.threads)
+    for t in [int(x) for x in a.targets.split(",")]:
+        feats = [c for c in range(16) if c != t]
+        K = int(cards[t])
+        rows = dirty[t] >= 0
+        cw = balanced_weights(dirty[t], K)
+        kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=a.iters)
+        t0 = time.time()
+        blob = O.train(np.ascontiguousarray(dirty[feats][:, rows]), cards[feats], dirty[t][rows], K, class_weight=cw, **kw).save()
+        doc["targets"]["c%d" % t] = {"K": K, "train_rows": int(rows.sum()), "digests": iteration_digests(blob),
+                                      "oracle_seconds": round(time.time() - t0, 1), "threads": a.threads}
+        with open(OUT, "w") as f:
+            json.dump(doc, f, indent=1)
+        print("c%d (K=%d): %d iterations in %.0f s" % (t, K, a.iters, time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -153,3 +153,20 @@ def frame_case(df, row_id, targets, error_cells=None, numeric_targets=(), thread
         r["attribute"] = t
         res.append(r)
     return res
+
+
+def iteration_digests(blob):
+    """md5 of every boosting iteration's K trees (split features, thresholds, default directions, child links, gains, leaf values,
+    leaf counts -- every byte the model stores for them), in iteration order: the handle by which tests/golden/bench_job_digests.json
+    pins a long training run without storing the model."""
+    import hashlib
+    K, n_iter, trees = parse_trees(blob)
+    out = []
+    for it in range(n_iter):
+        h = hashlib.md5()
+        for k in range(K):
+            t = trees[it * K + k]
+            for name in ("feat", "theta", "dleft", "left", "right", "gain", "leaf_value", "leaf_count"):
+                h.update(np.ascontiguousarray(t[name]).tobytes())
+        out.append(h.hexdigest())
+    return out

@@ -5,11 +5,12 @@ Both modes of the CPU oracle (oracle/rgbm_oracle_train.inc) train with the refer
 iterations (python/repair/train.py:102-131) on the reference's tables and on a synthetic table with a K = 64 target:
   spec          numerics v2 -- LightGBM's float32 g / h per row, exact integer histogram sums (what the HIP kernels implement),
   lightgbm_f32  the same float32 g / h, double sums in row order (GetGradients / ConstructHistograms of LightGBM 3.3.1).
-Asserted: the repaired label of EVERY dirty cell is the same; on the shapes the benchmark uses and on most reference tables every
-tree of all 300 iterations is identical (probabilities equal to the last bit); where a tree does differ it is late (a double sum
-that had to round) and the probabilities stay within 5e-3 on tables whose closest call is itself a 6e-5 coin flip.
-tools/numerics_bound.py prints the full table (profiles/r03b_*); profiles/r03a_* holds the same table for the
-round-1/2 numerics (2^-20 fixed point + hessian from the quantised gradient), which failed this test."""
+Asserted: the repaired label of EVERY dirty cell is the same, every probability is within north_star's 1e-4, and -- since numerics
+v2.1 (fixed-point grid of up to 2^50 per value instead of 2^40: every float32 gradient of these tables is on the grid exactly) -- every
+tree of all 300 iterations is IDENTICAL on every table measured, hospital's 55- and 303-class attributes included (v2.0: first
+differing tree at iteration 116 / 33, max |dp| 4.2e-3, because its 2^40 grid rounded the small gradients).
+tools/numerics_bound.py prints the full table (profiles/r04a_*); profiles/r03b_* is the v2.0 table and
+profiles/r03a_* the one of the round-1/2 numerics (2^-20 fixed point + hessian from the quantised gradient), which failed this test."""
 import numpy as np
 import pytest
 
@@ -23,7 +24,7 @@ def _check(r, identical=None):
     tag = "%s (K=%d)" % (r.get("attribute"), r["K"])
     if "label_mismatch" in d:
         assert d["label_mismatch"] == 0, "%s: %d repaired labels differ from LightGBM's arithmetic" % (tag, d["label_mismatch"])
-        assert d["max_dp"] <= 5e-3, "%s: max |dp| %.3e" % (tag, d["max_dp"])
+        assert d["max_dp"] <= 1e-4, "%s: max |dp| %.3e (north_star: 1e-4)" % (tag, d["max_dp"])
     else:
         assert d["rounded_mismatch"] == 0 and d["max_rel_diff"] <= 1e-9, "%s: regression values differ (%r)" % (tag, d)
     if identical is True:
@@ -59,11 +60,9 @@ def test_hospital_many_class_attributes():
     cells = frame(g["error_cells"], dtypes=False); cells["tid"] = cells["tid"].astype(int)
     res = {r["attribute"]: r for r in NB.frame_case(df, "tid", ["State", "HospitalOwner", "City", "Score"], error_cells=cells, threads=4, perm=False)}
     assert len(res) == 4
-    for a in ("State", "HospitalOwner"):
-        _check(res[a], identical=True)
-    _check(res["City"], identical=100)
-    _check(res["Score"], identical=20)     # 810 rows for 55 classes, 190 cells: the closest call among them is a 6e-5 gap between two classes
-    assert res["Score"]["cells"] >= 150    # (`Sample`, 303 classes on 909 rows, behaves the same: tools/numerics_bound.py, profiles/r03b_*)
+    for a in ("State", "HospitalOwner", "City", "Score"):
+        _check(res[a], identical=True)     # Score: 810 rows for 55 classes, 190 cells, the closest call among them is a 6e-5 gap between two classes
+    assert res["Score"]["cells"] >= 150    # (`Sample`, 303 classes on 909 rows: identical as well, tools/numerics_bound.py, profiles/r04a_*)
 
 
 def test_synthetic_k64_and_binary_targets_identical_trees():
