@@ -294,7 +294,7 @@ struct Tree {
 struct DeviceModel {   // predictor mirror of a model on one device
     DevBuf<rg::PNode> nodes; DevBuf<double> leaf_value;
     // bit-vector scoring tables (k_predict_qs): per tree the AND-masks of every (feature, bin) and the leaf values in left-to-right order
-    DevBuf<uint32_t> qs_masks; DevBuf<double> qs_leaves; DevBuf<int32_t> qs_foff; int qs_S = 0, qs_MW = 0;   // qs_MW = 0: not built
+    DevBuf<uint32_t> qs_masks, qs_used; DevBuf<double> qs_leaves; DevBuf<int32_t> qs_foff; int qs_S = 0, qs_MW = 0;   // qs_MW = 0: not built
     DevBuf<uint8_t> lut; DevBuf<long long> lut_off; DevBuf<int32_t> n_codes; DevBuf<uint8_t> miss; DevBuf<int32_t> ident;
     int node_stride = 1, leaf_stride = 1;
 };
@@ -398,8 +398,10 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // is needed in normal use.  RGBM_GROWER=leafwise|level, RGBM_TIMING=1 (host wall-clock of the phases to stderr), RGBM_LV_LDS=bytes
 // (shrinks the LDS pool of the level passes: more built-slot windows per level), RGBM_LV_BLOCKS / RGBM_MT_BLOCKS (row blocks per class
 // tree of the root / level passes), RGBM_MT_TREES (cap on the class trees per level-pass workgroup), RGBM_MT_REP (LDS replication the
-// level passes are sized for, default 8), RGBM_JOINT_ROOT=0.
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; };
+// level passes are sized for, default 8), RGBM_JOINT_ROOT=0, RGBM_MT_ACC2=0 (tables of 17..32 features: one level pass per 16-feature chunk
+// instead of one pass that accumulates both).
+constexpr int LV_THREADS_DEFAULT = 1024;
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -409,6 +411,8 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_TREES")) w.mt_T = atoi(e);
     if (const char* e = getenv("RGBM_MT_REP")) w.mt_rep = atoi(e);
     if (const char* e = getenv("RGBM_JOINT_ROOT")) w.joint_root = atoi(e) != 0;
+    if (const char* e = getenv("RGBM_MT_ACC2")) w.mt_acc2 = atoi(e) != 0;
+    if (const char* e = getenv("RGBM_MT_THREADS")) w.mt_threads = atoi(e) == 768 ? 768 : 1024;
     w.timing = getenv("RGBM_TIMING") != nullptr;
     return w;
 }
@@ -653,7 +657,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<FeatMeta> d_vfmeta; DevBuf<ChunkMeta> d_vcmeta; DevBuf<uint4> d_rec_j; DevBuf<HistBin> d_part_j, d_red_j;
     DevBuf<JointFeat> d_jf; DevBuf<int16_t> d_binfeat;
     // one k_level_mt launch of a level: (chunk, window of built slots); the first one of a level routes
-    struct MtLaunch { int ch, slot0, nslots, route, T, G, gx; };
+    struct MtLaunch { int ch, slot0, nslots, route, T, G, gx, acc2; };
     std::vector<std::vector<MtLaunch>> mt_plan(LV_MAX_DEPTH + 1);
     std::vector<int> mt_gx(LV_MAX_DEPTH + 1, 8);           // row blocks per class tree of a level's launches (one value per level: the partials share it)
     if (level_mode) {
@@ -696,10 +700,15 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         for (int level = 1; level < p.max_depth; ++level) {
             const int worst = 1 << (level - 1);
             int G_first = 1;
-            for (int ch = 0; ch < nchunk; ++ch) {
+            // tables of 17..32 features: ONE pass per level accumulates both 16-feature chunks (k_level_mt<2, ., ., MT_THREADS_ACC2, true>: both
+            // records of a row in registers and in the ring) instead of one pass per chunk that streams every (node id, g, h) again
+            const bool acc2 = nchunk == 2 && sw.mt_acc2;
+            for (int ch = 0; ch < (acc2 ? 1 : nchunk); ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
-                const long long node_bytes = (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 16;
-                long long cap = (lc.lds_bytes - mt_fixed_bytes()) / std::max<long long>(node_bytes, 1);
+                long long node_bytes = (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 16;
+                if (acc2) node_bytes += (long long)lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0) * 16;
+                const int mt_thr = acc2 ? MT_THREADS_ACC2 : ((nchunk == 1 && sw.mt_threads == 768) ? 768 : LV_THREADS);
+                long long cap = (lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2)) / std::max<long long>(node_bytes, 1);
                 cap = std::min<long long>(cap, MT_MAX_NODES);
                 if (cap < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
                 const int win = (int)std::min<long long>(worst, cap);                    // built slots per launch
@@ -715,13 +724,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 const int G = (K + T - 1) / T;
                 if (ch == 0) G_first = G;
                 for (int s0 = 0; s0 < worst; s0 += win)
-                    mt_plan[level].push_back(MtLaunch{ch, s0, win, (ch == 0 && s0 == 0) ? 1 : 0, T, G, 0});
+                    mt_plan[level].push_back(MtLaunch{ch, s0, win, (ch == 0 && s0 == 0) ? 1 : 0, T, G, 0, acc2 ? 1 : 0});
             }
             const long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
             // row blocks per class tree: a multiple of 8 (one XCD each); G * gx workgroups should fill whole rounds of 256 CUs (G = 24: 8 row
             // blocks leave a quarter of the chip idle, 32 make three full rounds) without cutting the table into slivers
             const long long nwt = (N + MT_WT_ROWS - 1) / MT_WT_ROWS;
-            const long long gx_lo = std::max<long long>(8, (gmin + 7) / 8 * 8), gx_hi = std::max<long long>(gx_lo, std::min<long long>(512, (nwt / (4 * MT_WAVES) + 7) / 8 * 8));
+            const long long gx_lo = std::max<long long>(8, (gmin + 7) / 8 * 8), gx_hi = std::max<long long>(gx_lo, std::min<long long>(512, (nwt / (4 * (LV_THREADS / 64)) + 7) / 8 * 8));
             long long gx = gx_lo; double best = -1.0;
             for (long long g = gx_lo; g <= gx_hi; g += 8) {
                 const long long tot = g * G_first, rounds = (tot + 255) / 256;
@@ -796,9 +805,17 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             std::lock_guard<std::mutex> lk(attr_mu);
             if (!attr_done[tab.device & 63]) {
                 HIPCHK(hipFuncSetAttribute((const void*)k_level_root, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-#define RGBM_MT_ATTR(NCHR, BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
-                                HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
+#define RGBM_MT_ATTR(NCHR, BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, true, LV_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
+                                HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, false, LV_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
                 RGBM_MT_ATTR(0, false); RGBM_MT_ATTR(1, false); RGBM_MT_ATTR(2, false); RGBM_MT_ATTR(0, true); RGBM_MT_ATTR(1, true); RGBM_MT_ATTR(2, true);
+#define RGBM_MT_ATTR2(BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<2, BAG, true, MT_THREADS_ACC2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
+                           HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<2, BAG, false, MT_THREADS_ACC2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
+                RGBM_MT_ATTR2(false); RGBM_MT_ATTR2(true);
+#define RGBM_MT_ATTR3(BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<1, BAG, true, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
+                           HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<1, BAG, false, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
+                RGBM_MT_ATTR3(false); RGBM_MT_ATTR3(true);
+#undef RGBM_MT_ATTR3
+#undef RGBM_MT_ATTR2
 #undef RGBM_MT_ATTR
                 attr_done[tab.device & 63] = 1;
             }
@@ -912,15 +929,17 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         for (const MtLaunch& L : mt_plan[level]) {
             LevelConst l1 = ll;
             l1.mt_T = L.T; l1.mt_G = L.G; l1.mt_ch = L.ch; l1.mt_slot0 = L.slot0; l1.mt_nslots = L.nslots; l1.mt_route = L.route;
-            const dim3 grid((unsigned)L.G * (unsigned)L.gx), blk(LV_THREADS);
+            const dim3 grid((unsigned)L.G * (unsigned)L.gx);
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
-#define RGBM_LAUNCH_MT(NCHR, BAG, INBAG) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true>), grid, blk, lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, l1); \
-                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false>), grid, blk, lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, l1); } while (0)
-                if (use_bagging) { if (nchr == 1) RGBM_LAUNCH_MT(1, true, d_inbag.p); else if (nchr == 2) RGBM_LAUNCH_MT(2, true, d_inbag.p); else RGBM_LAUNCH_MT(0, true, d_inbag.p); }
-                else { if (nchr == 1) RGBM_LAUNCH_MT(1, false, nullptr); else if (nchr == 2) RGBM_LAUNCH_MT(2, false, nullptr); else RGBM_LAUNCH_MT(0, false, nullptr); }
+#define RGBM_LAUNCH_MT(NCHR, BAG, INBAG, THR, ACC) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, l1); \
+                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, l1); } while (0)
+                if (L.acc2) { if (use_bagging) RGBM_LAUNCH_MT(2, true, d_inbag.p, MT_THREADS_ACC2, true); else RGBM_LAUNCH_MT(2, false, nullptr, MT_THREADS_ACC2, true); }
+                else if (nchr == 1 && sw.mt_threads == 768) { if (use_bagging) RGBM_LAUNCH_MT(1, true, d_inbag.p, 768, false); else RGBM_LAUNCH_MT(1, false, nullptr, 768, false); }
+                else if (use_bagging) { if (nchr == 1) RGBM_LAUNCH_MT(1, true, d_inbag.p, LV_THREADS, false); else if (nchr == 2) RGBM_LAUNCH_MT(2, true, d_inbag.p, LV_THREADS, false); else RGBM_LAUNCH_MT(0, true, d_inbag.p, LV_THREADS, false); }
+                else { if (nchr == 1) RGBM_LAUNCH_MT(1, false, nullptr, LV_THREADS, false); else if (nchr == 2) RGBM_LAUNCH_MT(2, false, nullptr, LV_THREADS, false); else RGBM_LAUNCH_MT(0, false, nullptr, LV_THREADS, false); }
 #undef RGBM_LAUNCH_MT
             });
         }
@@ -1080,6 +1099,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         snprintf(path, sizeof(path), "%s/target%d.idx", trace_dir, target_col);
         if (FILE* f = fopen(path, "w")) { for (const auto& r : trace_idx) fprintf(f, "%s %d %d %zu %zu\n", r.name.c_str(), r.it, r.level, r.off, r.bytes); fclose(f); }
     }
+    if (h_err & 2) throw std::runtime_error("level grower: a level pass was launched with more built nodes / route entries than its workgroup tables hold (sizing violated)");
     if (h_err) throw std::runtime_error("level grower: a node outside the speculative expansion was selected (expansion bound violated)");
 
     int n_iter = NE;
@@ -1205,7 +1225,7 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
             std::vector<int32_t> foff(F_ + 1, 0);
             for (int f = 0; f < F_; ++f) foff[f + 1] = foff[f] + std::max(m->feats[f].V, 1) + 1;       // value bins + the missing entry
             const int S = foff[F_];
-            std::vector<uint32_t> mk((size_t)NT * S * MW, 0xFFFFFFFFu); std::vector<double> lv2((size_t)NT * LP, 0.0);
+            std::vector<uint32_t> mk((size_t)NT * S * MW, 0xFFFFFFFFu), usedf(NT, 0u); std::vector<double> lv2((size_t)NT * LP, 0.0);
             std::vector<int> lo, mid;                                // per internal node: in-order ids [lo, mid) of the leaves of its left subtree
             for (size_t t = 0; t < NT; ++t) {
                 const Tree& tr = m->trees[t];
@@ -1227,6 +1247,7 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
                     uint32_t w[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
                     for (int b = lo[j]; b < mid[j]; ++b) w[b >> 5] &= ~(1u << (b & 31));
                     const int f = tr.feat[j], nb = foff[f + 1] - foff[f] - 1;
+                    usedf[t] |= 1u << f;
                     // the test of node j is FALSE (the row goes right) for bins above its threshold, and for a missing value unless it defaults left
                     for (int b = std::max(tr.theta[j] + 1, 0); b < nb; ++b) for (int q = 0; q < MW; ++q) tm[(size_t)(foff[f] + b) * MW + q] &= w[q];
                     if (!tr.dleft[j]) for (int q = 0; q < MW; ++q) tm[(size_t)(foff[f] + nb) * MW + q] &= w[q];
@@ -1234,6 +1255,7 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
             }
             dm->qs_masks.alloc(mk.size()); dm->qs_masks.upload(mk.data(), mk.size(), s);
             dm->qs_leaves.alloc(lv2.size()); dm->qs_leaves.upload(lv2.data(), lv2.size(), s);
+            dm->qs_used.alloc(usedf.size()); dm->qs_used.upload(usedf.data(), usedf.size(), s);
             dm->qs_foff.alloc(foff.size()); dm->qs_foff.upload(foff.data(), foff.size(), s);
             dm->qs_S = S; dm->qs_MW = MW;
             HIPCHK(hipStreamSynchronize(s));     // the vectors are locals
@@ -1274,15 +1296,15 @@ void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_c
     bool qs = dm->qs_MW > 0 && !force_walk;
     int qs_tb = 8;
     if (qs) {   // trees per LDS stage: two stages of (masks + leaves) within 48 KB
-        const size_t per_tree = (size_t)dm->qs_S * dm->qs_MW * 4 + (size_t)32 * dm->qs_MW * 8;
+        const size_t per_tree = (size_t)dm->qs_S * dm->qs_MW * 4 + (size_t)32 * dm->qs_MW * 8 + 4;
         while (qs_tb > 1 && 2 * qs_tb * per_tree + 16 > 48 * 1024) --qs_tb;
         if (2 * qs_tb * per_tree + 16 > 48 * 1024) qs = false;
     }
     if (qs) {   // bit-vector scoring: no tree walk at all
-        const size_t lds = (size_t)2 * qs_tb * ((size_t)dm->qs_S * dm->qs_MW * 4 + (size_t)32 * dm->qs_MW * 8) + 16;
+        const size_t lds = (size_t)2 * qs_tb * ((size_t)dm->qs_S * dm->qs_MW * 4 + (size_t)32 * dm->qs_MW * 8 + 4) + 16;
         const dim3 grid((unsigned)((n + 256 * QS_ROWS - 1) / (256 * QS_ROWS)), K);
         const uint8_t* r8 = reinterpret_cast<const uint8_t*>(rec.p);
-#define RGBM_QS(MW, FM) hipLaunchKernelGGL((k_predict_qs<MW, FM>), grid, dim3(256), lds, s, r8, n, dm->qs_masks.p, dm->qs_leaves.p, dm->qs_foff.p, F, dm->qs_S, qs_tb, m->n_iter, K, raw.p)
+#define RGBM_QS(MW, FM) hipLaunchKernelGGL((k_predict_qs<MW, FM>), grid, dim3(256), lds, s, r8, n, dm->qs_masks.p, dm->qs_leaves.p, dm->qs_used.p, dm->qs_foff.p, F, dm->qs_S, qs_tb, m->n_iter, K, raw.p)
         if (dm->qs_MW == 1) { if (F <= 16) RGBM_QS(1, 16); else RGBM_QS(1, 32); }
         else { if (F <= 16) RGBM_QS(2, 16); else RGBM_QS(2, 32); }
 #undef RGBM_QS

@@ -943,13 +943,15 @@ __global__ __launch_bounds__(256) void k_predict_raw(const uint8_t* __restrict__
 constexpr int QS_ROWS = 2;
 template <int MW, int FMAX>
 __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ rec8, long long n, const uint32_t* __restrict__ masks /* [T][S * MW] */,
-                                                    const double* __restrict__ leaves /* [T][32 * MW] */, const int32_t* __restrict__ foff /* [F + 1] */,
+                                                    const double* __restrict__ leaves /* [T][32 * MW] */, const uint32_t* __restrict__ used /* [T] features a tree splits on */,
+                                                    const int32_t* __restrict__ foff /* [F + 1] */,
                                                     int F, int S, int tb_n /* trees per LDS stage */, int n_iter, int K, double* __restrict__ raw /* [K][n] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = 32 * MW;
     const int tree_words = S * MW;                                   // mask words of a tree
     uint32_t* sm = reinterpret_cast<uint32_t*>(smem);                // [2][tb_n][S * MW]
     double* sl = reinterpret_cast<double*>(sm + 2 * tb_n * tree_words + ((2 * tb_n * tree_words) & 1));   // [2][tb_n][LP], 8-byte aligned
+    uint32_t* su = reinterpret_cast<uint32_t*>(sl + 2 * tb_n * LP);  // [2][tb_n] used-feature bits
     const int k = blockIdx.y, tid = threadIdx.x;
     const long long base = (long long)blockIdx.x * (256 * QS_ROWS);
     int off[QS_ROWS][FMAX]; long long row[QS_ROWS]; double s[QS_ROWS];
@@ -975,6 +977,7 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
             const long long t = (long long)it * K + k;
             for (int i = tid; i < tree_words; i += 256) sm[(buf * tb_n + tb) * tree_words + i] = masks[t * tree_words + i];
             if (tid < LP) sl[(buf * tb_n + tb) * LP + tid] = leaves[t * LP + tid];
+            if (tid == LP) su[buf * tb_n + tb] = used[t];
         }
     };
     stage(0, 0);
@@ -986,19 +989,27 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
         for (int tb = 0; tb < nt; ++tb) {
             const unsigned char* tm = reinterpret_cast<const unsigned char*>(sm + (buf * tb_n + tb) * tree_words);
             const double* tl = sl + (buf * tb_n + tb) * LP;
+            // the mask of a feature the tree never splits on is all ones for every bin: its lookup is skipped (a scalar branch per feature;
+            // a 31-leaf tree of the synthetic tables splits on 6-11 of its 15 features)
+            const uint32_t um = (uint32_t)__builtin_amdgcn_readfirstlane((int)su[buf * tb_n + tb]);
+            uint32_t v0[QS_ROWS], v1[QS_ROWS];
 #pragma unroll
-            for (int q = 0; q < QS_ROWS; ++q) {
-                uint32_t v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
+            for (int q = 0; q < QS_ROWS; ++q) { v0[q] = 0xFFFFFFFFu; v1[q] = 0xFFFFFFFFu; }
 #pragma unroll
-                for (int f = 0; f < FMAX; ++f) {
-                    if (f < F) {                                       // uniform
-                        if (MW == 1) v0 &= *reinterpret_cast<const uint32_t*>(tm + off[q][f]);
-                        else { const uint2 m2 = *reinterpret_cast<const uint2*>(tm + off[q][f]); v0 &= m2.x; v1 &= m2.y; }
+            for (int f = 0; f < FMAX; ++f) {
+                if (f < F && ((um >> f) & 1u)) {                       // uniform
+#pragma unroll
+                    for (int q = 0; q < QS_ROWS; ++q) {
+                        if (MW == 1) v0[q] &= *reinterpret_cast<const uint32_t*>(tm + off[q][f]);
+                        else { const uint2 m2 = *reinterpret_cast<const uint2*>(tm + off[q][f]); v0[q] &= m2.x; v1[q] &= m2.y; }
                     }
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < QS_ROWS; ++q) {
                 int leaf;
-                if (MW == 1) leaf = __ffs((int)v0) - 1;
-                else leaf = v0 ? __ffs((int)v0) - 1 : 32 + __ffs((int)v1) - 1;
+                if (MW == 1) leaf = __ffs((int)v0[q]) - 1;
+                else leaf = v0[q] ? __ffs((int)v0[q]) - 1 : 32 + __ffs((int)v1[q]) - 1;
                 s[q] += tl[leaf];
             }
         }

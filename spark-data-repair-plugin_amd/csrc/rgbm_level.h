@@ -51,7 +51,7 @@ constexpr int MT_MAX_RT = 256;               // route / child-lookup entries per
 constexpr int MT_WT_ROWS = 256;              // rows of one wave tile: 4 consecutive rows per lane
 constexpr int MT_RING = 128;                 // entries of a wave's built-row ring: <= 63 waiting + <= 64 appended per row step
 constexpr int MT_CNT_REP = 8;
-constexpr int MT_WAVES = LV_THREADS / 64;
+constexpr int MT_THREADS_ACC2 = 768;         // workgroup of a two-chunk pass: 12 waves with 168 VGPRs each (two records per row stay in registers), a third less ring
 
 struct SNode {   // speculative node of one class tree
     long long Gq, Hq;
@@ -113,11 +113,11 @@ __host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int q) {
 
 // bytes the root pass needs besides the histogram: nothing but alignment slack
 constexpr int LV_ROOT_FIXED = 256;
-// bytes k_level_mt needs besides the histogram: tree table | node -> tree map | route entries | built-row counters | per-wave rings
-// (record 16 B + (g, h) 8 B + slot 2 B per entry) | per-feature flush table | slack
-__host__ __device__ inline long long mt_fixed_bytes() {
-    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
-           (long long)MT_WAVES * MT_RING * (16 + 8 + 2) + 256;
+// bytes k_level_mt needs besides the histogram: tree table | node -> tree map | scalars | per-feature flush table (32 features) | packed
+// tree entries | route entries | built-row counters | per-wave rings (record(s) 16 / 32 B + (g, h) 8 B + slot 2 B per entry) | slack
+__host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2) {
+    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
+           (long long)(threads / 64) * MT_RING * ((acc2 ? 32 : 16) + 8 + 2) + 256;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -277,11 +277,15 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
 struct MtTree { int32_t base, nlev, rt_off, slot0, nb, live, child_first, k; };   // 32 B, one per class tree of the workgroup
 
 template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers), 0 = any number of chunks, the split byte is gathered */, bool BAG,
-          bool ROUTE /* the first launch of a level: moves the rows to their children; later launches find the built rows by the final ids */>
-__global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
-                                                            const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
-                                                            int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
-                                                            LevelConst c) {
+          bool ROUTE /* the first launch of a level: moves the rows to their children; later launches find the built rows by the final ids */,
+          int THREADS /* 1024, or MT_THREADS_ACC2 */, bool ACC2 /* NCHR == 2 only: the histograms of BOTH chunks are accumulated by this launch */>
+__global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
+                                                         const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
+                                                         int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
+                                                         int32_t* __restrict__ err_flag, LevelConst c) {
+    static_assert(!ACC2 || NCHR == 2, "a two-chunk pass keeps both records in registers");
+    constexpr int WAVES = THREADS / 64;
+    constexpr int NACC = ACC2 ? 2 : 1;                     // chunks accumulated by this launch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned id = blockIdx.x;
     const int xl = (int)(id & 7u), bslot = (int)(id >> 3);
@@ -289,24 +293,31 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
     const int k0 = grp * c.mt_T;
     const int nk = (c.K - k0) < c.mt_T ? (c.K - k0) : c.mt_T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = c.mt_ch;
+    const int ch = ACC2 ? 0 : c.mt_ch;
     constexpr bool route = ROUTE;
     const ChunkMeta cm = cmeta[ch];
+    const ChunkMeta cm1 = cmeta[ACC2 ? 1 : ch];
     const FeatMeta* fm = fmeta + cm.first_feat;
-    const int nfeat = cm.nfeat, wb = cm.wide_bins;
+    const FeatMeta* fm1 = fmeta + cm1.first_feat;
+    const int nfeat = cm.nfeat, nfeat1 = ACC2 ? cm1.nfeat : 0;
+    const int wb = cm.wide_bins + (ACC2 ? cm1.wide_bins : 0);
+    // the histogram slot of a ring entry rides in byte 15 of its (last) record whenever that chunk holds at most 15 features: one LDS
+    // write and one LDS read less per entry (the 10M x 16 and the 100M x 32 shapes have 15 features in their last chunk)
+    const bool li_in_rec = (ACC2 ? nfeat1 : nfeat) <= 15;
 
     // ---- LDS carve-up
     MtTree* ti = reinterpret_cast<MtTree*>(smem);                                              // [MT_MAX_T]
     uint8_t* nd_tree = smem + MT_MAX_T * 32;                                                   // [MT_MAX_NODES] local node -> class tree of the workgroup
     int32_t* scal = reinterpret_cast<int32_t*>(nd_tree + MT_MAX_NODES);                        // [4] total built nodes, replication shift, slots per node, any live class tree
-    int32_t* ftab = scal + 4;                                                                  // [4][16] per feature: first wide bin | first slot | replication shift | histogram offset
-    uint2* tpk = reinterpret_cast<uint2*>(ftab + 64);                                          // [MT_MAX_T + 2] what the row loop needs of a class tree: base | nlev << 8 | live << 31, rt_off | k << 16
-    uint2* rt = tpk + MT_MAX_T + 2;                                           // [MT_MAX_RT] route entries / child -> slot entries
+    int32_t* ftab = scal + 4;                                                                  // [4][32] per accumulated feature: first wide bin | first slot | replication shift | histogram offset
+    uint2* tpk = reinterpret_cast<uint2*>(ftab + 128);                                         // [MT_MAX_T + 2] what the row loop needs of a class tree: base | nlev << 8 | live << 31, rt_off | k << 16
+    uint2* rt = tpk + MT_MAX_T + 2;                                                            // [MT_MAX_RT] route entries / child -> slot entries
     int32_t* cnt = reinterpret_cast<int32_t*>(rt + MT_MAX_RT);                                 // [MT_MAX_NODES][MT_CNT_REP]
     uint4* ring_rec_all = reinterpret_cast<uint4*>(cnt + MT_MAX_NODES * MT_CNT_REP);           // [waves][MT_RING]
-    uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec_all + MT_WAVES * MT_RING);          // [waves][MT_RING]
-    uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + MT_WAVES * MT_RING);     // [waves][MT_RING]
-    size_t off = reinterpret_cast<unsigned char*>(ring_li_all + MT_WAVES * MT_RING) - smem;
+    uint4* ring_rec1_all = ring_rec_all + (ACC2 ? WAVES * MT_RING : 0);                        // [waves][MT_RING] (two-chunk pass)
+    uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec1_all + WAVES * MT_RING);            // [waves][MT_RING]
+    uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + WAVES * MT_RING);        // [waves][MT_RING]
+    size_t off = reinterpret_cast<unsigned char*>(ring_li_all + WAVES * MT_RING) - smem;
     off = (off + 15) & ~(size_t)15;
     unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem + off);     // [total][spn] gradient sums, then [total][spn] hessian sums (see k_level_root)
     const long long avail = (long long)c.lds_bytes - (long long)off;
@@ -332,8 +343,10 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
         t.slot0 = inc_nb - t.nb; t.rt_off = inc_rt - t.nlev;
         const int total = __shfl(inc_nb, 63), rt_total = __shfl(inc_rt, 63);
         const unsigned long long livem = __ballot(t.live != 0);
-        const bool ok = total <= MT_MAX_NODES && rt_total <= MT_MAX_RT;     // the host sizes T for the worst case: always true
-        if (!ok) { t.live = 0; t.nb = 0; t.nlev = 0; }
+        // the host sizes T for the worst case of the level (2^(L-1) expanded parents per class tree), so this always holds; if it ever did
+        // not, the pass would silently drop rows: the training call fails instead (err_flag bit 1)
+        const bool ok = total <= MT_MAX_NODES && rt_total <= MT_MAX_RT;
+        if (!ok) { t.live = 0; t.nb = 0; t.nlev = 0; if (lane == 0) atomicOr(err_flag, 2); }
         if (lane < nk) ti[lane] = t;
         tpk[lane] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
         if (lane < 2) tpk[64 + lane] = make_uint2(0u, 0u);
@@ -341,18 +354,21 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
             // replication: the largest uniform shift whose histograms fit
             int s = LV_MAX_Q;
             const int tot = ok ? total : 0;
-            while (s > 0 && (long long)tot * lv_slots(fm, nfeat, s) * 16 > avail) --s;
-            scal[0] = tot; scal[1] = s; scal[2] = lv_slots(fm, nfeat, s); scal[3] = (ok && livem != 0ull) ? 1 : 0;
+            while (s > 0 && (long long)tot * (lv_slots(fm, nfeat, s) + (ACC2 ? lv_slots(fm1, nfeat1, s) : 0)) * 16 > avail) --s;
+            const int spn0 = lv_slots(fm, nfeat, s) + (ACC2 ? lv_slots(fm1, nfeat1, s) : 0);
+            if ((long long)tot * spn0 * 16 > avail) atomicOr(err_flag, 2);          // (the host's window sizing guarantees the plain layout fits)
+            scal[0] = tot; scal[1] = s; scal[2] = spn0; scal[3] = (ok && livem != 0ull) ? 1 : 0;
         }
     }
     __syncthreads();
     if (!scal[3]) return;
-    const int total = scal[0], s = scal[1], spn = scal[2];
+    // wave-uniform from here on: in SGPRs, so that everything derived from them (shifts, strides) is scalar as well
+    const int total = __builtin_amdgcn_readfirstlane(scal[0]), s = __builtin_amdgcn_readfirstlane(scal[1]), spn = __builtin_amdgcn_readfirstlane(scal[2]);
     if (!route && total == 0) return;
     for (int kk = 0; kk < nk; ++kk) {
         const MtTree t = ti[kk];
         const LvPlan* pp = &plan[t.k];
-        for (int i = tid; i < t.nlev; i += LV_THREADS) {
+        for (int i = tid; i < t.nlev; i += THREADS) {
             const int n = t.base + i;
             uint2 e;
             if (route) {
@@ -372,65 +388,87 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
             }
             rt[t.rt_off + i] = e;
         }
-        for (int i = tid; i < t.nb; i += LV_THREADS) nd_tree[t.slot0 + i] = (uint8_t)kk;
+        for (int i = tid; i < t.nb; i += THREADS) nd_tree[t.slot0 + i] = (uint8_t)kk;
     }
-    for (int i = tid; i < total * MT_CNT_REP; i += LV_THREADS) cnt[i] = 0;
+    for (int i = tid; i < total * MT_CNT_REP; i += THREADS) cnt[i] = 0;
     unsigned long long* hist_h = hist_g + (size_t)total * spn;
-    for (int i = tid; i < 2 * total * spn; i += LV_THREADS) hist_g[i] = 0ull;
-    int sh[16], fbase[16];
+    for (int i = tid; i < 2 * total * spn; i += THREADS) hist_g[i] = 0ull;
+    // per accumulated feature: replication shift (scalar) and this lane's byte offset inside a node's slots (first slot + replica)
+    int sh3[NACC][16], cj[NACC][16];
     {
         int o = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < nfeat) { sh[j] = lv_shift(fm[j].nbins, s); fbase[j] = o; o += fm[j].nbins << sh[j]; }
-            else { sh[j] = 0; fbase[j] = 0; }
+        for (int a = 0; a < NACC; ++a) {
+            const FeatMeta* fa = a == 0 ? fm : fm1;
+            const int na = a == 0 ? nfeat : nfeat1;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int shj = 0, fb = 0;
+                if (j < na) { shj = lv_shift(fa[j].nbins, s); fb = o; o += fa[j].nbins << shj; }
+                sh3[a][j] = shj + 3; cj[a][j] = (fb + (lane & ((1 << shj) - 1))) * 8;
+                if (tid == 0) {
+                    const int q = a * 16 + j;
+                    const int wide = (a == 0 ? 0 : cm.wide_bins) + (j < na ? fa[j].wide_off : 0);
+                    ftab[q] = j < na ? wide : 0x7FFFFFFF; ftab[32 + q] = fb; ftab[64 + q] = shj; ftab[96 + q] = j < na ? fa[j].hoff - wide : 0;
+                }
+            }
         }
     }
-    if (tid < 16) {
-        const bool on = tid < nfeat;
-        int fb = 0, shj = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) if (j == tid) { fb = fbase[j]; shj = sh[j]; }
-        ftab[tid] = on ? fm[tid].wide_off : 0x7FFFFFFF; ftab[16 + tid] = fb; ftab[32 + tid] = shj; ftab[48 + tid] = on ? fm[tid].hoff - fm[tid].wide_off : 0;
-    }
-    int cj[16], sh3[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { sh3[j] = sh[j] + 3; cj[j] = (fbase[j] + (lane & ((1 << sh[j]) - 1))) * 8; }
     const int hdelta = total * spn;
     __syncthreads();
 
     uint4* ring_rec = ring_rec_all + wave * MT_RING;
+    uint4* ring_rec1 = ring_rec1_all + wave * MT_RING;
     uint2* ring_gh = ring_gh_all + wave * MT_RING;
     uint16_t* ring_li = ring_li_all + wave * MT_RING;
     int r_head = 0, r_cnt = 0;                                   // wave-uniform
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const unsigned spn8 = (unsigned)spn * 8u;
+    // lane kk keeps the packed entry of class tree kk: the row loop fetches it with a readlane instead of an LDS read per step
+    const uint2 tpk_v = tpk[lane];
+    auto tree_entry = [&](int kk) __attribute__((always_inline)) -> uint2 {
+        const int kc = kk < 64 ? kk : 63;
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.x, kc), y = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.y, kc);
+        return kk < nk ? make_uint2(x, y) : make_uint2(0u, 0u);
+    };
 
     // one FULL (or final, partial) wave of histogram updates from the ring
     auto run_batch = [&](int nb) __attribute__((always_inline)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ring entries are read by other lanes of this wave
         const bool on = lane < nb;
         const int pos = (r_head + lane) & (MT_RING - 1);
-        const uint4 r = ring_rec[pos]; const uint2 g = ring_gh[pos]; const unsigned li = ring_li[pos];
+        const uint4 r = ring_rec[pos]; const uint2 g = ring_gh[pos];
+        uint4 r1 = make_uint4(0, 0, 0, 0);
+        if (ACC2) r1 = ring_rec1[pos];
+        unsigned li;
+        if (li_in_rec) li = (ACC2 ? r1.w : r.w) >> 24; else li = ring_li[pos];
         r_head = (r_head + nb) & (MT_RING - 1); r_cnt -= nb;
         if (on) {
             const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), c.sg), hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), c.sh);
             if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], 1);
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g) + li * spn8;
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#if defined(MT_DBG) && MT_DBG == 1   // timing experiment (make EXTRA=-DMT_DBG=1): everything but the LDS atomics; results are wrong
-#define MT_ATOM(j) asm volatile("" :: "v"(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[j])), "v"(gq), "v"(hq), "v"(hdelta))
-#else
-#define MT_ATOM(j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[j])); \
-                     atomicAdd(p_, gq); atomicAdd(p_ + hdelta, hq); }
-#endif
+            const uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w};
+#define MT_ATOM(A, W, j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[A][j] + (int)(((W[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[A][j])); \
+                           atomicAdd(p_, gq); atomicAdd(p_ + hdelta, hq); }
             if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
-                MT_ATOM(0); MT_ATOM(1); MT_ATOM(2); MT_ATOM(3); MT_ATOM(4); MT_ATOM(5); MT_ATOM(6); MT_ATOM(7);
-                MT_ATOM(8); MT_ATOM(9); MT_ATOM(10); MT_ATOM(11); MT_ATOM(12); MT_ATOM(13); MT_ATOM(14);
-                if (nfeat == 16) MT_ATOM(15);
+                MT_ATOM(0, w, 0); MT_ATOM(0, w, 1); MT_ATOM(0, w, 2); MT_ATOM(0, w, 3); MT_ATOM(0, w, 4); MT_ATOM(0, w, 5); MT_ATOM(0, w, 6); MT_ATOM(0, w, 7);
+                MT_ATOM(0, w, 8); MT_ATOM(0, w, 9); MT_ATOM(0, w, 10); MT_ATOM(0, w, 11); MT_ATOM(0, w, 12); MT_ATOM(0, w, 13); MT_ATOM(0, w, 14);
+                if (nfeat == 16) MT_ATOM(0, w, 15);
             } else {
 #pragma unroll
-                for (int j = 0; j < 14; ++j) if (j < nfeat) MT_ATOM(j);
+                for (int j = 0; j < 14; ++j) if (j < nfeat) MT_ATOM(0, w, j);
+            }
+            if (ACC2) {
+                if (nfeat1 >= 15) {
+                    MT_ATOM(NACC - 1, w1, 0); MT_ATOM(NACC - 1, w1, 1); MT_ATOM(NACC - 1, w1, 2); MT_ATOM(NACC - 1, w1, 3); MT_ATOM(NACC - 1, w1, 4); MT_ATOM(NACC - 1, w1, 5);
+                    MT_ATOM(NACC - 1, w1, 6); MT_ATOM(NACC - 1, w1, 7); MT_ATOM(NACC - 1, w1, 8); MT_ATOM(NACC - 1, w1, 9); MT_ATOM(NACC - 1, w1, 10); MT_ATOM(NACC - 1, w1, 11);
+                    MT_ATOM(NACC - 1, w1, 12); MT_ATOM(NACC - 1, w1, 13); MT_ATOM(NACC - 1, w1, 14);
+                    if (nfeat1 == 16) MT_ATOM(NACC - 1, w1, 15);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 14; ++j) if (j < nfeat1) MT_ATOM(NACC - 1, w1, j);
+                }
             }
 #undef MT_ATOM
         }
@@ -441,16 +479,16 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
     const long long wt_lo = nwt_all * rb / c.gx, wt_hi = nwt_all * (rb + 1) / c.gx;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
     const uint4* rec_acc = rec + (long long)ch * N;                                  // the chunk whose features are accumulated
-    for (long long wt = wt_lo + wave; wt < wt_hi; wt += MT_WAVES) {
+    for (long long wt = wt_lo + wave; wt < wt_hi; wt += WAVES) {
         const long long row0 = wt * MT_WT_ROWS + lane * 4;
         const bool lane_on = row0 < N;
-        uint4 ra[4], r1[4];             // the accumulated chunk's records (a routing launch accumulates chunk 0: also the routing record); record 1 for routing
+        uint4 ra[4], r1[4];             // the accumulated chunk's records (a routing launch accumulates chunk 0: also the routing record); record 1 for routing / the two-chunk pass
         uint32_t rowmask = 0u;          // bit j: row0 + j exists (and is in the bag)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             long long rr = row0 + j; if (rr >= N) rr = N - 1;
             ra[j] = rec_acc[rr];
-            if (route && NCHR == 2) r1[j] = rec[N + rr]; else r1[j] = make_uint4(0, 0, 0, 0);
+            if (ACC2 || (route && NCHR == 2)) r1[j] = rec[N + rr]; else r1[j] = make_uint4(0, 0, 0, 0);
             if (row0 + j < N) rowmask |= 1u << j;
         }
         uint32_t bagmask = 0xFu;
@@ -479,15 +517,15 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
         };
         // Software pipeline over the class trees, three stages deep, so that no row step waits for a memory or LDS round trip
         // (the LDS queue is full of other waves' atomics: a dependent lookup inside the row loop cost hundreds of cycles):
-        //   stage A (tree kk + 2): global loads of the node ids and (g, h); LDS read of the tree's packed table entry
+        //   stage A (tree kk + 2): global loads of the node ids and (g, h); the tree's packed table entry (a readlane)
         //   stage B (tree kk + 1): node ids have arrived -> table indices -> LDS reads of the four route entries
         //   stage C (tree kk)    : route, append the built rows to the ring, run the batches
-        uint2 tq_a = tpk[0], tq_b = tpk[1];
+        uint2 tq_a = tree_entry(0), tq_b = tree_entry(1);
         fetch_tree(0, n4_a, ga0, ga1);
         fetch_tree(1, n4_b, gb0, gb1);
         uint2 e_a[4]; uint32_t in_a = 0u;
         auto lookup = [&](uint32_t n4, const uint2 tq, uint2 (&e)[4], uint32_t& inm) __attribute__((always_inline)) {
-            const uint32_t tq0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tq.x), tq1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tq.y);
+            const uint32_t tq0 = tq.x, tq1 = tq.y;       // scalar (tree_entry)
             const uint32_t base = tq0 & 0xFFu, nlev = (tq0 >> 8) & 0x1FFu, rt_off = tq1 & 0xFFFFu;
             inm = 0u;
 #pragma unroll
@@ -507,8 +545,8 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
             for (int j = 0; j < 4; ++j) e[j] = e_a[j];
             n4_a = n4_b; ga0 = gb0; ga1 = gb1; tq_a = tq_b;
             fetch_tree(kk + 2, n4_b, gb0, gb1);                     // stage A
-            tq_b = tpk[kk + 2];
-            lookup(n4_a, tq_a, e_a, in_a);                          // stage B (reads tpk / rt only: tables nobody writes during the row loop)
+            tq_b = tree_entry(kk + 2);
+            lookup(n4_a, tq_a, e_a, in_a);                          // stage B (reads rt only: a table nobody writes during the row loop)
             // ---- stage C
             if (__ballot(inm != 0u) == 0ull) continue;               // no row of this wave tile sits in a node of the level (or the tree is finished)
             uint32_t out4 = n4;
@@ -545,14 +583,16 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
                     built = in && e[j].x != 0u;
                 }
                 if (BAG) built = built && ((bagmask >> j) & 1u);
-#if defined(MT_DBG) && MT_DBG == 2   // timing experiment: routing only, nothing is appended or accumulated
-                built = built && c.lds_bytes < 0;
-#endif
                 const unsigned long long m = __ballot(built);
                 if (m != 0ull) {                                      // uniform
                     if (built) {
                         const int pos = (r_head + r_cnt + (int)__popcll(m & lane_lt)) & (MT_RING - 1);
-                        ring_rec[pos] = ra[j]; ring_gh[pos] = make_uint2(__float_as_uint(gg[j]), __float_as_uint(hh[j])); ring_li[pos] = (uint16_t)li;
+                        uint4 q0 = ra[j], q1 = r1[j];
+                        if (li_in_rec) { if (ACC2) q1.w = (q1.w & 0x00FFFFFFu) | (li << 24); else q0.w = (q0.w & 0x00FFFFFFu) | (li << 24); }
+                        else ring_li[pos] = (uint16_t)li;
+                        ring_rec[pos] = q0;
+                        if (ACC2) ring_rec1[pos] = q1;
+                        ring_gh[pos] = make_uint2(__float_as_uint(gg[j]), __float_as_uint(hh[j]));
                     }
                     r_cnt += (int)__popcll(m);
                     if (r_cnt >= 64) run_batch(64);
@@ -564,21 +604,22 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_mt(const uint4* __restr
     while (r_cnt > 0) run_batch(r_cnt < 64 ? r_cnt : 64);
     __syncthreads();
     // ---- flush this workgroup's partial histograms (plain stores: no global atomics, no zeroing) and the built-row counts
-    for (int i = tid; i < total * wb; i += LV_THREADS) {
+    constexpr int NQ = NACC * 16;
+    for (int i = tid; i < total * wb; i += THREADS) {
         const int ln = i / wb, b = i - ln * wb;
         const MtTree t = ti[nd_tree[ln]];
-        int j = 0;                                                  // feature of wide bin b: the last one whose first wide bin is <= b
+        int j = 0;                                                  // accumulated feature of wide bin b: the last one whose first wide bin is <= b
 #pragma unroll
-        for (int q = 1; q < 16; ++q) j += (b >= ftab[q]) ? 1 : 0;
-        const int shb = ftab[32 + j], s0 = ftab[16 + j] + ((b - ftab[j]) << shb);
+        for (int q = 1; q < NQ; ++q) j += (b >= ftab[q]) ? 1 : 0;
+        const int shb = ftab[64 + j], s0 = ftab[32 + j] + ((b - ftab[j]) << shb);
         long long tg = 0, th = 0;
         const unsigned long long* sg_ = hist_g + (size_t)ln * spn + s0; const unsigned long long* sh_ = hist_h + (size_t)ln * spn + s0;
         for (int r2 = 0; r2 < (1 << shb); ++r2) { tg += (long long)sg_[r2]; th += (long long)sh_[r2]; }
         HistBin o; o.g = tg; o.h = th;
-        part[(((long long)t.k * c.gx + rb) * c.max_built + (c.mt_slot0 + ln - t.slot0)) * c.totbins + ftab[48 + j] + b] = o;
+        part[(((long long)t.k * c.gx + rb) * c.max_built + (c.mt_slot0 + ln - t.slot0)) * c.totbins + ftab[96 + j] + b] = o;
     }
     if (ch == 0) {   // exact row counts of the built children (k_level_plan numbers the children of parent ei as child_first + 2 ei, + 1)
-        for (int ln = tid; ln < total; ln += LV_THREADS) {
+        for (int ln = tid; ln < total; ln += THREADS) {
             int tot = 0;
             for (int r2 = 0; r2 < MT_CNT_REP; ++r2) tot += cnt[ln * MT_CNT_REP + r2];
             const MtTree t = ti[nd_tree[ln]];
