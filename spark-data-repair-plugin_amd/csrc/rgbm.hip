@@ -401,7 +401,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // level passes are sized for, default 8), RGBM_JOINT_ROOT=0, RGBM_MT_ACC2=0 (tables of 17..32 features: one level pass per 16-feature chunk
 // instead of one pass that accumulates both).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -413,6 +413,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_JOINT_ROOT")) w.joint_root = atoi(e) != 0;
     if (const char* e = getenv("RGBM_MT_ACC2")) w.mt_acc2 = atoi(e) != 0;
     if (const char* e = getenv("RGBM_MT_THREADS")) w.mt_threads = atoi(e) == 768 ? 768 : 1024;
+    if (const char* e = getenv("RGBM_MT_SPEC")) w.mt_spec = atoi(e) != 0 ? 1 : 0;
     w.timing = getenv("RGBM_TIMING") != nullptr;
     return w;
 }
@@ -461,66 +462,42 @@ struct HostLabelStats {   // row-order weight sums, only used with per-row sampl
 };
 
 // ---------------------------------------------------------------------------------------------
-// The trainer (GBDT::Train) on a resident table.
+// What a fit derives from the code counts of its training rows before it touches row data (GBDT::Init / Dataset construction /
+// BoostFromScore): bins, lookup tables, chunk layout, label statistics, initial scores, the fixed-point grid.  Shared by the
+// single-fit trainer (train_core) and the batched small-table trainer (train_batch_small).
 // ---------------------------------------------------------------------------------------------
-rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t* feat_cols, int32_t F,
-                       const double* y_value, const double* class_weight, const double* sample_weight_host,
-                       const HostLabelStats* hls, const rgbm_params& p, rgbm_train_stats* stats) {
+struct FitHost {
+    int64_t n_train = 0; int nchunk = 1; size_t lds_hist = 0;
+    std::vector<int32_t> cols, ncod; std::vector<long long> cnt_off, lut_off; std::vector<unsigned int> cnt;
+    std::vector<rg::FeatMeta> fmeta; std::vector<rg::ChunkMeta> cmeta; std::vector<uint8_t> lut, miss, trivial;
+    std::vector<double> init, yv32; rg::TrainConst tc;
+    std::unique_ptr<rgbm_model> model;
+};
+
+void fit_setup(const rgbm_table& tab, const double* y_value_in, const double* class_weight, const HostLabelStats* hls, const rgbm_params& p, int32_t F, FitHost& h) {
     using namespace rg;
-    check_params(p);
-    if (F <= 0) throw std::invalid_argument("no feature columns");
-    if (target_col < 0 || target_col >= tab.c) throw std::invalid_argument("target column out of range");
-    for (int f = 0; f < F; ++f) if (feat_cols[f] < 0 || feat_cols[f] >= tab.c) throw std::invalid_argument("feature column out of range");
-    if (F > 65535) throw std::invalid_argument("more than 65535 feature columns");
     const int64_t N = tab.n;
     const int obj = p.objective;
-    const int n_y = tab.n_codes[target_col];
+    const std::vector<int32_t>& cols = h.cols; const std::vector<int32_t>& ncod = h.ncod; const std::vector<long long>& cnt_off = h.cnt_off;
+    const std::vector<unsigned int>& cnt = h.cnt;
+    const int n_y = ncod[F];
     const int K = obj == 1 ? p.num_class : 1;
-    if (obj == 1 && n_y > p.num_class) throw std::out_of_range("target has more label codes than num_class");
-    if (obj == 0 && n_y > 2) throw std::out_of_range("binary objective with more than 2 label codes");
-    if (obj == 2 && !y_value) throw std::out_of_range("regression needs the y_value dictionary");
-    std::vector<double> yv32;   // LightGBM keeps labels as float32: round the regression dictionary once
-    if (obj == 2) { yv32.resize(std::max(n_y, 1)); for (int c = 0; c < n_y; ++c) yv32[c] = (double)(float)y_value[c]; y_value = yv32.data(); }
-    StreamGuard sg_; hipStream_t s = sg_.s;
-    hipEvent_t ev_begin, ev_end; HIPCHK(hipEventCreate(&ev_begin)); HIPCHK(hipEventCreate(&ev_end));
-    HIPCHK(hipEventRecord(ev_begin, s));
-
-    const RunSwitches sw = read_switches();
-    const bool timing = sw.timing;   // host wall-clock of the phases, to stderr
-    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_start = now();
-    // ---- 1. code frequencies of the training rows (features + the target itself)
-    std::vector<int32_t> cols(feat_cols, feat_cols + F); cols.push_back(target_col);
-    std::vector<int32_t> ncod(F + 1); std::vector<long long> cnt_off(F + 2, 0);
-    for (int f = 0; f <= F; ++f) { ncod[f] = tab.n_codes[cols[f]]; cnt_off[f + 1] = cnt_off[f] + std::max(ncod[f], 1); }
-    DevBuf<int32_t> d_cols(F + 1), d_ncod(F + 1); DevBuf<long long> d_cnt_off(F + 2); DevBuf<unsigned int> d_cnt(cnt_off[F + 1]);
-    d_cols.upload(cols.data(), F + 1, s); d_ncod.upload(ncod.data(), F + 1, s); d_cnt_off.upload(cnt_off.data(), F + 2, s); d_cnt.zero(s);
-    const int32_t* d_ycol = tab.codes.p + (long long)target_col * N;
-    {
-        int gx = (int)std::min<int64_t>((N + 255) / 256, 1024);
-        hipLaunchKernelGGL(k_count_codes, dim3(gx, F + 1), dim3(256), 0, s, tab.codes.p, (long long)N, d_ycol, d_cols.p, d_ncod.p, d_cnt_off.p, d_cnt.p);
-    }
-    // row-sharded: this table is one rank's row shard (rgbm_params.reserved bit 0 = RGBM_FLAG_ROW_SHARDED)
-    if ((p.reserved & RGBM_FLAG_ROW_SHARDED) && g_comm.kind == 0) throw std::invalid_argument("row-sharded training requested but this thread has no communicator (rgbm_comm_init)");
-    const bool dp = (p.reserved & RGBM_FLAG_ROW_SHARDED) != 0;
-    if (dp) all_reduce(d_cnt.p, (size_t)cnt_off[F + 1], AR_U32, s);
-    std::vector<unsigned int> cnt(cnt_off[F + 1]);
-    d_cnt.download(cnt.data(), cnt.size(), s);
-    if (dp) stream_sync_watchdog(s); else HIPCHK(hipStreamSynchronize(s));
+    const double* y_value = nullptr;
+    if (obj == 2) { h.yv32.resize(std::max(n_y, 1)); for (int c = 0; c < n_y; ++c) h.yv32[c] = (double)(float)y_value_in[c]; y_value = h.yv32.data(); }
     const unsigned int* ycnt = cnt.data() + cnt_off[F];
-    int64_t n_train = 0;
+    int64_t& n_train = h.n_train; n_train = 0;
     for (int c = 0; c < n_y; ++c) n_train += ycnt[c];
     if (n_train <= 0) throw std::out_of_range("no training rows (every target cell is NULL)");
     if (N >= (1ll << 31) - 4096) throw std::invalid_argument("more than 2^31 rows per table are not supported");
 
     // ---- 2. bins
-    auto model = new rgbm_model();
-    std::unique_ptr<rgbm_model> guard(model);
+    h.model.reset(new rgbm_model());
+    rgbm_model* model = h.model.get();
     model->objective = obj; model->num_class = obj == 1 ? K : (obj == 0 ? 2 : 1); model->K = K; model->F = F;
     model->feats.resize(F);
-    std::vector<FeatMeta> fmeta(F);
-    std::vector<long long> lut_off(F + 1, 0);
-    std::vector<uint8_t> miss(F), trivial(F);
+    std::vector<FeatMeta>& fmeta = h.fmeta; fmeta.assign(F, FeatMeta());
+    std::vector<long long>& lut_off = h.lut_off; lut_off.assign(F + 1, 0);
+    std::vector<uint8_t>& miss = h.miss; std::vector<uint8_t>& trivial = h.trivial; miss.assign(F, 0); trivial.assign(F, 0);
     int totbins = 0;
     for (int f = 0; f < F; ++f) {
         Feat& ft = model->feats[f];
@@ -541,15 +518,15 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         miss[f] = (uint8_t)(ft.has_nan ? ft.V : 0);
         lut_off[f + 1] = lut_off[f] + std::max(ncod[f], 1);
     }
-    std::vector<uint8_t> lut(lut_off[F]);
+    std::vector<uint8_t>& lut = h.lut; lut.assign(lut_off[F], 0);
     for (int f = 0; f < F; ++f) {
         const Feat& ft = model->feats[f];
         int b = 0;
         for (int c = 0; c < ncod[f]; ++c) { while (b < ft.V - 1 && c > ft.ub[b]) ++b; lut[lut_off[f] + c] = (uint8_t)(ft.V > 0 ? b : 0); }
     }
-    const int nchunk = (F + 15) / 16;
-    std::vector<ChunkMeta> cmeta(nchunk);
-    size_t lds_hist = 0;
+    const int nchunk = (F + 15) / 16; h.nchunk = nchunk;
+    std::vector<ChunkMeta>& cmeta = h.cmeta; cmeta.assign(nchunk, ChunkMeta());
+    size_t& lds_hist = h.lds_hist; lds_hist = 0;
     for (int ch = 0; ch < nchunk; ++ch) {
         ChunkMeta& cm = cmeta[ch]; cm.first_feat = ch * 16; cm.nfeat = std::min(16, F - ch * 16); cm.fast_slots = 0; cm.wide_bins = 0;
         for (int j = 0; j < cm.nfeat; ++j) {
@@ -576,7 +553,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (!(w_max > 0.0)) w_max = 1.0;
     double sumw = 0.0;
     for (int c = 0; c < nl; ++c) sumw += tot[c];
-    std::vector<double> init(K, 0.0);
+    std::vector<double>& init = h.init; init.assign(K, 0.0);
     double ymin = 0.0, ymax = 0.0;
     const double keps = k_eps();
     if (obj == 2) {
@@ -606,12 +583,69 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     // 2^50 in magnitude (the range of the rint trick) and an int64 sum over all training rows (of all ranks) stays below 2^62
     const int e_g = rg::fx_exponent(bound_g, sumw / w_max), e_h = rg::fx_exponent(bound_h, sumw / w_max);
 
-    TrainConst tc; memset(&tc, 0, sizeof(tc));
+    TrainConst& tc = h.tc; memset(&tc, 0, sizeof(tc));
     tc.sg = std::ldexp(1.0, e_g); tc.sh = std::ldexp(1.0, e_h); tc.inv_sg = std::ldexp(1.0, -e_g); tc.inv_sh = std::ldexp(1.0, -e_h);
     tc.l1 = p.lambda_l1; tc.l2 = p.lambda_l2; tc.min_gain_to_split = p.min_gain_to_split; tc.min_sum_hessian = p.min_sum_hessian_in_leaf;
     tc.learning_rate = p.learning_rate; tc.factor = factor; tc.min_data_in_leaf = p.min_data_in_leaf; tc.max_depth = p.max_depth;
     tc.num_leaves = p.num_leaves; tc.F = F; tc.K = K; tc.totbins = std::max(totbins, 1); tc.nchunk = nchunk; tc.objective = obj;
-    tc.N = N; tc.n_train = n_train;
+    tc.N = N; tc.n_train = n_train; tc.NG = N;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The trainer (GBDT::Train) on a resident table.
+// ---------------------------------------------------------------------------------------------
+rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t* feat_cols, int32_t F,
+                       const double* y_value, const double* class_weight, const double* sample_weight_host,
+                       const HostLabelStats* hls, const rgbm_params& p, rgbm_train_stats* stats) {
+    using namespace rg;
+    check_params(p);
+    if (F <= 0) throw std::invalid_argument("no feature columns");
+    if (target_col < 0 || target_col >= tab.c) throw std::invalid_argument("target column out of range");
+    for (int f = 0; f < F; ++f) if (feat_cols[f] < 0 || feat_cols[f] >= tab.c) throw std::invalid_argument("feature column out of range");
+    if (F > 65535) throw std::invalid_argument("more than 65535 feature columns");
+    const int64_t N = tab.n;
+    const int obj = p.objective;
+    const int n_y = tab.n_codes[target_col];
+    const int K = obj == 1 ? p.num_class : 1;
+    if (obj == 1 && n_y > p.num_class) throw std::out_of_range("target has more label codes than num_class");
+    if (obj == 0 && n_y > 2) throw std::out_of_range("binary objective with more than 2 label codes");
+    if (obj == 2 && !y_value) throw std::out_of_range("regression needs the y_value dictionary");
+    StreamGuard sg_; hipStream_t s = sg_.s;
+    hipEvent_t ev_begin, ev_end; HIPCHK(hipEventCreate(&ev_begin)); HIPCHK(hipEventCreate(&ev_end));
+    HIPCHK(hipEventRecord(ev_begin, s));
+
+    const RunSwitches sw = read_switches();
+    const bool timing = sw.timing;   // host wall-clock of the phases, to stderr
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    // ---- 1. code frequencies of the training rows (features + the target itself)
+    std::vector<int32_t> cols(feat_cols, feat_cols + F); cols.push_back(target_col);
+    std::vector<int32_t> ncod(F + 1); std::vector<long long> cnt_off(F + 2, 0);
+    for (int f = 0; f <= F; ++f) { ncod[f] = tab.n_codes[cols[f]]; cnt_off[f + 1] = cnt_off[f] + std::max(ncod[f], 1); }
+    DevBuf<int32_t> d_cols(F + 1), d_ncod(F + 1); DevBuf<long long> d_cnt_off(F + 2); DevBuf<unsigned int> d_cnt(cnt_off[F + 1]);
+    d_cols.upload(cols.data(), F + 1, s); d_ncod.upload(ncod.data(), F + 1, s); d_cnt_off.upload(cnt_off.data(), F + 2, s); d_cnt.zero(s);
+    const int32_t* d_ycol = tab.codes.p + (long long)target_col * N;
+    {
+        int gx = (int)std::min<int64_t>((N + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_count_codes, dim3(gx, F + 1), dim3(256), 0, s, tab.codes.p, (long long)N, d_ycol, d_cols.p, d_ncod.p, d_cnt_off.p, d_cnt.p);
+    }
+    // row-sharded: this table is one rank's row shard (rgbm_params.reserved bit 0 = RGBM_FLAG_ROW_SHARDED)
+    if ((p.reserved & RGBM_FLAG_ROW_SHARDED) && g_comm.kind == 0) throw std::invalid_argument("row-sharded training requested but this thread has no communicator (rgbm_comm_init)");
+    const bool dp = (p.reserved & RGBM_FLAG_ROW_SHARDED) != 0;
+    if (dp) all_reduce(d_cnt.p, (size_t)cnt_off[F + 1], AR_U32, s);
+    std::vector<unsigned int> cnt(cnt_off[F + 1]);
+    d_cnt.download(cnt.data(), cnt.size(), s);
+    if (dp) stream_sync_watchdog(s); else HIPCHK(hipStreamSynchronize(s));
+    FitHost fh; fh.cols = cols; fh.ncod = ncod; fh.cnt_off = cnt_off; fh.cnt = cnt;
+    fit_setup(tab, y_value, class_weight, hls, p, F, fh);
+    if (obj == 2) y_value = fh.yv32.data();          // LightGBM keeps labels as float32: the dictionary rounded once
+    const int64_t n_train = fh.n_train;
+    rgbm_model* model = fh.model.get();
+    std::unique_ptr<rgbm_model>& guard = fh.model;
+    std::vector<FeatMeta>& fmeta = fh.fmeta; std::vector<ChunkMeta>& cmeta = fh.cmeta;
+    std::vector<long long>& lut_off = fh.lut_off; std::vector<uint8_t>& lut = fh.lut; std::vector<uint8_t>& miss = fh.miss; std::vector<uint8_t>& trivial = fh.trivial;
+    const int nchunk = fh.nchunk; const size_t lds_hist = fh.lds_hist;
+    std::vector<double>& init = fh.init; TrainConst tc = fh.tc;
     const int NL = p.num_leaves, NE = p.n_estimators;
 
     const double t_bins = now();
@@ -633,7 +667,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         d_base.alloc(n_train);
         hipLaunchKernelGGL(k_iota_train, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, (long long)N, d_base.p, d_counter.p);
     }
-    DevBuf<float2> d_gh((size_t)K * N); d_gh.zero(s);      // float32 (g, h) of every (row, class tree); non-training rows stay (0, 0)
+    if (level_mode) tc.NG = (N + 255) & ~255ll;            // level grower: every wave tile of a class tree's (g, h) row is in bounds and 32-byte aligned
+    DevBuf<float2> d_gh((size_t)K * tc.NG); d_gh.zero(s);      // float32 (g, h) of every (row, class tree); non-training rows stay (0, 0)
     DevBuf<double> d_score((size_t)K * N), d_init(K);
     d_init.upload(init.data(), K, s);
     hipLaunchKernelGGL(k_init_score, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_score.p, (long long)N, K, d_init.p);
@@ -665,7 +700,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         lc.lds_bytes = LV_LDS_BYTES;
         if (sw.lv_lds >= 65536 && sw.lv_lds <= LV_LDS_BYTES) lc.lds_bytes = sw.lv_lds;      // testing: a smaller LDS pool forces several built-slot windows per level
         lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
-        lc.num_leaves = NL; lc.max_depth = p.max_depth; lc.min_data_in_leaf = p.min_data_in_leaf; lc.N = N; lc.NS = (N + 15) & ~15ll;
+        lc.num_leaves = NL; lc.max_depth = p.max_depth; lc.min_data_in_leaf = p.min_data_in_leaf; lc.N = N; lc.NS = (N + 255) & ~255ll; lc.NG = lc.NS;
         lc.sg = tc.sg; lc.sh = tc.sh;
         lc.sib_local = (dp && g_comm.rank == 0) ? 1 : 0;
         n_hnodes = (1 << p.max_depth) - 1;
@@ -702,13 +737,18 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             int G_first = 1;
             // tables of 17..32 features: ONE pass per level accumulates both 16-feature chunks (k_level_mt<2, ., ., MT_THREADS_ACC2, true>: both
             // records of a row in registers and in the ring) instead of one pass per chunk that streams every (node id, g, h) again
-            const bool acc2 = nchunk == 2 && sw.mt_acc2;
+            bool acc2 = nchunk == 2 && sw.mt_acc2;
+            if (acc2) {   // ... when one node's histograms of both chunks fit the LDS of the 768-thread workgroup (else: one pass per chunk, as for > 32 features)
+                const long long nb2 = ((long long)lv_slots(fmeta.data() + cmeta[0].first_feat, cmeta[0].nfeat, 0) + lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0)) * 16;
+                if (nb2 > lc.lds_bytes - mt_fixed_bytes(MT_THREADS_ACC2, true, sw.mt_spec != 0)) acc2 = false;
+            }
             for (int ch = 0; ch < (acc2 ? 1 : nchunk); ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
                 long long node_bytes = (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 16;
                 if (acc2) node_bytes += (long long)lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0) * 16;
-                const int mt_thr = acc2 ? MT_THREADS_ACC2 : ((nchunk == 1 && sw.mt_threads == 768) ? 768 : LV_THREADS);
-                long long cap = (lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2)) / std::max<long long>(node_bytes, 1);
+                const int mt_thr = acc2 ? MT_THREADS_ACC2 : ((nchunk == 1 && sw.mt_threads == 768 && sw.mt_spec != 1) ? 768 : LV_THREADS);
+                const bool spec = acc2 ? sw.mt_spec != 0 : (nchunk == 1 && sw.mt_spec == 1);
+                long long cap = (lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec)) / std::max<long long>(node_bytes, 1);
                 cap = std::min<long long>(cap, MT_MAX_NODES);
                 if (cap < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
                 const int win = (int)std::min<long long>(worst, cap);                    // built slots per launch
@@ -805,18 +845,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             std::lock_guard<std::mutex> lk(attr_mu);
             if (!attr_done[tab.device & 63]) {
                 HIPCHK(hipFuncSetAttribute((const void*)k_level_root, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-#define RGBM_MT_ATTR(NCHR, BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, true, LV_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
-                                HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, false, LV_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
-                RGBM_MT_ATTR(0, false); RGBM_MT_ATTR(1, false); RGBM_MT_ATTR(2, false); RGBM_MT_ATTR(0, true); RGBM_MT_ATTR(1, true); RGBM_MT_ATTR(2, true);
-#define RGBM_MT_ATTR2(BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<2, BAG, true, MT_THREADS_ACC2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
-                           HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<2, BAG, false, MT_THREADS_ACC2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
-                RGBM_MT_ATTR2(false); RGBM_MT_ATTR2(true);
-#define RGBM_MT_ATTR3(BAG) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<1, BAG, true, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES)); \
-                           HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<1, BAG, false, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
-                RGBM_MT_ATTR3(false); RGBM_MT_ATTR3(true);
-#undef RGBM_MT_ATTR3
-#undef RGBM_MT_ATTR2
+#define RGBM_MT_ATTR1(NCHR, BAG, ROUTE, THR, ACC, SPEC) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, ROUTE, THR, ACC, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
+#define RGBM_MT_ATTR(NCHR, THR, ACC, SPEC) RGBM_MT_ATTR1(NCHR, false, true, THR, ACC, SPEC); RGBM_MT_ATTR1(NCHR, false, false, THR, ACC, SPEC); \
+                                           RGBM_MT_ATTR1(NCHR, true, true, THR, ACC, SPEC); RGBM_MT_ATTR1(NCHR, true, false, THR, ACC, SPEC)
+                RGBM_MT_ATTR(0, LV_THREADS, false, false); RGBM_MT_ATTR(1, LV_THREADS, false, false); RGBM_MT_ATTR(2, LV_THREADS, false, false);
+                RGBM_MT_ATTR(2, MT_THREADS_ACC2, true, false); RGBM_MT_ATTR(1, 768, false, false);
+                RGBM_MT_ATTR(1, LV_THREADS, false, true); RGBM_MT_ATTR(2, MT_THREADS_ACC2, true, true);
 #undef RGBM_MT_ATTR
+#undef RGBM_MT_ATTR1
                 attr_done[tab.device & 63] = 1;
             }
         }
@@ -932,14 +968,18 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const dim3 grid((unsigned)L.G * (unsigned)L.gx);
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
-#define RGBM_LAUNCH_MT(NCHR, BAG, INBAG, THR, ACC) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+#define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, SPEC) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, SPEC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
                                                                           d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, l1); \
-                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, SPEC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
                                                                    d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, l1); } while (0)
-                if (L.acc2) { if (use_bagging) RGBM_LAUNCH_MT(2, true, d_inbag.p, MT_THREADS_ACC2, true); else RGBM_LAUNCH_MT(2, false, nullptr, MT_THREADS_ACC2, true); }
-                else if (nchr == 1 && sw.mt_threads == 768) { if (use_bagging) RGBM_LAUNCH_MT(1, true, d_inbag.p, 768, false); else RGBM_LAUNCH_MT(1, false, nullptr, 768, false); }
-                else if (use_bagging) { if (nchr == 1) RGBM_LAUNCH_MT(1, true, d_inbag.p, LV_THREADS, false); else if (nchr == 2) RGBM_LAUNCH_MT(2, true, d_inbag.p, LV_THREADS, false); else RGBM_LAUNCH_MT(0, true, d_inbag.p, LV_THREADS, false); }
-                else { if (nchr == 1) RGBM_LAUNCH_MT(1, false, nullptr, LV_THREADS, false); else if (nchr == 2) RGBM_LAUNCH_MT(2, false, nullptr, LV_THREADS, false); else RGBM_LAUNCH_MT(0, false, nullptr, LV_THREADS, false); }
+#define RGBM_LAUNCH_MT(NCHR, THR, ACC, SPEC) do { if (use_bagging) RGBM_LAUNCH_MT2(NCHR, true, d_inbag.p, THR, ACC, SPEC); else RGBM_LAUNCH_MT2(NCHR, false, nullptr, THR, ACC, SPEC); } while (0)
+                if (L.acc2) { if (sw.mt_spec != 0) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true); else RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, false); }
+                else if (nchr == 1 && sw.mt_spec == 1) RGBM_LAUNCH_MT(1, LV_THREADS, false, true);
+                else if (nchr == 1 && sw.mt_threads == 768) RGBM_LAUNCH_MT(1, 768, false, false);
+                else if (nchr == 1) RGBM_LAUNCH_MT(1, LV_THREADS, false, false);
+                else if (nchr == 2) RGBM_LAUNCH_MT(2, LV_THREADS, false, false);
+                else RGBM_LAUNCH_MT(0, LV_THREADS, false, false);
+#undef RGBM_LAUNCH_MT2
 #undef RGBM_LAUNCH_MT
             });
         }
@@ -1054,7 +1094,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         if (use_bagging && it % p.bagging_freq == 0) enqueue_bagging();
         cur_it = it;
         enqueue_grad();
-        trace_sum("gh", d_gh.p, (size_t)K * N * 8);
+        trace_sum("gh", d_gh.p, (size_t)K * tc.NG * 8);
         const uint8_t* usedp = d_used.p + (size_t)it * K * F;
         if (level_mode) {
             enqueue_level_growth();

@@ -59,6 +59,7 @@ struct TrainConst {
     double l1, l2, min_gain_to_split, min_sum_hessian, learning_rate, factor;
     int32_t min_data_in_leaf, max_depth, num_leaves, F, K, totbins, nchunk, objective;
     long long N, n_train;
+    long long NG;   // row stride of the (g, h) arrays [K][NG]: N, or N rounded up to a whole wave tile (level grower)
 };
 
 // packed tree node for the predictor: one 8-byte load per visit

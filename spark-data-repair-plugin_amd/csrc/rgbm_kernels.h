@@ -104,14 +104,15 @@ __global__ __launch_bounds__(256) void k_init_score(double* __restrict__ score, 
     for (int k = 0; k < K; ++k) score[(long long)k * N + i] = init[k];
 }
 
+// the rows first, first + stride, ... of one fit (k_grad: a grid-stride loop; k_small_grad: the same loop per fit of a batch)
 template <int OBJ>
-__global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, const int32_t* __restrict__ ycol,
-                                              const double* __restrict__ y_value, const double* __restrict__ class_w,
-                                              const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
-                                              float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
-                                              long long NS, TrainConst c) {
+__device__ __forceinline__ void grad_rows(long long first, long long stride, const double* __restrict__ score, const int32_t* __restrict__ ycol,
+                                          const double* __restrict__ y_value, const double* __restrict__ class_w,
+                                          const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
+                                          float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
+                                          long long NS, const TrainConst& c) {
     const long long N = c.N;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+    for (long long i = first; i < N; i += stride) {
         const int y = ycol[i];
         if (node0) {   // every training row restarts in node 0 (the root); all other rows never take part
             const int KK = (OBJ == 1) ? c.K : 1;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
         if (y < 0) continue;   // not a training row: its gh stays 0 for ever
         if (row_in_bag && !row_in_bag[i]) {   // out of bag this round: contributes nothing to any histogram
             const int K = (OBJ == 1) ? c.K : 1;
-            for (int k = 0; k < K; ++k) store_gh(gh, (long long)k * N + i, 0.0, 0.0);
+            for (int k = 0; k < K; ++k) store_gh(gh, (long long)k * c.NG + i, 0.0, 0.0);
             continue;
         }
         double wi = class_w ? class_w[y] : 1.0;
@@ -142,10 +143,19 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
             for (int k = 0; k < K; ++k) wsum += rg_exp(score[(long long)k * N + i] - wmax);
             for (int k = 0; k < K; ++k) {
                 double pk = rg_exp(score[(long long)k * N + i] - wmax) / wsum;
-                store_gh(gh, (long long)k * N + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);   // MulticlassSoftmax::GetGradients
+                store_gh(gh, (long long)k * c.NG + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);   // MulticlassSoftmax::GetGradients
             }
         }
     }
+}
+
+template <int OBJ>
+__global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+                                              const double* __restrict__ y_value, const double* __restrict__ class_w,
+                                              const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
+                                              float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
+                                              long long NS, TrainConst c) {
+    grad_rows<OBJ>((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, score, ycol, y_value, class_w, sample_w, row_in_bag, gh, node0, NS, c);
 }
 
 // Multiclass gradients, FP64-VALU bound (one exp, one division and two quantisations per row and class).
@@ -185,14 +195,14 @@ __global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ scor
     if (wv == 0) { double wsum = 0.0; for (int k = 0; k < K; ++k) wsum += tile[k * 64 + r]; psum[r] = wsum; }
     __syncthreads();
     if (!valid || y < 0) return;    // not a training row: its gh stays 0 for ever
-    if (out_of_bag) { for (int k = wv; k < K; k += 4) store_gh(gh, (long long)k * N + i, 0.0, 0.0); return; }
+    if (out_of_bag) { for (int k = wv; k < K; k += 4) store_gh(gh, (long long)k * c.NG + i, 0.0, 0.0); return; }
     double wi = class_w ? class_w[y] : 1.0;
     if (sample_w) wi = wi * sample_w[i];
     wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
     const double wsum = psum[r];
     for (int k = wv; k < K; k += 4) {
         const double pk = tile[k * 64 + r] / wsum;
-        store_gh(gh, (long long)k * N + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
+        store_gh(gh, (long long)k * c.NG + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
     }
 }
 
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ s
         for (int kk = 0; kk < K; ++kk) node0[(long long)kk * NS + i] = v;
     }
     if (y < 0) return;
-    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) store_gh(gh, (long long)kk * N + i, 0.0, 0.0); return; }
+    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) store_gh(gh, (long long)kk * c.NG + i, 0.0, 0.0); return; }
     double wi = class_w ? class_w[y] : 1.0;
     if (sample_w) wi = wi * sample_w[i];
     wi = (double)(float)wi;
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ s
     for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
     for (int kk = 0; kk < K; ++kk) {
         const double pk = tile[kk * R] / wsum;
-        store_gh(gh, (long long)kk * N + i, ((y == kk) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
+        store_gh(gh, (long long)kk * c.NG + i, ((y == kk) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
     }
 }
 
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
     const long long cnt = st.hist_is_root ? N : (long long)st.hist_count;
     const int32_t* idx = st.hist_buf == 0 ? idx0 + (long long)k * c.n_train : (st.hist_buf == 1 ? idx1 + (long long)k * c.n_train : base_idx);
     const uint4* recc = rec + (long long)ch * N;
-    const float2* ghk = gh + (long long)k * N;
+    const float2* ghk = gh + (long long)k * c.NG;
     const long long ntiles = (cnt + TILE_ROWS - 1) / TILE_ROWS;
 
     for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {

@@ -49,9 +49,16 @@ constexpr int MT_MAX_T = 64;                 // class trees per workgroup
 constexpr int MT_MAX_NODES = 128;            // built nodes per workgroup (all its class trees together)
 constexpr int MT_MAX_RT = 256;               // route / child-lookup entries per workgroup (<= 2^L per class tree)
 constexpr int MT_WT_ROWS = 256;              // rows of one wave tile: 4 consecutive rows per lane
-constexpr int MT_RING = 128;                 // entries of a wave's built-row ring: <= 63 waiting + <= 64 appended per row step
+#ifndef MT_RING_N
+#define MT_RING_N 128
+#endif
+constexpr int MT_RING = MT_RING_N;                 // entries of a wave's built-row ring: <= 63 waiting + <= 64 appended per row step
 constexpr int MT_CNT_REP = 8;
-constexpr int MT_THREADS_ACC2 = 768;         // workgroup of a two-chunk pass: 12 waves with 168 VGPRs each (two records per row stay in registers), a third less ring
+constexpr int MT_THREADS_ACC2 = 768;
+#ifndef MT_CONSUMERS_N
+#define MT_CONSUMERS_N 4
+#endif
+constexpr int MT_CONSUMERS = MT_CONSUMERS_N;              // wave-specialised pass: consumer waves of a workgroup (one per SIMD)         // workgroup of a two-chunk pass: 12 waves with 168 VGPRs each (two records per row stay in registers), a third less ring
 
 struct SNode {   // speculative node of one class tree
     long long Gq, Hq;
@@ -80,7 +87,7 @@ struct LevelConst {
     int32_t xcd_blocks;          // root pass: 1-D grid of K * gx blocks, contiguous row blocks, all class trees of a row block on one XCD
     // k_level_mt launch: class trees per workgroup, tree groups, chunk whose features are accumulated, built-slot window, routing?
     int32_t mt_T, mt_G, mt_ch, mt_slot0, mt_nslots, mt_route;
-    long long N, NS;             // rows; row stride of the node-id arrays (multiple of 16)
+    long long N, NS, NG;         // rows; row stride of the node-id arrays and of the (g, h) arrays (both N rounded up to a whole wave tile of 256 rows)
     double sg, sh;               // 2^e_g, 2^e_h: float32 (g, h) -> fixed point (fx_from_f32)
 };
 
@@ -113,11 +120,12 @@ __host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int q) {
 
 // bytes the root pass needs besides the histogram: nothing but alignment slack
 constexpr int LV_ROOT_FIXED = 256;
-// bytes k_level_mt needs besides the histogram: tree table | node -> tree map | scalars | per-feature flush table (32 features) | packed
+// bytes k_level_mt needs besides the histogram: tree table | node -> tree map | scalars | per-feature flush table (32 features) | ring
+// heads / tails / done flags | packed
 // tree entries | route entries | built-row counters | per-wave rings (record(s) 16 / 32 B + (g, h) 8 B + slot 2 B per entry) | slack
-__host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2) {
-    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
-           (long long)(threads / 64) * MT_RING * ((acc2 ? 32 : 16) + 8 + 2) + 256;
+__host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2, bool spec = false) {
+    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
+           (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * MT_RING * ((acc2 ? 32 : 16) + 8 + 2) + 256;     // (consumer waves have no ring)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
     const long long N = c.N;
     const uint8_t* node_in = node + (long long)k * c.NS;
     const uint4* recc = rec + (long long)ch * N;
-    const float2* ghk = gh + (long long)k * N;
+    const float2* ghk = gh + (long long)k * c.NG;
     const long long ntiles_all = (N + LV_TILE - 1) / LV_TILE;
     const long long tbeg = c.xcd_blocks ? ntiles_all * bx / nbx : bx;
     const long long ntiles = c.xcd_blocks ? ntiles_all * (bx + 1) / nbx : ntiles_all;
@@ -278,14 +286,17 @@ struct MtTree { int32_t base, nlev, rt_off, slot0, nb, live, child_first, k; }; 
 
 template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers), 0 = any number of chunks, the split byte is gathered */, bool BAG,
           bool ROUTE /* the first launch of a level: moves the rows to their children; later launches find the built rows by the final ids */,
-          int THREADS /* 1024, or MT_THREADS_ACC2 */, bool ACC2 /* NCHR == 2 only: the histograms of BOTH chunks are accumulated by this launch */>
+          int THREADS /* 1024, or MT_THREADS_ACC2 */, bool ACC2 /* NCHR == 2 only: the histograms of BOTH chunks are accumulated by this launch */,
+          bool SPEC /* wave-specialised: the last MT_CONSUMERS waves only run the batches (LDS atomics) out of the other waves' rings */>
 __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
                                                          const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                          int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
                                                          int32_t* __restrict__ err_flag, LevelConst c) {
     static_assert(!ACC2 || NCHR == 2, "a two-chunk pass keeps both records in registers");
     constexpr int WAVES = THREADS / 64;
+    constexpr int NCONS = SPEC ? MT_CONSUMERS : 0, NPROD = WAVES - NCONS;     // waves that walk the rows / waves that only run batches
     constexpr int NACC = ACC2 ? 2 : 1;                     // chunks accumulated by this launch
+    constexpr int NRINGS = SPEC ? NPROD : WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned id = blockIdx.x;
     const int xl = (int)(id & 7u), bslot = (int)(id >> 3);
@@ -310,14 +321,19 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     uint8_t* nd_tree = smem + MT_MAX_T * 32;                                                   // [MT_MAX_NODES] local node -> class tree of the workgroup
     int32_t* scal = reinterpret_cast<int32_t*>(nd_tree + MT_MAX_NODES);                        // [4] total built nodes, replication shift, slots per node, any live class tree
     int32_t* ftab = scal + 4;                                                                  // [4][32] per accumulated feature: first wide bin | first slot | replication shift | histogram offset
-    uint2* tpk = reinterpret_cast<uint2*>(ftab + 128);                                         // [MT_MAX_T + 2] what the row loop needs of a class tree: base | nlev << 8 | live << 31, rt_off | k << 16
+    uint32_t* rsync = reinterpret_cast<uint32_t*>(ftab + 128);                                 // [3][16] per ring: entries appended | entries consumed | producer finished
+    // (read / written with relaxed workgroup-scope atomics: real LDS instructions every time, never hoisted or merged; a `volatile`
+    // pointer loses the LDS address space and turns into FLAT accesses that wait for every outstanding global load)
+#define RS_LOAD(i) __hip_atomic_load(rsync + (i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RS_STORE(i, v) __hip_atomic_store(rsync + (i), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    uint2* tpk = reinterpret_cast<uint2*>(ftab + 128 + 64);                                    // [MT_MAX_T + 2] what the row loop needs of a class tree: base | nlev << 8 | live << 31, rt_off | k << 16
     uint2* rt = tpk + MT_MAX_T + 2;                                                            // [MT_MAX_RT] route entries / child -> slot entries
     int32_t* cnt = reinterpret_cast<int32_t*>(rt + MT_MAX_RT);                                 // [MT_MAX_NODES][MT_CNT_REP]
     uint4* ring_rec_all = reinterpret_cast<uint4*>(cnt + MT_MAX_NODES * MT_CNT_REP);           // [waves][MT_RING]
-    uint4* ring_rec1_all = ring_rec_all + (ACC2 ? WAVES * MT_RING : 0);                        // [waves][MT_RING] (two-chunk pass)
-    uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec1_all + WAVES * MT_RING);            // [waves][MT_RING]
-    uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + WAVES * MT_RING);        // [waves][MT_RING]
-    size_t off = reinterpret_cast<unsigned char*>(ring_li_all + WAVES * MT_RING) - smem;
+    uint4* ring_rec1_all = ring_rec_all + (ACC2 ? NRINGS * MT_RING : 0);                        // [waves][MT_RING] (two-chunk pass)
+    uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec1_all + NRINGS * MT_RING);            // [waves][MT_RING]
+    uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + NRINGS * MT_RING);        // [waves][MT_RING]
+    size_t off = reinterpret_cast<unsigned char*>(ring_li_all + NRINGS * MT_RING) - smem;
     off = (off + 15) & ~(size_t)15;
     unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem + off);     // [total][spn] gradient sums, then [total][spn] hessian sums (see k_level_root)
     const long long avail = (long long)c.lds_bytes - (long long)off;
@@ -391,6 +407,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         for (int i = tid; i < t.nb; i += THREADS) nd_tree[t.slot0 + i] = (uint8_t)kk;
     }
     for (int i = tid; i < total * MT_CNT_REP; i += THREADS) cnt[i] = 0;
+    if (tid < 48) rsync[tid] = 0u;            // (before the barrier below)
     unsigned long long* hist_h = hist_g + (size_t)total * spn;
     for (int i = tid; i < 2 * total * spn; i += THREADS) hist_g[i] = 0ull;
     // per accumulated feature: replication shift (scalar) and this lane's byte offset inside a node's slots (first slot + replica)
@@ -417,10 +434,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     const int hdelta = total * spn;
     __syncthreads();
 
-    uint4* ring_rec = ring_rec_all + wave * MT_RING;
-    uint4* ring_rec1 = ring_rec1_all + wave * MT_RING;
-    uint2* ring_gh = ring_gh_all + wave * MT_RING;
-    uint16_t* ring_li = ring_li_all + wave * MT_RING;
+    const int my_ring = wave < NRINGS ? wave : 0;               // (consumer waves never append)
+    uint4* ring_rec = ring_rec_all + my_ring * MT_RING;
+    uint4* ring_rec1 = ring_rec1_all + my_ring * MT_RING;
+    uint2* ring_gh = ring_gh_all + my_ring * MT_RING;
+    uint16_t* ring_li = ring_li_all + my_ring * MT_RING;
     int r_head = 0, r_cnt = 0;                                   // wave-uniform
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const unsigned spn8 = (unsigned)spn * 8u;
@@ -433,24 +451,29 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     };
 
     // one FULL (or final, partial) wave of histogram updates from the ring
-    auto run_batch = [&](int nb) __attribute__((always_inline)) {
+    // (ring `rid`, first entry `head`): the calling wave's own ring in the plain pass, a producer's ring in the wave-specialised one
+    auto run_batch_of = [&](int rid, int head, int nb) __attribute__((always_inline)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ring entries are read by other lanes of this wave
         const bool on = lane < nb;
-        const int pos = (r_head + lane) & (MT_RING - 1);
-        const uint4 r = ring_rec[pos]; const uint2 g = ring_gh[pos];
+        const int pos = rid * MT_RING + ((head + lane) & (MT_RING - 1));
+        const uint4 r = ring_rec_all[pos]; const uint2 g = ring_gh_all[pos];
         uint4 r1 = make_uint4(0, 0, 0, 0);
-        if (ACC2) r1 = ring_rec1[pos];
+        if (ACC2) r1 = ring_rec1_all[pos];
         unsigned li;
-        if (li_in_rec) li = (ACC2 ? r1.w : r.w) >> 24; else li = ring_li[pos];
-        r_head = (r_head + nb) & (MT_RING - 1); r_cnt -= nb;
+        if (li_in_rec) li = (ACC2 ? r1.w : r.w) >> 24; else li = ring_li_all[pos];
         if (on) {
             const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), c.sg), hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), c.sh);
             if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], 1);
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g) + li * spn8;
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
             const uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w};
+#if defined(MT_DBL_ATOM)   /* timing experiment: twice the LDS atomics, same sums */
+#define MT_ATOMIC_ADD(p, v) { atomicAdd(p, (v) - 1ull); atomicAdd(p, 1ull); }
+#else
+#define MT_ATOMIC_ADD(p, v) atomicAdd(p, v)
+#endif
 #define MT_ATOM(A, W, j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[A][j] + (int)(((W[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[A][j])); \
-                           atomicAdd(p_, gq); atomicAdd(p_ + hdelta, hq); }
+                           MT_ATOMIC_ADD(p_, gq); MT_ATOMIC_ADD(p_ + hdelta, hq); }
             if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
                 MT_ATOM(0, w, 0); MT_ATOM(0, w, 1); MT_ATOM(0, w, 2); MT_ATOM(0, w, 3); MT_ATOM(0, w, 4); MT_ATOM(0, w, 5); MT_ATOM(0, w, 6); MT_ATOM(0, w, 7);
                 MT_ATOM(0, w, 8); MT_ATOM(0, w, 9); MT_ATOM(0, w, 10); MT_ATOM(0, w, 11); MT_ATOM(0, w, 12); MT_ATOM(0, w, 13); MT_ATOM(0, w, 14);
@@ -471,137 +494,233 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                 }
             }
 #undef MT_ATOM
+#undef MT_ATOMIC_ADD
         }
     };
+    auto run_batch = [&](int nb) __attribute__((always_inline)) {
+        run_batch_of(wave, r_head, nb);
+        r_head = (r_head + nb) & (MT_RING - 1); r_cnt -= nb;
+    };
 
-    const long long N = c.N, NS = c.NS;
+    if (SPEC && wave >= NPROD) {
+        // ---- consumer wave: the batches of the rings cw, cw + NCONS, ...  A producer publishes how many entries it has appended
+        // (rsync[ring]) after writing them, this wave how many it has consumed (rsync[16 + ring]); LDS operations of one wave are
+        // carried out in order, so an entry is visible before the count that covers it.
+        const int cw = wave - NPROD;
+        constexpr int NR = SPEC ? (NPROD + MT_CONSUMERS - 1) / MT_CONSUMERS : 1;
+        uint32_t head[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) head[i] = 0u;
+        for (;;) {
+            bool any = false, all_done = true;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int rid = cw + i * MT_CONSUMERS;
+                if (rid >= NPROD) continue;
+                const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)RS_LOAD(32 + rid));     // read BEFORE the count: done => the count is final
+                asm volatile("" ::: "memory");
+                const uint32_t tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)RS_LOAD(rid));
+                asm volatile("" ::: "memory");
+                uint32_t avail = tail - head[i];
+                while (avail >= 64u) { run_batch_of(rid, (int)head[i], 64); head[i] += 64u; avail -= 64u; any = true; }
+                if (done && avail > 0u) { run_batch_of(rid, (int)head[i], (int)avail); head[i] += avail; avail = 0u; any = true; }
+                if (any) { asm volatile("" ::: "memory"); if (lane == 0) RS_STORE(16 + rid, head[i]); }
+                if (!done || avail > 0u) all_done = false;
+            }
+            if (all_done) break;
+            if (!any) __builtin_amdgcn_s_sleep(4);
+        }
+    }
+
+    uint32_t p_tail = 0u, p_head_seen = 0u;                       // producer of a wave-specialised pass: entries appended / known to be consumed
+    const long long N = c.N, NS = c.NS, NG = c.NG;
     const long long nwt_all = (N + MT_WT_ROWS - 1) / MT_WT_ROWS;
     const long long wt_lo = nwt_all * rb / c.gx, wt_hi = nwt_all * (rb + 1) / c.gx;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
     const uint4* rec_acc = rec + (long long)ch * N;                                  // the chunk whose features are accumulated
-    for (long long wt = wt_lo + wave; wt < wt_hi; wt += WAVES) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+
+    // ---- the three stages of a step = (wave tile of 256 rows: 4 consecutive rows per lane, class tree kk of the workgroup)
+    // records of a wave tile (+ the bag bits of its rows); rows past the end of the table read the last row and are masked out later
+    auto load_rec = [&](long long wt, uint4 (&ra)[4], uint4 (&r1)[4], uint32_t& bagmask) __attribute__((always_inline)) {
         const long long row0 = wt * MT_WT_ROWS + lane * 4;
-        const bool lane_on = row0 < N;
-        uint4 ra[4], r1[4];             // the accumulated chunk's records (a routing launch accumulates chunk 0: also the routing record); record 1 for routing / the two-chunk pass
-        uint32_t rowmask = 0u;          // bit j: row0 + j exists (and is in the bag)
+        bagmask = 0xFu;
+        if (BAG) bagmask = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             long long rr = row0 + j; if (rr >= N) rr = N - 1;
             ra[j] = rec_acc[rr];
             if (ACC2 || (route && NCHR == 2)) r1[j] = rec[N + rr]; else r1[j] = make_uint4(0, 0, 0, 0);
-            if (row0 + j < N) rowmask |= 1u << j;
+            if (BAG) bagmask |= (inbag[rr] ? 1u : 0u) << j;
         }
-        uint32_t bagmask = 0xFu;
-        if (BAG) { bagmask = 0u; for (int j = 0; j < 4; ++j) if (row0 + j < N && inbag[row0 + j]) bagmask |= 1u << j; }
-        // (node ids, g, h) of the class trees are requested TWO class trees ahead
-        uint32_t n4_a = 0xFFFFFFFFu, n4_b = 0xFFFFFFFFu; float4 ga0, ga1, gb0, gb1;
-        ga0 = ga1 = gb0 = gb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto fetch_tree = [&](int kk, uint32_t& n4, float4& g0, float4& g1) __attribute__((always_inline)) {
-            if (kk < nk && lane_on) {
-                const long long kq = k0 + kk;
-                // node ids and (g, h) are read once per level: non-temporal, so that they do not push the records -- which the other class
-                // tree groups of the row block re-read -- out of the XCD's L2
-                n4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(node + kq * NS + row0));
-                const float2* gp = gh + kq * N + row0;
-                if (row0 + 3 < N && ((kq * N + row0) & 1ll) == 0) {
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp)), b2 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp + 2));
-                    g0 = make_float4(a.x, a.y, a.z, a.w); g1 = make_float4(b2.x, b2.y, b2.z, b2.w);
-                }
-                else {
-                    float2 v[4];
-                    for (int j = 0; j < 4; ++j) { long long rr = row0 + j; if (rr >= N) rr = N - 1; v[j] = gh[kq * N + rr]; }
-                    g0 = make_float4(v[0].x, v[0].y, v[1].x, v[1].y); g1 = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
-                }
-            } else n4 = 0xFFFFFFFFu;
-        };
-        // Software pipeline over the class trees, three stages deep, so that no row step waits for a memory or LDS round trip
-        // (the LDS queue is full of other waves' atomics: a dependent lookup inside the row loop cost hundreds of cycles):
-        //   stage A (tree kk + 2): global loads of the node ids and (g, h); the tree's packed table entry (a readlane)
-        //   stage B (tree kk + 1): node ids have arrived -> table indices -> LDS reads of the four route entries
-        //   stage C (tree kk)    : route, append the built rows to the ring, run the batches
-        uint2 tq_a = tree_entry(0), tq_b = tree_entry(1);
-        fetch_tree(0, n4_a, ga0, ga1);
-        fetch_tree(1, n4_b, gb0, gb1);
-        uint2 e_a[4]; uint32_t in_a = 0u;
-        auto lookup = [&](uint32_t n4, const uint2 tq, uint2 (&e)[4], uint32_t& inm) __attribute__((always_inline)) {
-            const uint32_t tq0 = tq.x, tq1 = tq.y;       // scalar (tree_entry)
-            const uint32_t base = tq0 & 0xFFu, nlev = (tq0 >> 8) & 0x1FFu, rt_off = tq1 & 0xFFFFu;
-            inm = 0u;
+    };
+    // node ids and (g, h) of the tile's rows in class tree kk: read once per level, so non-temporal (they must not push the records --
+    // which the other class tree groups of the row block re-read -- out of the XCD's L2).  The rows of both arrays are padded to whole
+    // wave tiles (NS, NG), so the loads need neither a bounds check nor an alignment case: straight-line code, exact vmcnt bookkeeping.
+    auto load_tree = [&](long long wt, int kk, uint32_t& n4, float4& g0, float4& g1) __attribute__((always_inline)) {
+        const long long row0 = wt * MT_WT_ROWS + lane * 4, kq = k0 + kk;
+        n4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(node + kq * NS + row0));
+        const float2* gp = gh + kq * NG + row0;
+        const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp)), b2 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp + 2));
+        g0 = make_float4(a.x, a.y, a.z, a.w); g1 = make_float4(b2.x, b2.y, b2.z, b2.w);
+    };
+    auto row_mask = [&](long long wt) __attribute__((always_inline)) -> uint32_t {
+        const long long row0 = wt * MT_WT_ROWS + lane * 4;
+        uint32_t m = 0u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t idx = ((n4 >> (8 * j)) & 0xFFu) - base;
-                const bool in = (tq0 >> 31) != 0u && idx < nlev && ((rowmask >> j) & 1u);
-                inm |= in ? (1u << j) : 0u;
-                e[j] = rt[rt_off + (in ? idx : 0u)];
-            }
-        };
-        lookup(n4_a, tq_a, e_a, in_a);
-        for (int kk = 0; kk < nk; ++kk) {
-            // ---- rotate the pipeline
-            const uint32_t n4 = n4_a; const float4 g0 = ga0, g1 = ga1;
-            uint2 e[4]; const uint32_t inm = in_a; const uint2 tq = tq_a;
+        for (int j = 0; j < 4; ++j) if (row0 + j < N) m |= 1u << j;
+        return m;
+    };
+    // table indices of the four rows -> LDS reads of their route entries
+    auto lookup = [&](uint32_t n4, const uint2 tq, uint32_t rowmask, uint2 (&e)[4], uint32_t& inm) __attribute__((always_inline)) {
+        const uint32_t tq0 = tq.x, tq1 = tq.y;       // scalar (tree_entry)
+        const uint32_t base = tq0 & 0xFFu, nlev = (tq0 >> 8) & 0x1FFu, rt_off = tq1 & 0xFFFFu;
+        inm = 0u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = e_a[j];
-            n4_a = n4_b; ga0 = gb0; ga1 = gb1; tq_a = tq_b;
-            fetch_tree(kk + 2, n4_b, gb0, gb1);                     // stage A
-            tq_b = tree_entry(kk + 2);
-            lookup(n4_a, tq_a, e_a, in_a);                          // stage B (reads rt only: a table nobody writes during the row loop)
-            // ---- stage C
-            if (__ballot(inm != 0u) == 0ull) continue;               // no row of this wave tile sits in a node of the level (or the tree is finished)
-            uint32_t out4 = n4;
-            const float gg[4] = {g0.x, g0.z, g1.x, g1.z}, hh[4] = {g0.y, g0.w, g1.y, g1.w};
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t idx = ((n4 >> (8 * j)) & 0xFFu) - base;
+            const bool in = (tq0 >> 31) != 0u && idx < nlev && ((rowmask >> j) & 1u);
+            inm |= in ? (1u << j) : 0u;
+            e[j] = rt[rt_off + (in ? idx : 0u)];
+        }
+    };
+    // route the four rows, append the built ones to the ring (and, in the plain pass, run the batches)
+    auto stage_c = [&](long long wt, const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t bagmask, uint32_t n4, const float4 g0, const float4 g1,
+                       const uint2 (&e)[4], uint32_t inm, const uint2 tq) __attribute__((always_inline)) {
+        if (__ballot(inm != 0u) == 0ull) return;               // no row of this wave tile sits in a node of the level (or the tree is finished)
+        const long long row0 = wt * MT_WT_ROWS + lane * 4;
+        uint32_t out4 = n4;
+        const float gg[4] = {g0.x, g0.z, g1.x, g1.z}, hh[4] = {g0.y, g0.w, g1.y, g1.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool in = ((inm >> j) & 1u) != 0u;
-                unsigned li;
-                bool built;
-                if (ROUTE) {
-                    const uint32_t ex = e[j].x, ey = e[j].y;
-                    const bool expd = in && (ex & (1u << 24)) != 0u;
-                    const unsigned f = ex & 0xFFu;
-                    unsigned bin;
-                    if (NCHR == 0) {
-                        bin = 0u;
-                        if (expd) bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)];
-                    } else {
-                        uint32_t rx = ra[j].x, ry = ra[j].y, rz = ra[j].z, rw = ra[j].w;
-                        if (NCHR == 2) { const bool second = (f >> 4) != 0u; rx = second ? r1[j].x : rx; ry = second ? r1[j].y : ry; rz = second ? r1[j].z : rz; rw = second ? r1[j].w : rw; }
-                        const bool hi = (f & 8u) != 0u;
-                        const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
-                        bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
-                    }
-                    // left = (bin == nan bin) ? default-left : (bin < theta + 1), without a branch
-                    const uint32_t is_nan = (bin == ((ex >> 16) & 0xFFu)) ? 1u : 0u, lt = (bin < ((ex >> 8) & 0xFFu)) ? 1u : 0u;
-                    const uint32_t left = (is_nan & (ex >> 25)) | ((is_nan ^ 1u) & lt);
-                    const unsigned sel = (left & 1u) ? ey : (ey >> 8);     // child in bits 0..7, workgroup-local built slot in bits 16..23
-                    out4 = expd ? ((out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j))) : out4;
-                    li = (sel >> 16) & 0xFFu;
-                    built = expd && li != 0xFFu;
+        for (int j = 0; j < 4; ++j) {
+            const bool in = ((inm >> j) & 1u) != 0u;
+            unsigned li;
+            bool built;
+            if (ROUTE) {
+                const uint32_t ex = e[j].x, ey = e[j].y;
+                const bool expd = in && (ex & (1u << 24)) != 0u;
+                const unsigned f = ex & 0xFFu;
+                unsigned bin;
+                if (NCHR == 0) {
+                    bin = 0u;
+                    if (expd) bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)];
                 } else {
-                    li = e[j].y & 0xFFu;
-                    built = in && e[j].x != 0u;
+                    uint32_t rx = ra[j].x, ry = ra[j].y, rz = ra[j].z, rw = ra[j].w;
+                    if (NCHR == 2) { const bool second = (f >> 4) != 0u; rx = second ? r1[j].x : rx; ry = second ? r1[j].y : ry; rz = second ? r1[j].z : rz; rw = second ? r1[j].w : rw; }
+                    const bool hi = (f & 8u) != 0u;
+                    const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
+                    bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
                 }
-                if (BAG) built = built && ((bagmask >> j) & 1u);
-                const unsigned long long m = __ballot(built);
-                if (m != 0ull) {                                      // uniform
-                    if (built) {
-                        const int pos = (r_head + r_cnt + (int)__popcll(m & lane_lt)) & (MT_RING - 1);
-                        uint4 q0 = ra[j], q1 = r1[j];
-                        if (li_in_rec) { if (ACC2) q1.w = (q1.w & 0x00FFFFFFu) | (li << 24); else q0.w = (q0.w & 0x00FFFFFFu) | (li << 24); }
-                        else ring_li[pos] = (uint16_t)li;
-                        ring_rec[pos] = q0;
-                        if (ACC2) ring_rec1[pos] = q1;
-                        ring_gh[pos] = make_uint2(__float_as_uint(gg[j]), __float_as_uint(hh[j]));
-                    }
-                    r_cnt += (int)__popcll(m);
-                    if (r_cnt >= 64) run_batch(64);
-                }
+                // left = (bin == nan bin) ? default-left : (bin < theta + 1), without a branch
+                const uint32_t is_nan = (bin == ((ex >> 16) & 0xFFu)) ? 1u : 0u, lt = (bin < ((ex >> 8) & 0xFFu)) ? 1u : 0u;
+                const uint32_t left = (is_nan & (ex >> 25)) | ((is_nan ^ 1u) & lt);
+                const unsigned sel = (left & 1u) ? ey : (ey >> 8);     // child in bits 0..7, workgroup-local built slot in bits 16..23
+                out4 = expd ? ((out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j))) : out4;
+                li = (sel >> 16) & 0xFFu;
+                built = expd && li != 0xFFu;
+            } else {
+                li = e[j].y & 0xFFu;
+                built = in && e[j].x != 0u;
             }
-            if (ROUTE && out4 != n4) __builtin_nontemporal_store(out4, reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0));
+            if (BAG) built = built && ((bagmask >> j) & 1u);
+            const unsigned long long m = __ballot(built);
+            if (m != 0ull) {                                      // uniform
+                if (SPEC) {   // room for this row step's entries?  (the consumer is at most one batch behind a full ring)
+                    const uint32_t n_new = (uint32_t)__popcll(m);
+                    while (p_tail + n_new - p_head_seen > (uint32_t)MT_RING) {
+                        asm volatile("" ::: "memory");
+                        if (lane == 0) RS_STORE(wave, p_tail);        // the consumer must see the entries of this step's earlier rows to make room
+                        p_head_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)RS_LOAD(16 + wave));
+                        if (p_tail + n_new - p_head_seen > (uint32_t)MT_RING) __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                if (built) {
+                    const int pos = SPEC ? (int)((p_tail + (uint32_t)__popcll(m & lane_lt)) & (uint32_t)(MT_RING - 1))
+                                         : (r_head + r_cnt + (int)__popcll(m & lane_lt)) & (MT_RING - 1);
+                    uint4 q0 = ra[j], q1 = r1[j];
+                    if (li_in_rec) { if (ACC2) q1.w = (q1.w & 0x00FFFFFFu) | (li << 24); else q0.w = (q0.w & 0x00FFFFFFu) | (li << 24); }
+                    else ring_li[pos] = (uint16_t)li;
+                    ring_rec[pos] = q0;
+                    if (ACC2) ring_rec1[pos] = q1;
+                    ring_gh[pos] = make_uint2(__float_as_uint(gg[j]), __float_as_uint(hh[j]));
+                }
+                if (SPEC) p_tail += (uint32_t)__popcll(m);
+                else { r_cnt += (int)__popcll(m); if (r_cnt >= 64) run_batch(64); }
+            }
+        }
+        if (SPEC) { asm volatile("" ::: "memory"); if (lane == 0) RS_STORE(wave, p_tail); }     // publish (after the entries: in-order LDS)
+        if (ROUTE && out4 != n4) __builtin_nontemporal_store(out4, reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0));
+    };
+
+    if (SPEC) {
+        // ---- producer wave: ONE software pipeline over all its steps (tile-major, class trees inside), so that a wave always has the
+        // loads of two further steps in flight -- also when the workgroup holds a single class tree (deep levels: T = 1), where a
+        // per-tile pipeline has nothing to prefetch and every tile costs a full memory + LDS round trip (Little's law: 16 waves x one
+        // 6 KB step in flight per CU sustained ~3 TB/s).  Per iteration, in this order and unconditionally:
+        //   stage R (step q + 1): the tile's records;   stage A (step q + 2): node ids + (g, h);
+        //   stage B (step q + 1): route-table lookups;   stage C (step q): route + append.
+        // Past the last step the stages re-load the last step (never used), which keeps the loop body branch-free for the loads.
+        const long long my_first = wt_lo + wave;
+        const long long ntile_w = (wave < NPROD && my_first < wt_hi) ? (wt_hi - my_first + NPROD - 1) / NPROD : 0;
+        const long long Q = ntile_w * nk;
+        if (Q > 0) {
+            auto step_fwd = [&](long long& wt, int& kk) __attribute__((always_inline)) { if (++kk == nk) { kk = 0; wt += NPROD; } };
+            long long wt_c = my_first, wt_b = my_first, wt_a = my_first; int kk_c = 0, kk_b = 0, kk_a = 0;   // steps q, min(q + 1, Q - 1), min(q + 2, Q - 1)
+            if (Q > 1) step_fwd(wt_b, kk_b);
+            wt_a = wt_b; kk_a = kk_b;
+            if (Q > 2) step_fwd(wt_a, kk_a);
+            uint4 ra[4], r1[4], rn[4], r1n[4]; uint32_t bag_c, bag_n;
+            uint32_t n4_a, n4_b, n4_c; float4 ga0, ga1, gb0, gb1, gc0, gc1;
+            uint2 e_a[4], e_b[4]; uint32_t in_a = 0u, in_b = 0u;
+            load_rec(wt_c, ra, r1, bag_c);
+            load_tree(wt_c, kk_c, n4_a, ga0, ga1);
+            load_tree(wt_b, kk_b, n4_b, gb0, gb1);
+            lookup(n4_a, tree_entry(kk_c), row_mask(wt_c), e_a, in_a);
+            for (long long q = 0; q < Q; ++q) {
+                load_rec(wt_b, rn, r1n, bag_n);                                        // stage R
+                load_tree(wt_a, kk_a, n4_c, gc0, gc1);                                 // stage A
+                lookup(n4_b, tree_entry(kk_b), row_mask(wt_b), e_b, in_b);             // stage B
+                stage_c(wt_c, ra, r1, bag_c, n4_a, ga0, ga1, e_a, in_a, tree_entry(kk_c));   // stage C
+                // rotate
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ra[j] = rn[j]; r1[j] = r1n[j]; e_a[j] = e_b[j]; }
+                bag_c = bag_n; in_a = in_b;
+                n4_a = n4_b; ga0 = gb0; ga1 = gb1; n4_b = n4_c; gb0 = gc0; gb1 = gc1;
+                wt_c = wt_b; kk_c = kk_b; wt_b = wt_a; kk_b = kk_a;
+                if (q + 3 < Q) step_fwd(wt_a, kk_a);
+            }
+        }
+    } else {
+        // ---- plain pass: per wave tile, a pipeline over the class trees of the workgroup (node ids, g, h requested two trees ahead)
+        for (long long wt = wt_lo + wave; wt < wt_hi; wt += WAVES) {
+            uint4 ra[4], r1[4]; uint32_t bagmask;
+            load_rec(wt, ra, r1, bagmask);
+            const uint32_t rowmask = row_mask(wt);
+            uint32_t n4_a = 0xFFFFFFFFu, n4_b = 0xFFFFFFFFu; float4 ga0, ga1, gb0, gb1;
+            ga0 = ga1 = gb0 = gb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 tq_a = tree_entry(0), tq_b = tree_entry(1);
+            load_tree(wt, 0, n4_a, ga0, ga1);
+            if (nk > 1) load_tree(wt, 1, n4_b, gb0, gb1);
+            uint2 e_a[4]; uint32_t in_a = 0u;
+            lookup(n4_a, tq_a, rowmask, e_a, in_a);
+            for (int kk = 0; kk < nk; ++kk) {
+                // ---- rotate the pipeline
+                const uint32_t n4 = n4_a; const float4 g0 = ga0, g1 = ga1;
+                uint2 e[4]; const uint32_t inm = in_a; const uint2 tq = tq_a;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = e_a[j];
+                n4_a = n4_b; ga0 = gb0; ga1 = gb1; tq_a = tq_b;
+                if (kk + 2 < nk) load_tree(wt, kk + 2, n4_b, gb0, gb1); else n4_b = 0xFFFFFFFFu;     // stage A
+                tq_b = tree_entry(kk + 2);
+                lookup(n4_a, tq_a, rowmask, e_a, in_a);                 // stage B (reads rt only: a table nobody writes during the row loop)
+                stage_c(wt, ra, r1, bagmask, n4, g0, g1, e, inm, tq);   // stage C
+            }
         }
     }
-    while (r_cnt > 0) run_batch(r_cnt < 64 ? r_cnt : 64);
+    if (SPEC) { if (wave < NPROD) { asm volatile("" ::: "memory"); if (lane == 0) { RS_STORE(wave, p_tail); asm volatile("" ::: "memory"); RS_STORE(32 + wave, 1u); } } }
+#undef RS_LOAD
+#undef RS_STORE
+    else while (r_cnt > 0) run_batch(r_cnt < 64 ? r_cnt : 64);
     __syncthreads();
     // ---- flush this workgroup's partial histograms (plain stores: no global atomics, no zeroing) and the built-row counts
     constexpr int NQ = NACC * 16;
