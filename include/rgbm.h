@@ -153,6 +153,25 @@ int rgbm_table_train(const rgbm_table* t, int32_t target_col, const int32_t* fea
                      const double* y_value /* regression dictionary or NULL */,
                      const double* class_weight /* [n_codes[target]] or NULL */,
                      const rgbm_params* p, rgbm_model** out, rgbm_train_stats* stats);
+/* ---- many small fits in one go ------------------------------------------------------------------
+ * Replaces the LOOP over fits of python/repair/train.py:158-209 (every hyper-parameter trial is `cross_val_score`: n_splits fits of
+ * the same estimator on row subsets of one frame, train.py:171-172) and of python/repair/model.py:768-815 on the reference's default
+ * <= 10 000-row training samples (model.py:755-766).  Each spec is one rgbm_table_train call -- its own table (e.g. a fold gathered
+ * with rgbm_table_gather_rows), target, features, class weights and parameters -- and every model is the one that call returns, bit
+ * for bit; what changes is the schedule: all fits of the batch advance through their boosting iterations TOGETHER, three kernel
+ * launches per iteration for the whole batch (csrc/rgbm_small.h: one workgroup grows one class tree of one fit).  Fits the fused
+ * kernels do not cover (tables above RGBM_SMALL_ROWS = 65536 rows, more than 256 leaves, row-sharded calls) run one by one inside.
+ * out_status[i] = RGBM_OK or fit i's error code (out_models[i] = NULL then): one failing fit does not fail the batch, which is the
+ * reference's contract (train.py:227-229: a failing build yields PoorModel).  All tables must live on one device. */
+typedef struct {
+    const rgbm_table* table;
+    int32_t target_col, n_features;
+    const int32_t* feat_cols;
+    const double* y_value;        /* regression dictionary or NULL */
+    const double* class_weight;   /* [n_codes[target]] or NULL */
+    const rgbm_params* params;
+} rgbm_fit_spec;
+int rgbm_table_train_batch(const rgbm_fit_spec* fits, int32_t n_fits, rgbm_model** out_models /* [n_fits] */, int32_t* out_status /* [n_fits] */);
 /* Chained repair of rows [row_begin, row_begin+n_rows) of the resident table, in place in HBM.
  * out_label/out_prob [T][n_rows] are copied back to the host (either may be NULL). */
 int rgbm_table_repair_chain(rgbm_table* t, const rgbm_model* const* models, int32_t T,

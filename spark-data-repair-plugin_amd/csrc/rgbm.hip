@@ -30,6 +30,7 @@
 #include "rgbm_host.h"
 #include "rgbm_kernels.h"
 #include "rgbm_level.h"
+#include "rgbm_small.h"
 
 #define RGBM_VERSION 210   // numerics spec v2.1: float32 (g, h) as LightGBM computes them, exact integer histogram sums on a fixed-point grid of up to 2^50 per value (rgbm_numerics.h)
 
@@ -591,6 +592,42 @@ void fit_setup(const rgbm_table& tab, const double* y_value_in, const double* cl
     tc.N = N; tc.n_train = n_train; tc.NG = N;
 }
 
+// the trees as the trainer leaves them in its flat device arrays (TreeOut), copied to the host: -> the model's tree list
+struct HostTrees { const int32_t *L, *feat, *theta, *dleft, *left, *right, *cnt; const double *gain, *val; const int32_t* any; };
+void model_from_trees(rgbm_model* model, const HostTrees& h, int NE, int K, int NL) {
+    int n_iter = NE;
+    for (int it = 0; it < NE; ++it) if (!h.any[it]) { n_iter = it > 0 ? it : 1; break; }   // "no more leaves that meet the split requirements"
+    model->n_iter = n_iter;
+    model->trees.resize((size_t)n_iter * K);
+    for (size_t t = 0; t < (size_t)n_iter * K; ++t) {
+        Tree& tr = model->trees[t];
+        tr.L = h.L[t]; const int n = tr.L - 1;
+        const size_t nb = t * (NL - 1), lb = t * NL;
+        tr.feat.assign(h.feat + nb, h.feat + nb + n); tr.theta.assign(h.theta + nb, h.theta + nb + n);
+        tr.dleft.assign(h.dleft + nb, h.dleft + nb + n); tr.left.assign(h.left + nb, h.left + nb + n);
+        tr.right.assign(h.right + nb, h.right + nb + n); tr.gain.assign(h.gain + nb, h.gain + nb + n);
+        tr.leaf_value.assign(h.val + lb, h.val + lb + tr.L); tr.leaf_count.assign(h.cnt + lb, h.cnt + lb + tr.L);
+    }
+}
+
+// per-tree feature masks (ColSampler::ResetByTree), generated in LightGBM's draw order: [n_estimators * K][F]
+std::vector<uint8_t> make_used_masks(const rgbm_params& p, size_t NT, int F, const std::vector<uint8_t>& trivial) {
+    std::vector<uint8_t> used(NT * F, 0);
+    LgbRand sr((uint32_t)p.seed);
+    sr.rnd16(); sr.rnd16(); sr.rnd16();
+    LgbRand ff((uint32_t)sr.rnd16());
+    std::vector<int> valid; for (int f = 0; f < F; ++f) if (!trivial[f]) valid.push_back(f);
+    for (size_t t = 0; t < NT; ++t) {
+        uint8_t* u = used.data() + t * F;
+        if (p.feature_fraction < 1.0) {
+            int cntf = (int)std::floor((double)valid.size() * p.feature_fraction + 0.5);
+            if (cntf < 1) cntf = 1;
+            for (int i : ff.sample((int)valid.size(), cntf)) u[valid[i]] = 1;
+        } else for (int f : valid) u[f] = 1;
+    }
+    return used;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The trainer (GBDT::Train) on a resident table.
 // ---------------------------------------------------------------------------------------------
@@ -867,22 +904,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (y_value) { d_yv.alloc(n_y); d_yv.upload(y_value, n_y, s); }
     if (sample_weight_host) { d_sw.alloc(N); d_sw.upload(sample_weight_host, N, s); }
 
-    // per-tree feature masks (ColSampler::ResetByTree), generated in LightGBM's draw order
-    std::vector<uint8_t> used((size_t)NT * F, 0);
-    {
-        LgbRand sr((uint32_t)p.seed);
-        sr.rnd16(); sr.rnd16(); sr.rnd16();
-        LgbRand ff((uint32_t)sr.rnd16());
-        std::vector<int> valid; for (int f = 0; f < F; ++f) if (!trivial[f]) valid.push_back(f);
-        for (size_t t = 0; t < NT; ++t) {
-            uint8_t* u = used.data() + t * F;
-            if (p.feature_fraction < 1.0) {
-                int cntf = (int)std::floor((double)valid.size() * p.feature_fraction + 0.5);
-                if (cntf < 1) cntf = 1;
-                for (int i : ff.sample((int)valid.size(), cntf)) u[valid[i]] = 1;
-            } else for (int f : valid) u[f] = 1;
-        }
-    }
+    const std::vector<uint8_t> used = make_used_masks(p, NT, F, trivial);
     DevBuf<uint8_t> d_used(used.size()); d_used.upload(used.data(), used.size(), s);
 
     // bagging state (GBDT::Bagging): stable training-row order, one LCG per 1024 positions
@@ -1142,19 +1164,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     if (h_err & 2) throw std::runtime_error("level grower: a level pass was launched with more built nodes / route entries than its workgroup tables hold (sizing violated)");
     if (h_err) throw std::runtime_error("level grower: a node outside the speculative expansion was selected (expansion bound violated)");
 
-    int n_iter = NE;
-    for (int it = 0; it < NE; ++it) if (!hany[it]) { n_iter = it > 0 ? it : 1; break; }   // "no more leaves that meet the split requirements"
-    model->n_iter = n_iter;
-    model->trees.resize((size_t)n_iter * K);
-    for (size_t t = 0; t < (size_t)n_iter * K; ++t) {
-        Tree& tr = model->trees[t];
-        tr.L = hL[t]; const int n = tr.L - 1;
-        const size_t nb = t * (NL - 1), lb = t * NL;
-        tr.feat.assign(hfeat.begin() + nb, hfeat.begin() + nb + n); tr.theta.assign(htheta.begin() + nb, htheta.begin() + nb + n);
-        tr.dleft.assign(hdleft.begin() + nb, hdleft.begin() + nb + n); tr.left.assign(hleft.begin() + nb, hleft.begin() + nb + n);
-        tr.right.assign(hright.begin() + nb, hright.begin() + nb + n); tr.gain.assign(hgain.begin() + nb, hgain.begin() + nb + n);
-        tr.leaf_value.assign(hval.begin() + lb, hval.begin() + lb + tr.L); tr.leaf_count.assign(hcnt.begin() + lb, hcnt.begin() + lb + tr.L);
-    }
+    HostTrees ht{hL.data(), hfeat.data(), htheta.data(), hdleft.data(), hleft.data(), hright.data(), hcnt.data(), hgain.data(), hval.data(), hany.data()};
+    model_from_trees(model, ht, NE, K, NL);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ev_begin, ev_end)); stats->total_ms = ms;
@@ -1220,6 +1231,211 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     }
     (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
     return guard.release();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The batched small-table trainer (rgbm_small.h): many fits, three launches per boosting iteration for all of them.
+// Replaces the loop over fits of python/repair/train.py:158-209 (cross_val_score inside the hyper-parameter search: folds x
+// trials) and python/repair/model.py:768-815 on <= 10 000-row samples.  Every fit is an rgbm_table_train call in all but time:
+// the models are the same bytes.
+// ---------------------------------------------------------------------------------------------
+struct SmallFitDev {   // device state of one fit of a batch
+    FitHost h; int F = 0, K = 1, NL = 0, NE = 0; size_t NT = 0; bool bag = false; long long bag_nrb = 1;
+    DevBuf<int32_t> cols, ncod; DevBuf<long long> cnt_off, lut_off; DevBuf<unsigned int> cnt, counter;
+    DevBuf<rg::FeatMeta> fmeta; DevBuf<rg::ChunkMeta> cmeta; DevBuf<uint8_t> lut, miss, used, inbag;
+    DevBuf<uint4> rec; DevBuf<float2> gh; DevBuf<double> score, init, upd, cw, yv;
+    DevBuf<int32_t> idx0, idx1, base, tree_L, any, sorted_rows, oob; DevBuf<rg::HistBin> pool;
+    DevBuf<unsigned int> blk, rand, bagcnt;
+    DevBuf<int32_t> t_L, t_feat, t_theta, t_dleft, t_left, t_right, t_cnt; DevBuf<double> t_gain, t_val;
+    std::vector<int32_t> hL, hfeat, htheta, hdleft, hleft, hright, hcnt, hany; std::vector<double> hgain, hval;
+    std::vector<uint8_t> h_used; std::vector<unsigned int> h_rand;      // host sources of asynchronous uploads: alive until the batch has drained
+};
+
+bool small_fit_eligible(const rgbm_table& tab, int32_t F, const rgbm_params& p, long long small_rows) {
+    if (tab.n > small_rows || tab.n >= (1ll << 31) - 4096) return false;
+    if (p.num_leaves > rg::SM_MAX_LEAVES || F > rg::SM_MAX_FEATS) return false;
+    if (p.reserved & RGBM_FLAG_ROW_SHARDED) return false;
+    return true;
+}
+
+// status[i] = RGBM_OK or the error code of fit i (its message is the thread's last error when exactly one fit fails; the Python
+// binding raises per fit).  Fits the fused kernel does not cover (large tables, > 256 leaves) run through train_core one by one.
+void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** out, int32_t* status) {
+    using namespace rg;
+    long long small_rows = 65536;
+    if (const char* e = getenv("RGBM_SMALL_ROWS")) small_rows = atoll(e);
+    const int device = specs[0].table->device;
+    std::vector<int> batch;                                           // fits that go through the fused kernels
+    auto record_error = [&](int i, const std::exception& e, int code) { status[i] = code; rgh::last_error() = e.what(); };
+    auto run_single = [&](int i) {
+        const rgbm_fit_spec& sp = specs[i];
+        try { out[i] = train_core(*sp.table, sp.target_col, sp.feat_cols, sp.n_features, sp.y_value, sp.class_weight, nullptr, nullptr, *sp.params, nullptr); status[i] = RGBM_OK; }
+        catch (const std::invalid_argument& e) { record_error(i, e, RGBM_ERR_PARAM); }
+        catch (const std::out_of_range& e) { record_error(i, e, RGBM_ERR_LABEL); }
+        catch (const std::domain_error& e) { record_error(i, e, RGBM_ERR_NO_DEVICE); }
+        catch (const std::exception& e) { record_error(i, e, RGBM_ERR_HIP); }
+    };
+    for (int i = 0; i < n_fits; ++i) {
+        out[i] = nullptr; status[i] = RGBM_OK;
+        const rgbm_fit_spec& sp = specs[i];
+        if (!sp.table || !sp.feat_cols || !sp.params) { status[i] = RGBM_ERR_ARG; rgh::last_error() = "rgbm_table_train_batch: bad fit spec"; continue; }
+        if (sp.table->device != device) throw std::invalid_argument("rgbm_table_train_batch: all tables of a batch must live on one device");
+        if (small_fit_eligible(*sp.table, sp.n_features, *sp.params, small_rows)) batch.push_back(i); else run_single(i);
+    }
+    if (batch.empty()) return;
+    if (batch.size() == 1 && !getenv("RGBM_SMALL_ALWAYS")) { run_single(batch[0]); return; }    // one fit: the level grower's kernel chain is faster than one workgroup per class tree
+
+    StreamGuard sg_; hipStream_t s = sg_.s;
+    const bool timing = getenv("RGBM_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    std::vector<std::unique_ptr<SmallFitDev>> dev(n_fits);
+    // ---- A. argument checks + code frequencies of every fit's training rows (one launch per fit, ONE synchronisation for all)
+    std::vector<int> live;
+    for (int i : batch) {
+        const rgbm_fit_spec& sp = specs[i]; const rgbm_table& tab = *sp.table; const rgbm_params& p = *sp.params; const int F = sp.n_features;
+        try {
+            check_params(p);
+            if (F <= 0) throw std::invalid_argument("no feature columns");
+            if (sp.target_col < 0 || sp.target_col >= tab.c) throw std::invalid_argument("target column out of range");
+            for (int f = 0; f < F; ++f) if (sp.feat_cols[f] < 0 || sp.feat_cols[f] >= tab.c) throw std::invalid_argument("feature column out of range");
+            const int obj = p.objective, n_y = tab.n_codes[sp.target_col];
+            if (obj == 1 && n_y > p.num_class) throw std::out_of_range("target has more label codes than num_class");
+            if (obj == 0 && n_y > 2) throw std::out_of_range("binary objective with more than 2 label codes");
+            if (obj == 2 && !sp.y_value) throw std::out_of_range("regression needs the y_value dictionary");
+        }
+        catch (const std::invalid_argument& e) { record_error(i, e, RGBM_ERR_PARAM); continue; }
+        catch (const std::out_of_range& e) { record_error(i, e, RGBM_ERR_LABEL); continue; }
+        dev[i].reset(new SmallFitDev());
+        SmallFitDev& d = *dev[i]; FitHost& h = d.h;
+        d.F = F; d.K = p.objective == 1 ? p.num_class : 1; d.NL = p.num_leaves; d.NE = p.n_estimators; d.NT = (size_t)d.NE * d.K;
+        h.cols.assign(sp.feat_cols, sp.feat_cols + F); h.cols.push_back(sp.target_col);
+        h.ncod.resize(F + 1); h.cnt_off.assign(F + 2, 0);
+        for (int f = 0; f <= F; ++f) { h.ncod[f] = tab.n_codes[h.cols[f]]; h.cnt_off[f + 1] = h.cnt_off[f] + std::max(h.ncod[f], 1); }
+        d.cols.alloc(F + 1); d.ncod.alloc(F + 1); d.cnt_off.alloc(F + 2); d.cnt.alloc(h.cnt_off[F + 1]);
+        d.cols.upload(h.cols.data(), F + 1, s); d.ncod.upload(h.ncod.data(), F + 1, s); d.cnt_off.upload(h.cnt_off.data(), F + 2, s); d.cnt.zero(s);
+        const int32_t* d_ycol = tab.codes.p + (long long)sp.target_col * tab.n;
+        const int gx = (int)std::min<int64_t>((tab.n + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_count_codes, dim3(gx, F + 1), dim3(256), 0, s, tab.codes.p, (long long)tab.n, d_ycol, d.cols.p, d.ncod.p, d.cnt_off.p, d.cnt.p);
+        h.cnt.resize(h.cnt_off[F + 1]);
+        d.cnt.download(h.cnt.data(), h.cnt.size(), s);
+        live.push_back(i);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    // ---- B. per fit: bins, tables, records, state
+    std::vector<int> ok;
+    int NE_max = 0; size_t lds_max = 0; long long N_max = 1, ntrain_max = 1, nrb_max = 1; bool any_bag = false;
+    for (int i : live) {
+        const rgbm_fit_spec& sp = specs[i]; const rgbm_table& tab = *sp.table; const rgbm_params& p = *sp.params;
+        SmallFitDev& d = *dev[i]; FitHost& h = d.h; const int F = d.F, K = d.K, NL = d.NL, NE = d.NE; const long long N = tab.n;
+        try { fit_setup(tab, sp.y_value, sp.class_weight, nullptr, p, F, h); }
+        catch (const std::invalid_argument& e) { record_error(i, e, RGBM_ERR_PARAM); dev[i].reset(); continue; }
+        catch (const std::out_of_range& e) { record_error(i, e, RGBM_ERR_LABEL); dev[i].reset(); continue; }
+        const size_t lds = sm_lds_bytes(h.lds_hist, NL, F);
+        if (lds > 160 * 1024) { dev[i].reset(); run_single(i); continue; }          // (histogram working set of one chunk + leaves exceed the LDS)
+        const int nchunk = h.nchunk; const long long n_train = h.n_train;
+        d.fmeta.alloc(F); d.cmeta.alloc(nchunk); d.lut_off.alloc(F + 1); d.lut.alloc(std::max<size_t>(h.lut.size(), 1)); d.miss.alloc(F);
+        d.fmeta.upload(h.fmeta.data(), F, s); d.cmeta.upload(h.cmeta.data(), nchunk, s); d.lut_off.upload(h.lut_off.data(), F + 1, s);
+        d.lut.upload(h.lut.data(), h.lut.size(), s); d.miss.upload(h.miss.data(), F, s);
+        d.rec.alloc((size_t)nchunk * N);
+        hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tab.codes.p, N, 0ll, N, d.cols.p, d.ncod.p, d.lut_off.p, d.lut.p, d.miss.p, F, nchunk, d.rec.p);
+        const int32_t* d_ycol = tab.codes.p + (long long)sp.target_col * N;
+        d.bag = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
+        d.counter.alloc(1); d.counter.zero(s);
+        d.base.alloc(n_train);
+        hipLaunchKernelGGL(k_iota_train, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_ycol, N, d.base.p, d.counter.p);
+        d.gh.alloc((size_t)K * N); d.gh.zero(s);
+        d.score.alloc((size_t)K * N); d.init.alloc(K); d.init.upload(h.init.data(), K, s);
+        hipLaunchKernelGGL(k_init_score, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d.score.p, N, K, d.init.p);
+        d.idx0.alloc((size_t)K * n_train); d.idx1.alloc((size_t)K * n_train);
+        d.pool.alloc((size_t)K * NL * h.tc.totbins); d.upd.alloc((size_t)K * NL); d.tree_L.alloc(K); d.any.alloc(NE); d.any.zero(s);
+        const size_t NT = d.NT;
+        d.t_L.alloc(NT); d.t_feat.alloc(NT * (NL - 1)); d.t_theta.alloc(NT * (NL - 1)); d.t_dleft.alloc(NT * (NL - 1)); d.t_left.alloc(NT * (NL - 1)); d.t_right.alloc(NT * (NL - 1));
+        d.t_cnt.alloc(NT * NL); d.t_gain.alloc(NT * (NL - 1)); d.t_val.alloc(NT * NL); d.t_cnt.zero(s); d.t_val.zero(s);
+        const int n_y = h.ncod[F];
+        if (sp.class_weight) { d.cw.alloc(n_y); d.cw.upload(sp.class_weight, n_y, s); }
+        if (p.objective == 2) { d.yv.alloc(n_y); d.yv.upload(h.yv32.data(), n_y, s); }
+        d.h_used = make_used_masks(p, NT, F, h.trivial);
+        d.used.alloc(d.h_used.size()); d.used.upload(d.h_used.data(), d.h_used.size(), s);
+        if (d.bag) {   // GBDT::Bagging state: stable training-row order, one LCG per 1024 positions
+            const long long nblk = (N + 1023) / 1024;
+            d.blk.alloc(nblk); d.sorted_rows.alloc(n_train); d.oob.alloc(n_train); d.inbag.alloc(N); d.bagcnt.alloc(2);
+            hipLaunchKernelGGL(k_block_count, dim3((unsigned)nblk), dim3(256), 0, s, d_ycol, N, d.blk.p);
+            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, d.blk.p, nblk);
+            hipLaunchKernelGGL(k_stable_compact, dim3((unsigned)nblk), dim3(256), 0, s, d_ycol, N, d.blk.p, d.sorted_rows.p);
+            d.bag_nrb = std::max<long long>(1, (n_train + 1023) / 1024);
+            LgbRand sr2((uint32_t)p.seed); sr2.rnd16();
+            const int bagging_seed = sr2.rnd16();
+            d.h_rand.resize(d.bag_nrb);
+            for (long long b = 0; b < d.bag_nrb; ++b) d.h_rand[b] = (unsigned int)(bagging_seed + b);
+            d.rand.alloc(d.bag_nrb); d.rand.upload(d.h_rand.data(), d.bag_nrb, s);
+            any_bag = true; nrb_max = std::max(nrb_max, d.bag_nrb);
+        }
+        NE_max = std::max(NE_max, NE); lds_max = std::max(lds_max, lds); N_max = std::max(N_max, N); ntrain_max = std::max(ntrain_max, n_train);
+        ok.push_back(i);
+    }
+    if (ok.empty()) return;
+    if (timing) HIPCHK(hipStreamSynchronize(s));
+    const double t_setup = now();
+    // ---- C. descriptors
+    std::vector<SmallFit> fits(ok.size()); std::vector<int32_t> tree2fit;
+    for (size_t j = 0; j < ok.size(); ++j) {
+        const int i = ok[j]; const rgbm_fit_spec& sp = specs[i]; const rgbm_params& p = *sp.params; SmallFitDev& d = *dev[i]; FitHost& h = d.h;
+        SmallFit& f = fits[j]; memset(&f, 0, sizeof(f));
+        f.c = h.tc; f.rec = d.rec.p; f.ycol = sp.table->codes.p + (long long)sp.target_col * sp.table->n; f.gh = d.gh.p; f.score = d.score.p;
+        f.idx0 = d.idx0.p; f.idx1 = d.idx1.p; f.base_idx = d.base.p; f.pool = d.pool.p; f.fmeta = d.fmeta.p; f.cmeta = d.cmeta.p; f.used = d.used.p;
+        f.out = TreeOut{d.t_L.p, d.t_feat.p, d.t_theta.p, d.t_dleft.p, d.t_left.p, d.t_right.p, d.t_gain.p, d.t_val.p, d.t_cnt.p};
+        f.init = d.init.p; f.upd = d.upd.p; f.tree_L = d.tree_L.p; f.any_split = d.any.p;
+        f.class_w = sp.class_weight ? d.cw.p : nullptr; f.y_value = p.objective == 2 ? d.yv.p : nullptr;
+        f.rand_state = d.rand.p; f.sorted_rows = d.sorted_rows.p; f.inbag = d.inbag.p; f.bagcnt = d.bagcnt.p; f.oob = d.oob.p;
+        f.bag_fraction = p.bagging_fraction; f.bag_nrb = d.bag_nrb; f.bag_freq = d.bag ? p.bagging_freq : 0;
+        f.tree0 = (int32_t)tree2fit.size(); f.n_estimators = d.NE; f.lds_hist = (unsigned long long)h.lds_hist;
+        for (int k = 0; k < d.K; ++k) tree2fit.push_back((int32_t)j);
+    }
+    DevBuf<SmallFit> d_fits(fits.size()); DevBuf<int32_t> d_t2f(tree2fit.size());
+    d_fits.upload(fits.data(), fits.size(), s); d_t2f.upload(tree2fit.data(), tree2fit.size(), s);
+    {
+        static std::mutex attr_mu; static std::vector<char> attr_done(64, 0);
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (!attr_done[device & 63]) { HIPCHK(hipFuncSetAttribute((const void*)k_small_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); attr_done[device & 63] = 1; }
+    }
+    if (lds_max > 160 * 1024 - 2048) throw std::invalid_argument("small-table batch: histogram working set exceeds LDS");
+    // ---- D. the boosting iterations of the whole batch: enqueue only
+    const unsigned nf = (unsigned)fits.size(), KT = (unsigned)tree2fit.size();
+    const unsigned gx_rows = (unsigned)std::min<long long>((N_max + 255) / 256, 64), gx_train = (unsigned)std::min<long long>((ntrain_max + 255) / 256, 64);
+    for (int it = 0; it < NE_max; ++it) {
+        if (any_bag) {
+            hipLaunchKernelGGL(k_small_bagging, dim3((unsigned)((nrb_max + 63) / 64), nf), dim3(64), 0, s, d_fits.p, it);
+            hipLaunchKernelGGL(k_small_bag_lists, dim3(gx_train, nf), dim3(256), 0, s, d_fits.p, it);
+        }
+        hipLaunchKernelGGL(k_small_grad, dim3(gx_rows, nf), dim3(256), 0, s, d_fits.p, it);
+        hipLaunchKernelGGL(k_small_tree, dim3(KT), dim3(SM_THREADS), lds_max, s, d_fits.p, d_t2f.p, it);
+        if (any_bag) hipLaunchKernelGGL(k_small_oob, dim3(gx_train, KT), dim3(256), 0, s, d_fits.p, d_t2f.p, it);
+    }
+    HIPCHK(hipGetLastError());
+    const double t_enq = now();
+    if (timing) HIPCHK(hipStreamSynchronize(s));
+    const double t_iter = now();
+    // ---- E. trees back to the host, one model per fit
+    for (int i : ok) {
+        SmallFitDev& d = *dev[i]; const size_t NT = d.NT; const int NL = d.NL;
+        d.hL.resize(NT); d.hfeat.resize(NT * (NL - 1)); d.htheta.resize(NT * (NL - 1)); d.hdleft.resize(NT * (NL - 1)); d.hleft.resize(NT * (NL - 1)); d.hright.resize(NT * (NL - 1));
+        d.hcnt.resize(NT * NL); d.hany.resize(d.NE); d.hgain.resize(NT * (NL - 1)); d.hval.resize(NT * NL);
+        d.t_L.download(d.hL.data(), d.hL.size(), s); d.t_feat.download(d.hfeat.data(), d.hfeat.size(), s); d.t_theta.download(d.htheta.data(), d.htheta.size(), s);
+        d.t_dleft.download(d.hdleft.data(), d.hdleft.size(), s); d.t_left.download(d.hleft.data(), d.hleft.size(), s); d.t_right.download(d.hright.data(), d.hright.size(), s);
+        d.t_cnt.download(d.hcnt.data(), d.hcnt.size(), s); d.t_gain.download(d.hgain.data(), d.hgain.size(), s); d.t_val.download(d.hval.data(), d.hval.size(), s);
+        d.any.download(d.hany.data(), d.NE, s);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i : ok) {
+        SmallFitDev& d = *dev[i];
+        HostTrees ht{d.hL.data(), d.hfeat.data(), d.htheta.data(), d.hdleft.data(), d.hleft.data(), d.hright.data(), d.hcnt.data(), d.hgain.data(), d.hval.data(), d.hany.data()};
+        model_from_trees(d.h.model.get(), ht, d.NE, d.K, d.NL);
+        out[i] = d.h.model.release(); status[i] = RGBM_OK;
+    }
+    if (timing) fprintf(stderr, "[rgbm] batch of %zu fits, %u class trees, %d iterations: setup %.1f ms, enqueue %.1f ms, iterations drained after %.1f ms, download + models %.1f ms\n",
+                        ok.size(), KT, NE_max, t_setup - t_start, t_enq - t_setup, t_iter - t_setup, now() - t_iter);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1525,6 +1741,15 @@ RGBM_EXPORT int rgbm_table_train(const rgbm_table* t, int32_t target_col, const 
             if ((p->reserved & RGBM_FLAG_ROW_SHARDED) && g_comm.kind == 1) comm_abort();
             throw;
         }
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_table_train_batch(const rgbm_fit_spec* fits, int32_t n_fits, rgbm_model** out_models, int32_t* out_status) {
+    if (!fits || n_fits <= 0 || !out_models || !out_status || !fits[0].table) return fail(RGBM_ERR_ARG, "rgbm_table_train_batch: bad argument");
+    return guarded([&]() {
+        use_device(fits[0].table->device);
+        train_batch_small(fits, n_fits, out_models, out_status);
         return RGBM_OK;
     });
 }

@@ -54,8 +54,13 @@ struct SmallFit {   // one fit of a batch; lives in device memory, indexed by fi
     unsigned long long lds_hist;
 };
 
+// the histogram area doubles as the leaf-delta table of the final score update: at least num_leaves doubles
+__host__ __device__ inline size_t sm_hist_area(size_t lds_hist, int num_leaves) {
+    const size_t a = lds_hist > (size_t)num_leaves * 8 ? lds_hist : (size_t)num_leaves * 8;
+    return (a + 15) & ~(size_t)15;
+}
 __host__ __device__ inline size_t sm_lds_bytes(size_t lds_hist, int num_leaves, int F) {
-    size_t b = (lds_hist + 15) & ~(size_t)15;
+    size_t b = sm_hist_area(lds_hist, num_leaves);
     b += (size_t)num_leaves * sizeof(Leaf);
     b = (b + 15) & ~(size_t)15;
     b += (size_t)2 * F * sizeof(Cand);
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void k_small_oob(const SmallFit* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // k_small_tree: grid (class trees of the batch), block SM_THREADS; dynamic LDS = the largest sm_lds_bytes() of the batch
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SM_THREADS) void k_small_tree(const SmallFit* __restrict__ fits, const int32_t* __restrict__ tree2fit, int it) {
+__global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: two workgroups per CU */) void k_small_tree(const SmallFit* __restrict__ fits, const int32_t* __restrict__ tree2fit, int it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ TreeState st;
     __shared__ int wl[SM_WAVES], wr[SM_WAVES];
@@ -152,8 +157,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_tree(const SmallFit* __res
     const TrainConst c = sf.c;
     const int k = (int)blockIdx.x - sf.tree0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NL = c.num_leaves, F = c.F;
-    const size_t lds_hist = (size_t)sf.lds_hist;
-    size_t off = (lds_hist + 15) & ~(size_t)15;
+    size_t off = sm_hist_area((size_t)sf.lds_hist, NL);
     Leaf* lk = reinterpret_cast<Leaf*>(smem + off);
     off = (off + (size_t)NL * sizeof(Leaf) + 15) & ~(size_t)15;
     Cand* ck = reinterpret_cast<Cand*>(smem + off);

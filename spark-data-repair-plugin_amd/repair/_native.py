@@ -74,7 +74,7 @@ def lib():
         l = C.CDLL(path)
         l.rgbm_last_error.restype = C.c_char_p
         for name in ("rgbm_device_count", "rgbm_version", "rgbm_release_cache", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
-                     "rgbm_table_create", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
+                     "rgbm_table_create", "rgbm_table_train", "rgbm_table_train_batch", "rgbm_table_repair_chain", "rgbm_table_read_column",
                      "rgbm_model_save", "rgbm_model_load", "rgbm_model_info", "rgbm_model_importance",
                      "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
                      "rgbm_local_group_create", "rgbm_comm_init_local",
@@ -92,7 +92,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rgbm_device_count", "rgbm_last_error", "rgbm_version", "rgbm_release_cache", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
-    "rgbm_table_create", "rgbm_table_free", "rgbm_table_train", "rgbm_table_repair_chain", "rgbm_table_read_column",
+    "rgbm_table_create", "rgbm_table_free", "rgbm_table_train", "rgbm_table_train_batch", "rgbm_table_repair_chain", "rgbm_table_read_column",
     "rgbm_model_save", "rgbm_model_load", "rgbm_model_free", "rgbm_model_info", "rgbm_model_importance",
     "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
     "rgbm_local_group_create", "rgbm_local_group_free", "rgbm_comm_init_local",
@@ -232,6 +232,50 @@ def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample
                             C.byref(p), C.byref(h), C.byref(st) if want_stats else None), "rgbm_train")
     m = Model(h)
     return (m, st.as_dict()) if want_stats else m
+
+
+class RgbmFitSpec(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("target_col", C.c_int32), ("n_features", C.c_int32), ("feat_cols", C.POINTER(C.c_int32)),
+                ("y_value", C.POINTER(C.c_double)), ("class_weight", C.POINTER(C.c_double)), ("params", C.POINTER(RgbmParams))]
+
+
+def train_batch(fits):
+    """Many fits in one go (include/rgbm.h rgbm_table_train_batch): ``fits`` is a list of dicts with the arguments of
+    ``Table.train`` plus ``table`` -- dict(table=Table, target_col=int, feat_cols=[...], y_value=None, class_weight=None, **params).
+    Returns one entry per fit: the ``Model``, or the ``RepairGbmError`` of a fit that failed (a failing fit does not fail the
+    batch: the reference turns a failing build into PoorModel, python/repair/train.py:227-229).  Every model is the one
+    ``Table.train`` returns for the same arguments, bit for bit."""
+    n = len(fits)
+    if n == 0:
+        return []
+    specs = (RgbmFitSpec * n)()
+    keep = []
+    for i, f in enumerate(fits):
+        f = dict(f)
+        tab = f.pop("table")
+        fc = _i32(f.pop("feat_cols"))
+        yv, cw = _f64(f.pop("y_value", None)), _f64(f.pop("class_weight", None))
+        target = int(f.pop("target_col"))
+        f.setdefault("device_id", tab.device_id)
+        p = make_params(**f)
+        keep.append((tab, fc, yv, cw, p))
+        specs[i].table = tab.h
+        specs[i].target_col = target
+        specs[i].n_features = len(fc)
+        specs[i].feat_cols = _p(fc, C.c_int32)
+        specs[i].y_value = _p(yv, C.c_double)
+        specs[i].class_weight = _p(cw, C.c_double)
+        specs[i].params = C.pointer(p)
+    handles = (C.c_void_p * n)()
+    status = np.zeros(n, np.int32)
+    _check(lib().rgbm_table_train_batch(specs, C.c_int32(n), handles, _p(status, C.c_int32)), "rgbm_table_train_batch")
+    out = []
+    for i in range(n):
+        if status[i] == 0 and handles[i]:
+            out.append(Model(C.c_void_p(handles[i])))
+        else:
+            out.append(RepairGbmError("fit %d of the batch failed (%d): %s" % (i, int(status[i]), lib().rgbm_last_error().decode("utf-8", "replace"))))
+    return out
 
 
 def _chain_args(models, feat_cols, class_codes):

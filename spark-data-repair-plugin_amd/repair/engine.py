@@ -42,6 +42,18 @@ class HipEngine:
     def train(self, table, target, feats, class_weight, params, y_value=None, want_stats=False):
         return table.train(target, feats, y_value=y_value, class_weight=class_weight, want_stats=want_stats, **params)
 
+    @staticmethod
+    def small_rows():
+        """Tables up to this many rows train through the batched small-table trainer when several fits are at hand."""
+        import os
+        return int(os.environ.get("RGBM_SMALL_ROWS", "65536"))
+
+    def train_many(self, fits):
+        """Many fits in one batched call (rgbm_table_train_batch; include/rgbm.h): fits = [(table, target, feats, class_weight,
+        params, y_value), ...] -> [model or the exception of that fit].  Every model equals `train` on the same arguments."""
+        return _native.train_batch([dict(table=tab, target_col=t, feat_cols=feats, y_value=yv, class_weight=cw, **params)
+                                    for tab, t, feats, cw, params, yv in fits])
+
     def train_row_sharded(self, shard_table, target, feats, class_weight, params, y_value=None, want_stats=False):
         """Collective: every rank calls this for the same target with its own row shard (needs dist.init_row_comm)."""
         return shard_table.train(target, feats, y_value=y_value, class_weight=class_weight, want_stats=want_stats, row_sharded=True, **params)
@@ -187,17 +199,36 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     # not depend on any of this.
     conc = _train_concurrency(engine, train_table, [c for c in costs if c[0] in set(mine)] + list(big), train_concurrency,
                               search_fits=getattr(param_search, "fits_in_flight", 0) if param_search is not None else 0)
+    # The reference's default job trains every model on a <= 10 000-row sample (model.py:755-766): such fits are chains of tiny
+    # dependent kernels, so all of this rank's small fits go through ONE batched training call (rgbm_table_train_batch: one
+    # workgroup per (fit, class tree), three launches per boosting iteration for the whole batch); same models, bit for bit.
+    batched = []
+    if param_search is None and not want_stats and hasattr(engine, "train_many"):
+        batched = [t for t in mine if getattr(train_tables.get(t, train_table), "n", 1 << 62) <= engine.small_rows()]
+        if len(batched) < 2:
+            batched = []
+    if batched:
+        fits = []
+        for t in batched:
+            feats = [c for c in range(n_cols) if c != t]
+            fits.append((train_tables.get(t, train_table), t, feats, balanced_class_weight(label_counts[t]),
+                         model_params(int(n_codes[t]), dict(base_params), continuous=t in y_values), y_values.get(t)))
+        for t, m in zip(batched, engine.train_many(fits)):
+            if isinstance(m, Exception):
+                raise m
+            blobs[t] = m.save()
+    mine_single = [t for t in mine if t not in set(batched)]
     pool, futs = None, {}
-    if conc > 1 and len(mine) + len(big) > 1 and mine:
+    if conc > 1 and len(mine_single) + len(big) > 1 and mine_single:
         from concurrent.futures import ThreadPoolExecutor
         cost_of = dict(costs)
-        order = sorted(mine, key=lambda t: -cost_of[t])
+        order = sorted(mine_single, key=lambda t: -cost_of[t])
         pool = ThreadPoolExecutor(max_workers=max(1, conc - (1 if big else 0)))
         futs = {t: pool.submit(one, t, train_tables.get(t, train_table), engine.train) for t in order}
     try:
         for t, _ in big:                  # collective: same order on every rank, identical model everywhere
             shared[t] = one(t, row_table, engine.train_row_sharded)
-        for t in mine:
+        for t in mine_single:
             blobs[t] = futs[t].result() if pool is not None else one(t, train_tables.get(t, train_table), engine.train)
     finally:
         if pool is not None:

@@ -95,7 +95,32 @@ def search_on_table(engine, table, t, n_codes, base_params, opts, y_value=None, 
             return float(f1_score(truth, lab[0], average="macro"))
         return -float(mean_squared_error(np.asarray(y_value, np.float64)[truth], pr[0]))
 
-    point, _, _ = run_search(opts, folds, fold_score)
+    def score(m, vtab):
+        lab, pr = engine.repair_chain(vtab, [m], [t], [feats], 0, vtab.n)
+        truth = vtab.read_column(t)
+        if discrete:
+            return float(f1_score(truth, lab[0], average="macro"))
+        return -float(mean_squared_error(np.asarray(y_value, np.float64)[truth], pr[0]))
+
+    def batch_scores(jobs):
+        """All fold fits of a batch of evaluations through ONE batched training call (engine.train_many ->
+        rgbm_table_train_batch); a fit that fails yields its exception, like the fold_score future would."""
+        fits, vtabs = [], []
+        for point, (tr, va) in jobs:
+            ttab, vtab = table.gather_rows(np.sort(rows[tr])), table.gather_rows(np.sort(rows[va]))
+            cnt = ttab.count_codes(t)[0]
+            fits.append((ttab, t, feats, balanced_class_weight(cnt), model_params(int(n_codes[t]), core(point), continuous=not discrete), y_value))
+            vtabs.append(vtab)
+        out = []
+        for m, vtab in zip(engine.train_many(fits), vtabs):
+            try:
+                out.append(m if isinstance(m, Exception) else score(m, vtab))
+            except Exception as e:   # noqa: BLE001
+                out.append(e)
+        return out
+
+    use_batch = hasattr(engine, "train_many") and table.n <= engine.small_rows()
+    point, _, _ = run_search(opts, folds, fold_score, batch_scores=batch_scores if use_batch else None)
     return {_POINT_TO_CORE[k]: (int(v) if k in ("num_leaves", "subsample_freq", "min_child_samples") else float(v)) for k, v in point.items()}
 
 

@@ -105,11 +105,14 @@ def search_fits_in_flight(opts: Dict[str, str]) -> int:
     return max(1, int(g(_opt_batch_size))) * int(g(_opt_n_splits))
 
 
-def run_search(opts: Dict[str, str], n_folds_of: Any, fold_score: Any) -> Tuple[Dict[str, Any], float, int]:
+def run_search(opts: Dict[str, str], n_folds_of: Any, fold_score: Any, batch_scores: Any = None) -> Tuple[Dict[str, Any], float, int]:
     """The hyper-parameter search loop of train.py:133-209, independent of WHERE a fit runs.
 
     n_folds_of(seed) -> the CV folds of one evaluation (a list; shuffled with `seed`, train.py:158-173)
     fold_score(point, fold) -> the score of one fit (macro-F1 / -MSE) -- called from a thread pool, several at a time
+    batch_scores([(point, fold), ...]) -> [score or Exception, ...] (optional): ALL fits of a batch of evaluations in one call -- the
+        resident-table search hands them to the batched device trainer (rgbm_table_train_batch: one launch sequence for the whole
+        batch) instead of one training call per fit; same fits, same scores, same accounting
     Returns (best point, best score, evaluations).  Evaluation #0 is LightGBM's defaults for the searched parameters; the folds of
     `model.hp.batch_size` consecutive evaluations are in flight together (every fit owns a HIP stream); the no-progress / timeout
     rule is applied to the losses in trial order, so the outcome equals the sequential search."""
@@ -132,11 +135,29 @@ def run_search(opts: Dict[str, str], n_folds_of: Any, fold_score: Any) -> Tuple[
             futs: List[Any] = []
             if max_evals > 1:   # a single evaluation decides nothing: skip the CV fits
                 # ... train every CV fold of every point of the batch concurrently (one HIP stream per fit) ...
+                jobs: List[Any] = []
                 for i, point in enumerate(points):
                     try:
-                        futs.append([pool.submit(fold_score, point, fold) for fold in n_folds_of(len(trials) + i)])
+                        fl = n_folds_of(len(trials) + i)
+                        if batch_scores is not None:
+                            futs.append([len(jobs) + j for j in range(len(fl))])
+                            jobs.extend((point, fold) for fold in fl)
+                        else:
+                            futs.append([pool.submit(fold_score, point, fold) for fold in fl])
                     except Exception as e:   # noqa: BLE001
                         futs.append(e)
+                if batch_scores is not None and jobs:
+                    scored = batch_scores(jobs)
+
+                    class _Done:   # the future protocol of the loop below
+                        def __init__(self, v: Any) -> None:
+                            self.v = v
+
+                        def result(self) -> Any:
+                            if isinstance(self.v, Exception):
+                                raise self.v
+                            return self.v
+                    futs = [f if isinstance(f, Exception) else [_Done(scored[j]) for j in f] for f in futs]
             # ... and account for the losses in trial order, exactly like the sequential loop
             for i, point in enumerate(points):
                 if max_evals == 1:

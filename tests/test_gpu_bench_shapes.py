@@ -5,6 +5,12 @@ configs[3] (100M x 32: 12.5M rows x 32 columns -> two 16-feature chunks).  The o
 two hold the HIP trainer to the oracle at the real shapes: the K = 64 and the binary target of configs[2], and the K = 24
 target of a configs[3] shard, two boosting iterations each, serialised model bytes identical.  The oracle runs its histograms
 feature-parallel (OpenMP; bit-identical for any thread count), which keeps each case to a minute or two of host time.
+
+Round 4 adds the pin PAST iteration 2: tests/golden/bench_job_digests.json holds the oracle's per-iteration
+tree digests of the K = 64 and the binary target of the 10M x 16 job for 60 boosting iterations (20 minutes of host time, generated
+once by tests/golden/make_bench_job_golden.py); the HIP trainer trains those targets WITH FIVE OTHER TARGETS IN FLIGHT -- the
+bench's own schedule, where an intermediate build of round 3 once produced a second model from iteration 44 on -- and every one of
+the 60 iterations must carry the oracle's digest.
 """
 import os
 
@@ -52,3 +58,36 @@ def test_config3_per_gpu_shape_12_5m_x_32():
     assert int(cards[target]) == 24
     mg, mo = _both(dirty, cards, target, iters=2)
     assert mg == mo, "12.5M x 32 (two feature chunks), target c7: HIP model differs from the oracle"
+
+
+@pytest.mark.timeout(1800)
+def test_bench_job_60_iterations_with_six_targets_in_flight_match_the_oracle_digests():
+    """engine.run_job's schedule: the six most expensive targets of the 10M x 16 job train concurrently (one HIP stream each, host
+    threads); then the binary target next to five small ones.  Digest of EVERY boosting iteration == the committed oracle digests."""
+    import json
+    from concurrent.futures import ThreadPoolExecutor
+    from repair import _native as N
+    from tests.numerics_bound import iteration_digests
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_job_digests.json")))
+    assert gold["numerics_version"] == N.lib().rgbm_version(), "regenerate tests/golden/bench_job_digests.json (tests/golden/make_bench_job_golden.py)"
+    iters = int(gold["iters"])
+    dirty, clean, cards = make_table(gold["table"]["rows"], gold["table"]["cols"], seed=gold["table"]["seed"])
+    del clean
+    tab = N.Table(dirty, cards)
+
+    def fit(target):
+        feats = [c for c in range(dirty.shape[0]) if c != target]
+        K = int(cards[target])
+        return tab.train(target, feats, class_weight=balanced_weights(dirty[target], K), objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=iters).save()
+
+    for wave in ([10, 9, 8, 7, 6, 5], [0, 11, 1, 12, 2, 13]):
+        with ThreadPoolExecutor(len(wave)) as ex:
+            blobs = dict(zip(wave, ex.map(fit, wave)))
+        for t in wave:
+            g = gold["targets"].get("c%d" % t)
+            if g is None:
+                continue
+            got = iteration_digests(blobs[t])
+            assert len(got) == len(g["digests"]) == iters
+            bad = [i for i, (a, b) in enumerate(zip(got, g["digests"])) if a != b]
+            assert not bad, "target c%d (K=%d): iterations %s differ from the oracle (first at %d)" % (t, g["K"], bad[:8], bad[0])
