@@ -203,9 +203,20 @@ def main():
     cols = a.cols or cfg["cols"]
     targets = list(range(min(cfg["n_targets"], cols)))
 
+    # ---- multi-GPU, large table: every rank builds, uploads and keeps ONLY ITS ROW SHARD (rows [b0, b0 + c0) of the same table: the
+    # generator draws the chunks that overlap the range), every target is trained row-sharded over all ranks (integer all-reduce of
+    # histograms: same models as on one GPU), the rank repairs the dirty rows of its shard and the repaired cells are all-gathered.
+    # No rank ever holds the 12.8 GB table.  (Decided collectively: it needs the RCCL communicator on every rank.)
+    shard_only, row_base = False, 0
+    if world > 1 and a.mode == "auto" and rows * cols > 400_000_000 and not (0 < a.train_rows < rows):
+        shard_only = bool(rdist.init_row_comm(local_rank))
     # ---- inputs (outside the timed region: detector + encoder outputs, resident in HBM)
     t_gen = time.perf_counter()
-    if rows * cols > 400_000_000:
+    if shard_only:
+        row_base, c0 = rdist.shard_rows(rows, world, rank)
+        dirty, null_truth, cards = make_table_parallel(rows, cols, seed=cfg["seed"], threads=max(1, min(32, os.cpu_count() or 1) // max(1, min(world, 8))),
+                                                       row_range=(row_base, row_base + c0))
+    elif rows * cols > 400_000_000:
         dirty, null_truth, cards = make_table_parallel(rows, cols, seed=cfg["seed"], threads=min(32, os.cpu_count() or 1) // max(1, min(world, 4)) or 1)
     else:
         dirty, clean, cards = make_table(rows, cols, seed=cfg["seed"])
@@ -213,15 +224,20 @@ def main():
         del clean
     t_gen = time.perf_counter() - t_gen
     dirty_mask = (dirty[targets] < 0).any(axis=0)
-    dirty_pos = np.flatnonzero(dirty_mask)
+    dirty_pos = np.flatnonzero(dirty_mask) + row_base                    # positions in the whole table
     dirty_rows = np.ascontiguousarray(dirty[:, dirty_mask])
     n_cells = int((dirty_rows[targets] < 0).sum())
+    n_dirty_rows = int(dirty_rows.shape[1])
+    if shard_only:
+        n_cells, n_dirty_rows = int(rdist.sum_over_ranks(n_cells)), int(rdist.sum_over_ranks(n_dirty_rows))
     eng = HipEngine(device_id=local_rank)
     train_src = dirty
     if 0 < a.train_rows < rows:
         sel = np.sort(np.random.Generator(np.random.PCG64(7)).choice(rows, a.train_rows, replace=False))
         train_src = np.ascontiguousarray(dirty[:, sel])
     label_counts = {t: np.bincount(train_src[t][train_src[t] >= 0], minlength=int(cards[t])) for t in targets}
+    if shard_only:
+        label_counts = {t: rdist.sum_arrays(label_counts[t].astype(np.int64)) for t in targets}      # GLOBAL counts (class weights, costs)
     eng.upload(np.ascontiguousarray(train_src[:, :4096]), cards)   # creates the library's pinned staging ring (one-time hipHostMalloc, ~0.1 s) outside the upload figure
     torch.cuda.synchronize()
     t_up = time.perf_counter()
@@ -231,7 +247,9 @@ def main():
     t_up = time.perf_counter() - t_up
     upload_bytes = train_src.nbytes + dirty_rows.nbytes
     row_tab = None
-    if world > 1 and a.mode == "auto" and rdist.init_row_comm(local_rank):
+    if shard_only:
+        row_tab = train_tab
+    elif world > 1 and a.mode == "auto" and rdist.init_row_comm(local_rank):
         b0, c0 = rdist.shard_rows(train_src.shape[1], world, rank)
         row_tab = eng.upload(np.ascontiguousarray(train_src[:, b0:b0 + c0]), cards)
     elif world == 1 and a.force_row_sharding:
@@ -259,7 +277,11 @@ def main():
             ok = 1
             try:
                 ms = eng.train_row_sharded(row_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
-                ok = int(ms.save() == m_bytes)
+                if shard_only:   # no rank holds the whole table: the ranks must at least agree on the model, byte for byte
+                    digests = rdist.exchange_blobs({rank: hashlib.md5(ms.save()).digest()})
+                    ok = int(len(set(digests.values())) == 1)
+                else:
+                    ok = int(ms.save() == m_bytes)
             except Exception as e:  # noqa: BLE001
                 print("[bench] row-sharded warm-up failed on rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
                 ok = 0
@@ -267,6 +289,8 @@ def main():
                 flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
                 ok = int(flag.item())
+            if not ok and shard_only:
+                raise SystemExit("bench.py: the ranks of the row-sharded warm-up fit disagree on the model (or the fit failed); a shard-only job cannot fall back")
             if not ok:
                 from repair import _native
                 _native.comm_finalize()
@@ -275,7 +299,7 @@ def main():
 
     def plan_of(row_sharding):
         costs = [(t, (1 if int(cards[t]) <= 2 else int(cards[t])) * float(np.sum(label_counts[t])) * 1e-6) for t in targets]
-        pl = rdist.plan(costs, world, row_sharding, force=a.force_row_sharding)
+        pl = rdist.plan(costs, world, row_sharding, force=a.force_row_sharding, all_targets=shard_only)
         return {k: ([round(x, 1) for x in v] if k == "target_sharded_units_per_rank" else (round(v, 2) if isinstance(v, float) else v)) for k, v in pl.items()}
 
     def timed_job(n_estimators, want_stats=False, concurrency=None):
@@ -286,7 +310,7 @@ def main():
         rdist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = run_job(eng, train_tab, fresh, cards, targets, label_counts, params, want_stats=want_stats, row_table=row_tab,
-                      force_row_sharding=a.force_row_sharding, train_concurrency=concurrency)
+                      force_row_sharding=a.force_row_sharding, train_concurrency=concurrency, dirty_is_shard=shard_only, row_shard_all=shard_only)
         torch.cuda.synchronize(); rdist.barrier()
         return res, rdist.max_over_ranks(time.perf_counter() - t0)
 
@@ -314,6 +338,13 @@ def main():
     n_root = rdist.sum_over_ranks(roof_steps * len(res_roof["stats"]))       # one root launch per boosting iteration and trained model (nchunk = 1 workloads)
     train_s = rdist.max_over_ranks(res["times"]["train"]); infer_s = rdist.max_over_ranks(res["times"]["infer"])
 
+    fixed_shards = 0.0
+    if shard_only:   # every rank checks the cells of its own dirty rows against the clean values it generated
+        mine_l = res["labels"][:, res["dirty_row0"]:res["dirty_row0"] + dirty_rows.shape[1]]
+        for i, t in enumerate(targets):
+            pos, truth = null_truth[t]
+            fixed_shards += float((mine_l[i][np.searchsorted(dirty_pos, pos)] == truth).sum())
+        fixed_shards = rdist.sum_over_ranks(fixed_shards)
     out = None
     if rank == 0:
         labels = res["labels"]
@@ -322,8 +353,8 @@ def main():
             for t in targets:
                 with open(a.dump_labels + "_model_%d.bin" % t, "wb") as f:
                     f.write(res["models"][t])
-        fixed = 0
-        for i, t in enumerate(targets):
+        fixed = int(fixed_shards)
+        for i, t in enumerate(targets if not shard_only else []):
             pos, truth = null_truth[t]
             # the dirty table holds the dirty rows in ascending row order: map the nulled cells of t to their dirty-row index
             idx = np.searchsorted(dirty_pos, pos)
@@ -352,10 +383,12 @@ def main():
             "config": {"workload": "synthetic %dM rows x %d categorical cols, 1%% NULLs, seed %d (BASELINE %s); %d target attributes, "
                                    "n_estimators=%d (reference default), %s" % (rows // 1_000_000, cols, cfg["seed"], cfg["baseline"], len(targets), REF_N_ESTIMATORS,
                                                                                  "train on all rows" if not (0 < a.train_rows < rows) else "train on a %d-row sample (reference default)" % a.train_rows),
-                       "name": a.config, "rows": rows, "cols": cols, "targets": len(targets), "dirty_rows": int(dirty_rows.shape[1]),
+                       "name": a.config, "rows": rows, "cols": cols, "targets": len(targets), "dirty_rows": n_dirty_rows,
                        "error_cells": n_cells,
-                       "parallelism": ("hybrid x%d: targets %s row-sharded over all ranks (RCCL int64 all-reduce of histograms), rest target-sharded"
-                                       % (world, res["row_sharded_targets"])) if res["row_sharded_targets"] else "target-sharded x%d" % world,
+                       "parallelism": ("row-sharded x%d: every rank generates, uploads and keeps only its row shard; all %d targets trained over all ranks (RCCL int64 "
+                                       "all-reduce of histograms), dirty rows repaired where they live, repaired cells all-gathered" % (world, len(targets))) if shard_only else
+                                      (("hybrid x%d: targets %s row-sharded over all ranks (RCCL int64 all-reduce of histograms), rest target-sharded"
+                                        % (world, res["row_sharded_targets"])) if res["row_sharded_targets"] else "target-sharded x%d" % world),
                        # the schedule in cost units (class trees x training rows / 1e6), checkable without hardware: repair.dist.plan
                        "plan": plan_of(row_tab is not None or a.force_row_sharding)},
             "steps_region_sec": elapsed_k, "job_steps": job_steps, "elapsed_sec": elapsed,

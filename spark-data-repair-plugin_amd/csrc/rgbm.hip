@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <chrono>
 #include <cmath>
@@ -1428,12 +1429,22 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
         d.any.download(d.hany.data(), d.NE, s);
     }
     HIPCHK(hipStreamSynchronize(s));
-    for (int i : ok) {
-        SmallFitDev& d = *dev[i];
-        HostTrees ht{d.hL.data(), d.hfeat.data(), d.htheta.data(), d.hdleft.data(), d.hleft.data(), d.hright.data(), d.hcnt.data(), d.hgain.data(), d.hval.data(), d.hany.data()};
-        model_from_trees(d.h.model.get(), ht, d.NE, d.K, d.NL);
-        out[i] = d.h.model.release(); status[i] = RGBM_OK;
+    {   // the tree lists of the models: host work proportional to fits x iterations x class trees, spread over a few threads
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t j = next.fetch_add(1); j < ok.size(); j = next.fetch_add(1)) {
+                SmallFitDev& d = *dev[ok[j]];
+                HostTrees ht{d.hL.data(), d.hfeat.data(), d.htheta.data(), d.hdleft.data(), d.hleft.data(), d.hright.data(), d.hcnt.data(), d.hgain.data(), d.hval.data(), d.hany.data()};
+                model_from_trees(d.h.model.get(), ht, d.NE, d.K, d.NL);
+            }
+        };
+        const size_t nth = std::min<size_t>(std::min<size_t>(ok.size(), 16), std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (size_t q = 1; q < nth; ++q) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
     }
+    for (int i : ok) { out[i] = dev[i]->h.model.release(); status[i] = RGBM_OK; }
     if (timing) fprintf(stderr, "[rgbm] batch of %zu fits, %u class trees, %d iterations: setup %.1f ms, enqueue %.1f ms, iterations drained after %.1f ms, download + models %.1f ms\n",
                         ok.size(), KT, NE_max, t_setup - t_start, t_enq - t_setup, t_iter - t_setup, now() - t_iter);
 }

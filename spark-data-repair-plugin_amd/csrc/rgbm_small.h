@@ -28,7 +28,10 @@
 
 namespace rg {
 
-constexpr int SM_THREADS = 512;
+#ifndef SM_THREADS_N
+#define SM_THREADS_N 512
+#endif
+constexpr int SM_THREADS = SM_THREADS_N;
 constexpr int SM_WAVES = SM_THREADS / 64;
 constexpr int SM_MAX_LEAVES = 256;
 constexpr int SM_MAX_FEATS = 255;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void k_small_oob(const SmallFit* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // k_small_tree: grid (class trees of the batch), block SM_THREADS; dynamic LDS = the largest sm_lds_bytes() of the batch
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: two workgroups per CU */) void k_small_tree(const SmallFit* __restrict__ fits, const int32_t* __restrict__ tree2fit, int it) {
+__global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs, so that two 512-thread workgroups share a CU */) void k_small_tree(const SmallFit* __restrict__ fits, const int32_t* __restrict__ tree2fit, int it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ TreeState st;
     __shared__ int wl[SM_WAVES], wr[SM_WAVES];

@@ -50,7 +50,15 @@ def assign_targets(costs, world_size):
     return out
 
 
-def split_targets(costs, world_size, row_sharding, force=False):
+# What one boosting iteration of ONE target costs however few rows a rank holds, in the plan's cost units (class trees x 10^6 training
+# rows): the level grower is a chain of ~35 dependent kernels (plan / split-find / reduce / replay around the passes) of ~1.5 ms per
+# iteration on MI355X (binary target, 10M rows: 1.9-3.0 ms per iteration measured, profiles/r04e_*), where a K = 64 target on 10M rows
+# (640 units) takes 27 ms: 1.5 ms ~ 36 units; a row-sharded target adds one integer all-reduce per level (~7 x 30 us ~ 5 units).
+LAUNCH_FLOOR_UNITS = 36.0
+COLLECTIVE_UNITS = 5.0
+
+
+def split_targets(costs, world_size, row_sharding, force=False, all_targets=False):
     """(big, small): targets whose cost exceeds a QUARTER of a rank's fair share are trained row-sharded over all ranks (in the
     given order, identical on every rank); the rest is LPT-assigned rank by rank.
 
@@ -58,9 +66,12 @@ def split_targets(costs, world_size, row_sharding, force=False):
     target-sharded one sits on ONE rank whole.  With the round-2 threshold (half a fair share) the 100M x 32 job on 8 ranks kept
     the K in {2, 3, 4} targets whole: 66 / 8 + 4 = 12.25 of 74 units on the critical path = 6.04x before any overhead.  At a
     quarter only the binary target stays whole: 73 / 8 + 1 = 10.1 units = 7.3x (`plan` prints this for any job).
-    force: apply the rule of a 2-rank job even with one rank (single-GPU dry run of the collective path)."""
+    force: apply the rule of a 2-rank job even with one rank (single-GPU dry run of the collective path).
+    all_targets: every target is row-sharded (a job whose ranks hold nothing but their row shard)."""
     if not row_sharding or (world_size <= 1 and not force):
         return [], list(costs)
+    if all_targets:
+        return list(costs), []
     total = float(sum(c for _, c in costs))
     thr = total / (4.0 * max(world_size, 2))
     big = [(t, c) for t, c in costs if float(c) > thr]
@@ -68,20 +79,30 @@ def split_targets(costs, world_size, row_sharding, force=False):
     return big, small
 
 
-def plan(costs, world_size, row_sharding, force=False):
+def plan(costs, world_size, row_sharding, force=False, all_targets=False):
     """The schedule `engine.run_job` will follow, in cost units (class trees x training rows), so that it can be checked without
     hardware: which targets are row-sharded, the load every rank gets from the target-sharded ones, the critical path and the
-    speed-up it allows before collective / tail costs."""
-    big, small = split_targets(costs, world_size, row_sharding, force=force)
+    speed-up it allows before collective / tail costs -- and, when the costs are given in class trees x 10^6 rows, the same with the
+    per-iteration launch floor of every target and the per-level collectives of the row-sharded ones charged (`*_with_floor`): a
+    12.5 M-row shard of a 3-class target is launch-bound, and eight ranks do not make it eight times faster."""
+    big, small = split_targets(costs, world_size, row_sharding, force=force, all_targets=all_targets)
     total = float(sum(c for _, c in costs))
     assign = assign_targets(small, world_size)
     cost_of = dict(costs)
     loads = [float(sum(cost_of[t] for t in a)) for a in assign]
     shared = float(sum(c for _, c in big)) / max(world_size, 1)
     path = shared + (max(loads) if loads else 0.0)
+    # with the launch floor: the row-sharded targets train one after another on every rank, the target-sharded ones next to them
+    ws = max(world_size, 1)
+    floor_of = lambda c: max(float(c), LAUNCH_FLOOR_UNITS)   # noqa: E731
+    shared_f = float(sum(max(float(c) / ws, LAUNCH_FLOOR_UNITS) + (COLLECTIVE_UNITS if ws > 1 else 0.0) for _, c in big))
+    loads_f = [float(sum(floor_of(cost_of[t]) for t in a)) for a in assign]
+    path_f = shared_f + (max(loads_f) if loads_f else 0.0)
+    single_f = float(sum(floor_of(c) for _, c in costs))
     return dict(world_size=world_size, total_units=total, row_sharded=[t for t, _ in big], row_sharded_units_per_rank=shared,
                 target_sharded=assign, target_sharded_units_per_rank=loads, critical_path_units=path,
-                ideal_speedup=(total / path) if path > 0 else 1.0)
+                ideal_speedup=(total / path) if path > 0 else 1.0,
+                critical_path_units_with_floor=path_f, speedup_with_floor=(single_f / path_f) if path_f > 0 else 1.0)
 
 
 def init_row_comm(device_id):
@@ -181,6 +202,43 @@ def gather_rows(local, n_rows_total):
         b, c = shard_rows(n_rows_total, ws, r)
         res[:, b:b + c] = outs[r].cpu().numpy()[:, :c]
     return res
+
+
+def gather_rows_var(local):
+    """All-gather row shards whose sizes only the owning rank knows (every rank repairs the dirty rows of ITS row shard):
+    local [T][rows_of_rank] -> ([T][sum of the ranks' rows] in rank order, first row of this rank)."""
+    d = _dist()
+    local = np.ascontiguousarray(local)
+    if d is None or d.get_world_size() == 1:
+        return local, 0
+    import torch
+    dev = _tensor_device()
+    ws, rank = d.get_world_size(), d.get_rank()
+    T = local.shape[0]
+    n = torch.tensor([local.shape[1]], dtype=torch.int64, device=dev)
+    ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    d.all_gather(ns, n)
+    counts = [int(x.item()) for x in ns]
+    mx = max(max(counts), 1)
+    pad = np.zeros((T, mx), local.dtype)
+    pad[:, :local.shape[1]] = local
+    t = torch.from_numpy(pad).to(dev)
+    outs = [torch.zeros_like(t) for _ in range(ws)]
+    d.all_gather(outs, t)
+    res = np.concatenate([outs[r].cpu().numpy()[:, :counts[r]] for r in range(ws)], axis=1)
+    return res, int(sum(counts[:rank]))
+
+
+def sum_arrays(a):
+    """Element-wise sum of an integer / float array over the ranks (label counts of row shards)."""
+    d = _dist()
+    a = np.ascontiguousarray(a)
+    if d is None or d.get_world_size() == 1:
+        return a
+    import torch
+    t = torch.from_numpy(a.astype(np.float64 if a.dtype.kind == "f" else np.int64)).to(_tensor_device())
+    d.all_reduce(t, op=d.ReduceOp.SUM)
+    return t.cpu().numpy().astype(a.dtype)
 
 
 def barrier():

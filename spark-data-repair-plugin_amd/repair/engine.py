@@ -149,13 +149,18 @@ def _train_concurrency(engine, table, costs, requested, search_fits=0):
 
 
 def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, base_params, want_stats=False, row_table=None,
-            force_row_sharding=False, train_concurrency=None, y_values=None, integral=(), train_tables=None, param_search=None):
+            force_row_sharding=False, train_concurrency=None, y_values=None, integral=(), train_tables=None, param_search=None,
+            dirty_is_shard=False, row_shard_all=False):
     """Train + repair, sharded over the ranks of the current torch.distributed group (if any).
 
     train_table / dirty_table : engine tables (all rows with error cells NULLed / the dirty rows)
     label_counts[t]           : per-code row counts of target t over its non-NULL rows (GLOBAL counts)
     row_table                 : this rank's row shard of the training table; when given (and more than one rank),
                                 the expensive targets are trained row-sharded over ALL ranks (dist.split_targets)
+    row_shard_all             : every target is row-sharded (with `dirty_is_shard`: a job whose ranks hold nothing but their shard)
+    dirty_is_shard            : the dirty table holds the dirty rows of THIS rank's row shard only (a rank that never sees the whole
+                                table: every target is then row-sharded, train_table may be None); the rank repairs all of them and the
+                                all-gather concatenates the ranks' rows in rank order (`dirty_row0` = position of this rank's first row)
     y_values[t]               : CONTINUOUS targets only -- the ascending distinct values behind the codes of column t: the target gets
                                 an L2 regressor (train.py:97-100) on those values; `integral` names the ones rounded after prediction
     Returns dict(labels [T][D], probs [T][D], values [T][D] or None, models {target: bytes}, times, stats).
@@ -171,7 +176,7 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     for t in targets:
         k = int(n_codes[t])
         costs.append((t, (1 if (k <= 2 or t in y_values) else k) * float(np.sum(label_counts[t]))))
-    big, small = dist.split_targets(costs, ws, row_table is not None, force=force_row_sharding)
+    big, small = dist.split_targets(costs, ws, row_table is not None, force=force_row_sharding, all_targets=row_shard_all)
     mine = dist.assign_targets(small, ws)[rank]
     t0 = time.perf_counter()
     blobs, stats, shared = {}, [], {}
@@ -243,7 +248,7 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     # data-parallel chained inference on this rank's row shard
     t0 = time.perf_counter()
     D = dirty_table.n
-    b, c = dist.shard_rows(D, ws, rank)
+    b, c = (0, D) if dirty_is_shard else dist.shard_rows(D, ws, rank)
     feats_l = [[cc for cc in range(n_cols) if cc != t] for t in targets]
     if y_values:
         lab, prob, val = chained_repair(engine, dirty_table, models, targets, feats_l, b, c, y_values, integral)
@@ -253,9 +258,15 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     t_infer = time.perf_counter() - t0
     # C2: all-gather of the repaired cells
     t0 = time.perf_counter()
-    labels = dist.gather_rows(lab, D)
-    probs = dist.gather_rows(prob, D) if prob is not None else None
-    values = dist.gather_rows(val, D) if val is not None else None
+    row0 = 0
+    if dirty_is_shard:
+        labels, row0 = dist.gather_rows_var(lab)
+        probs = dist.gather_rows_var(prob)[0] if prob is not None else None
+        values = dist.gather_rows_var(val)[0] if val is not None else None
+    else:
+        labels = dist.gather_rows(lab, D)
+        probs = dist.gather_rows(prob, D) if prob is not None else None
+        values = dist.gather_rows(val, D) if val is not None else None
     t_gather = time.perf_counter() - t0
     return dict(labels=labels, probs=probs, values=values, models=all_blobs, stats=stats, my_targets=mine, row_sharded_targets=[t for t, _ in big],
-                times=dict(train=t_train, exchange=t_xchg, infer=t_infer, gather=t_gather))
+                dirty_row0=row0, times=dict(train=t_train, exchange=t_xchg, infer=t_infer, gather=t_gather))

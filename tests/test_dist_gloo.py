@@ -17,7 +17,7 @@ PARAMS = dict(num_leaves=15, max_depth=7, max_bin=255, min_data_in_leaf=20, min_
               bagging_fraction=1.0, feature_fraction=1.0, n_estimators=6)
 
 
-def _job(hybrid=False):
+def _job(hybrid=False, shard_only=False):
     from repair import dist as rdist
     from repair.engine import run_job
     from tests.helpers import OracleEngine
@@ -27,6 +27,16 @@ def _job(hybrid=False):
     mask = (dirty[targets] < 0).any(axis=0)
     eng = OracleEngine()
     row_table = None
+    if shard_only:   # bench.py --config 100m32 --gpus N: a rank sees nothing but its row shard (and the GLOBAL label counts, all-reduced)
+        rank, ws = rdist.world()
+        b, c = rdist.shard_rows(dirty.shape[1], ws, rank)
+        mine = np.ascontiguousarray(dirty[:, b:b + c])
+        local = {t: np.bincount(mine[t][mine[t] >= 0], minlength=int(cards[t])).astype(np.int64) for t in targets}
+        counts2 = {t: rdist.sum_arrays(local[t]) for t in targets}
+        assert all(np.array_equal(counts2[t], counts[t]) for t in targets)
+        shard = eng.upload(mine, cards)
+        return run_job(eng, shard, eng.upload(np.ascontiguousarray(mine[:, mask[b:b + c]]), cards), cards, targets, counts2, PARAMS,
+                       row_table=shard, row_shard_all=True, dirty_is_shard=True)
     if hybrid:
         rank, ws = rdist.world()
         b, c = rdist.shard_rows(dirty.shape[1], ws, rank)
@@ -36,13 +46,13 @@ def _job(hybrid=False):
     return res
 
 
-def _worker(rank, world, port, q, hybrid=False):
+def _worker(rank, world, port, q, hybrid=False, shard_only=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spark-data-repair-plugin_amd"))
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _job(hybrid)
+        res = _job(hybrid, shard_only)
         q.put((rank, res["labels"], res["probs"], sorted(res["models"].items()), res["my_targets"] + res["row_sharded_targets"]))
     finally:
         dist.destroy_process_group()
@@ -164,3 +174,38 @@ def test_two_rank_gloo_pipeline_equals_single_process():
         for k, v in arrays.items():
             assert np.array_equal(v, single[k]), "rank %d: %s" % (rank, k)
         assert models == sorted(single["models"].items())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_shard_only_job_equals_single_process(world):
+    """bench.py's multi-GPU mode for the 100M x 32 table: every rank holds ONLY its row shard (training rows and dirty rows), every
+    target is row-sharded, the repaired cells of the ranks' own dirty rows are all-gathered with sizes only the owners know.  Models,
+    labels and probabilities equal the single-process job; 3 ranks make the shards (and the dirty-row counts) uneven."""
+    import torch.multiprocessing as mp
+    single = _job()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, False, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, labels, probs, models, trained in outs:
+        assert np.array_equal(labels, single["labels"])
+        assert np.array_equal(probs, single["probs"])
+        assert models == sorted(single["models"].items())
+        assert sorted(trained) == [0, 2, 3, 5]                    # every target went through the collective path on every rank
+
+
+def test_plan_charges_launch_floor_and_collectives():
+    from repair import dist
+    north = [(0, 100.0), (1, 300.0), (2, 400.0), (3, 600.0), (4, 800.0), (5, 1200.0), (6, 1600.0), (7, 2400.0)]     # class trees x 10^6 rows, 100M x 32
+    pl = dist.plan(north, 8, True, all_targets=True)
+    assert pl["row_sharded"] == list(range(8)) and abs(pl["ideal_speedup"] - 8.0) < 1e-9
+    assert 7.0 < pl["speedup_with_floor"] < 8.0            # 7.5: the floor costs the cheap targets, the collectives all of them
+    tiny = [(t, 30.0) for t in range(8)]                    # eight targets below the launch floor: eight ranks cannot make row sharding pay
+    assert dist.plan(tiny, 8, True, all_targets=True)["speedup_with_floor"] < 1.0
+    assert dist.plan(tiny, 8, False)["speedup_with_floor"] >= 7.9    # ... target sharding does
