@@ -452,6 +452,8 @@ void check_params(const rgbm_params& p) {
     if (p.num_leaves < 2 || p.num_leaves > 32767) throw std::invalid_argument("num_leaves must be in [2, 32767]");
     if (p.n_estimators < 1) throw std::invalid_argument("n_estimators must be positive");
     if (!(p.learning_rate > 0.0)) throw std::invalid_argument("learning_rate must be positive");
+    // regression: the fixed-point grid of the histogram sums is sized for |score - y| <= (max y - min y), which a shrinkage above 1 can break
+    if (p.objective == 2 && p.learning_rate > 1.0) throw std::invalid_argument("regression with learning_rate > 1 is not supported");
     if (p.objective == 1 && p.num_class < 2) throw std::invalid_argument("multiclass needs num_class >= 2");
     if (p.min_data_in_leaf < 0 || p.lambda_l1 < 0 || p.lambda_l2 < 0) throw std::invalid_argument("negative regularisation / min_data_in_leaf");
     if (p.bagging_fraction <= 0.0 || p.bagging_fraction > 1.0) throw std::invalid_argument("bagging_fraction must be in (0, 1]");

@@ -235,6 +235,12 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
             shared[t] = one(t, row_table, engine.train_row_sharded)
         for t in mine_single:
             blobs[t] = futs[t].result() if pool is not None else one(t, train_tables.get(t, train_table), engine.train)
+    except BaseException:
+        # a failing fit must surface now: do not sit out the queued fits first (the peers of a collective job are waiting)
+        if pool is not None:
+            pool.shutdown(wait=False, cancel_futures=True)
+            pool = None
+        raise
     finally:
         if pool is not None:
             pool.shutdown(wait=True)

@@ -14,6 +14,9 @@ import time
 import numpy as np
 
 from repair.engine import run_job
+from repair.utils import setup_logger
+
+_logger = setup_logger()
 
 
 def _merge_cells(n, parts):
@@ -130,6 +133,17 @@ class NotResidentEligible(ValueError):
     (model.py:1008-1017, 779-783); `RepairModel._run` catches this and takes the value-space path, which has that short-cut."""
 
 
+class DeadClasses(NotResidentEligible):
+    """Detection ran on the device and found error cells that hold the ONLY occurrences of some values of a target attribute: the
+    dictionaries were built before the cells were known, so those values would stay behind as classes without rows.  Carries the
+    detected cells (row positions, column indices): `repair_frame` NULLs them in the dictionary indices, drops the dead values,
+    uploads again and goes on WITHOUT detecting a second time (and without leaving the resident path)."""
+
+    def __init__(self, msg, rows, cols):
+        super().__init__(msg)
+        self.rows, self.cols = np.asarray(rows, np.int64), np.asarray(cols, np.int32)
+
+
 class UnseenCategories(NotResidentEligible):
     """A dirty row holds a categorical feature value that none of the target's training rows has (see `unseen_categories`)."""
 
@@ -213,7 +227,7 @@ def repair_table(engine, table, targets, base_params, constraints=(), detect_nul
             if int((cnt > 0).sum()) < 1:
                 raise NotResidentEligible("continuous target column %d has no non-NULL row to learn from" % t)
         elif only_noisy_targets and int((cnt > 0).sum()) < len(cnt):
-            raise NotResidentEligible("target column %d: %d of its %d values are held by error cells only" % (t, int((cnt <= 0).sum()), len(cnt)))
+            raise DeadClasses("target column %d: %d of its %d values are held by error cells only" % (t, int((cnt <= 0).sum()), len(cnt)), rows, cols)
         elif int((cnt > 0).sum()) < 2:
             raise NotResidentEligible("target column %d has fewer than two classes among its non-NULL rows; the reference short-cuts such "
                              "attributes with a constant model (model.py:1008-1017) -- drop it from `targets`" % t)
@@ -332,19 +346,15 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
     indices, remaps, dicts = encode_frame(df, cols)
     pos = {c: i for i, c in enumerate(cols)}
     cells, given_current = None, None
-    if error_cells is not None:
-        if row_id not in error_cells.columns or "attribute" not in error_cells.columns:
-            raise ValueError("Error cells should have `%s` and `attribute` in columns" % row_id)
-        rpos = pd.Series(np.arange(len(df)), index=df[row_id].to_numpy()).reindex(error_cells[row_id].to_numpy()).to_numpy(np.float64)
-        cpos = np.array([pos.get(a, -1) for a in error_cells["attribute"]], np.int64)
-        ok = ~np.isnan(rpos) & (cpos >= 0)                      # cells of unknown rows / attributes drop out (join semantics)
-        cells = (rpos[ok].astype(np.int64), cpos[ok].astype(np.int32))
-        # The cells are known before the table exists, so they are NULLed here already and values that ONLY they held leave the
-        # dictionaries: the reference counts a target's classes over the frame with the error cells removed (model.py:1005,
-        # count(distinct y)), and num_class enters the softmax hessian factor K / (K - 1) -- a dead class would change every tree.
+
+    def null_known_cells(kr, kc):
+        """The cells (row positions kr, column indices kc) are known before the table is (re)built: NULL them in the dictionary
+        indices and drop the values that ONLY they held from the dictionaries of the target attributes -- the reference counts a
+        target's classes over the frame with the error cells removed (model.py:1005, count(distinct y)), and num_class enters the
+        softmax hessian factor K / (K - 1): a dead class would change every tree.  Returns (keys, values): what the cells held."""
         tset = {pos[t] for t in targets}
-        sel = np.isin(cells[1], list(tset))
-        gr, gc = cells[0][sel], cells[1][sel]
+        sel = np.isin(kc, list(tset))
+        gr, gc = kr[sel], kc[sel]
         gv = np.empty(len(gr), object)                          # the values the cells hold now: `current_value` of the result
         for j in np.unique(gc):
             m = gc == j
@@ -353,7 +363,6 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
             v[idx >= 0] = dicts[j][remaps[j][idx[idx >= 0]]]
             v[idx < 0] = None
             gv[m] = v
-        given_current = (gc.astype(np.int64) * len(df) + gr, gv)
         indices[gc, gr] = -1
         for j in sorted(tset):
             live = np.bincount(indices[j][indices[j] >= 0], minlength=len(remaps[j])) > 0
@@ -363,6 +372,16 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
                 new[live] = np.searchsorted(live_codes, remaps[j][live]).astype(np.int32)
                 dicts[j] = dicts[j][live_codes]
                 remaps[j] = new
+        return gc.astype(np.int64) * len(df) + gr, gv
+
+    if error_cells is not None:
+        if row_id not in error_cells.columns or "attribute" not in error_cells.columns:
+            raise ValueError("Error cells should have `%s` and `attribute` in columns" % row_id)
+        rpos = pd.Series(np.arange(len(df)), index=df[row_id].to_numpy()).reindex(error_cells[row_id].to_numpy()).to_numpy(np.float64)
+        cpos = np.array([pos.get(a, -1) for a in error_cells["attribute"]], np.int64)
+        ok = ~np.isnan(rpos) & (cpos >= 0)                      # cells of unknown rows / attributes drop out (join semantics)
+        cells = (rpos[ok].astype(np.int64), cpos[ok].astype(np.int32))
+        given_current = null_known_cells(cells[0], cells[1])
     if error_cells is not None and not detect_nulls and not constraints:
         # every error cell is known and NULLed: the class counts the models will see are final.  Say so BEFORE anything is uploaded
         # (a constraint / regex / user-given cell may hold the only occurrence of a class; an all-NULL numeric column has no value)
@@ -371,22 +390,35 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
             live = len(np.unique(indices[j][indices[j] >= 0]))
             if live < (1 if t in continuous_columns else 2):
                 raise NotResidentEligible("target `%s` is left with %d distinct value(s) once the error cells are removed" % (t, live))
-    table = engine.upload_dictionaries(indices, remaps)
-    for j, c in enumerate(cols):               # numeric columns: bin bounds at the midpoints of the values, like LightGBM on raw numbers
-        if dicts[j].dtype != object and len(dicts[j]) > 0:
-            table.set_column_values(j, dicts[j])
-        elif dicts[j].dtype == object:
-            table.set_column_kind(j, True)     # categories a model's training rows do not show are missing for that model
-    cons = [([pos[x] for x in xs], pos[y]) for xs, y in constraints]
-    cont = {}
-    for c in continuous_columns:
-        if c in pos and c in targets:
-            cont[pos[c]] = (np.asarray(dicts[pos[c]], np.float64), pd.api.types.is_integer_dtype(df[c]))
-    res = repair_table(engine, table, [pos[t] for t in targets], dict(base_params or {}), constraints=cons, detect_nulls=detect_nulls,
-                       error_cells=cells, want_pmf=want_pmf, top_k=top_k, threshold=threshold, continuous=cont, search_opts=search_opts,
-                       only_noisy_targets=only_noisy_targets,
-                       check_unseen=([pos[c] for c in cols if pd.api.types.is_numeric_dtype(df[c]) and not pd.api.types.is_bool_dtype(df[c])] or True) if check_unseen else False,
-                       train_rows=(lambda t, r: train_rows(cols[t], r)) if callable(train_rows) else train_rows)
+
+    def build_and_run(cells_, detect_nulls_, constraints_):
+        table = engine.upload_dictionaries(indices, remaps)
+        for j, c in enumerate(cols):               # numeric columns: bin bounds at the midpoints of the values, like LightGBM on raw numbers
+            if dicts[j].dtype != object and len(dicts[j]) > 0:
+                table.set_column_values(j, dicts[j])
+            elif dicts[j].dtype == object:
+                table.set_column_kind(j, True)     # categories a model's training rows do not show are missing for that model
+        cons = [([pos[x] for x in xs], pos[y]) for xs, y in constraints_]
+        cont_ = {}
+        for c in continuous_columns:
+            if c in pos and c in targets:
+                cont_[pos[c]] = (np.asarray(dicts[pos[c]], np.float64), pd.api.types.is_integer_dtype(df[c]))
+        return cont_, repair_table(engine, table, [pos[t] for t in targets], dict(base_params or {}), constraints=cons, detect_nulls=detect_nulls_,
+                                   error_cells=cells_, want_pmf=want_pmf, top_k=top_k, threshold=threshold, continuous=cont_, search_opts=search_opts,
+                                   only_noisy_targets=only_noisy_targets,
+                                   check_unseen=([pos[c] for c in cols if pd.api.types.is_numeric_dtype(df[c]) and not pd.api.types.is_bool_dtype(df[c])] or True) if check_unseen else False,
+                                   train_rows=(lambda t, r: train_rows(cols[t], r)) if callable(train_rows) else train_rows)
+
+    try:
+        cont, res = build_and_run(cells, detect_nulls, constraints)
+    except DeadClasses as e:
+        # Detection ran on the device; some values of a target were held by error cells only (a typo occurs once).  The cells are
+        # known now: NULL them on the host side of the encoding, drop the dead values, upload the (cached) encoding again and go on
+        # with the cells as GIVEN -- no second detection, no pandas detectors, no value-space fallback.
+        _logger.info("%s: re-encoding the target dictionaries without them" % e)
+        cells = (e.rows, e.cols)
+        given_current = null_known_cells(cells[0], cells[1])
+        cont, res = build_and_run(cells, False, ())
     rows, ccols = res["rows"], res["cols"]
 
     def decode(codes, col_idx):

@@ -244,7 +244,7 @@ def smoten_resample(X: pd.DataFrame, y: pd.Series, targets: Dict[Any, int], k_ne
       * every column is nominal: ordinal codes of its sorted distinct values;
       * Value Difference Metric fitted on ALL rows: p_f(c | v) = share of class c among the rows with value v in feature f;
         d(a, b) = sum over features of (sum over classes |p_f(c | a_f) - p_f(c | b_f)|) ** 2   (k = 1, r = 2);
-      * per class to grow (`targets`: class -> number of rows it should end up with), in the order given: the k nearest neighbours of
+      * per class to grow (`targets`: class -> number of rows it should end up with), in ascending class order (as imbalanced-learn sorts a dict strategy): the k nearest neighbours of
         every row of the class AMONG the rows of the class (the row itself excluded); a fresh RandomState(random_state) draws, with
         replacement, the rows to grow from; a new row takes, feature by feature, the most common value among the drawn row's
         neighbours (ties: the smallest code);
@@ -266,7 +266,7 @@ def smoten_resample(X: pd.DataFrame, y: pd.Series, targets: Dict[Any, int], k_ne
         np.add.at(cnt, (codes[:, j], y_idx), 1.0)
         proba.append(cnt / cnt.sum(axis=1, keepdims=True))
     new_X, new_y = [], []
-    for klass, n_target in targets.items():
+    for klass, n_target in sorted(targets.items(), key=lambda kv: kv[0]):     # imbalanced-learn sorts a dict strategy by class (check_sampling_strategy)
         rows = np.flatnonzero(yv == klass)
         n_new = int(n_target) - len(rows)
         if n_new <= 0 or len(rows) <= k_neighbors:
@@ -275,7 +275,10 @@ def smoten_resample(X: pd.DataFrame, y: pd.Series, targets: Dict[Any, int], k_ne
         dist = np.zeros((len(rows), len(rows)), np.float64)
         for j in range(F):
             pj = proba[j][Xc[:, j]]
-            dist += np.abs(pj[:, None, :] - pj[None, :, :]).sum(axis=2) ** 2
+            dj = np.zeros((len(rows), len(rows)), np.float64)
+            for c in range(pj.shape[1]):          # class by class: peak memory stays O(m^2), not O(m^2 x classes)
+                dj += np.abs(pj[:, c][:, None] - pj[:, c][None, :])
+            dist += dj ** 2
         np.fill_diagonal(dist, -1.0)          # the row itself comes first and is dropped
         nn = np.argsort(dist, axis=1, kind="stable")[:, 1:k_neighbors + 1]
         rs = np.random.RandomState(random_state)

@@ -313,3 +313,34 @@ def test_hospital_config1_through_the_resident_path(oracle_backend):
         RepairModel._resident_engine = prev
     assert taken and len(a) == len(b) > 150
     pd.testing.assert_frame_equal(_sorted(a), _sorted(b))
+
+
+def test_typo_values_held_by_error_cells_only_stay_on_the_resident_path(oracle_backend):
+    """denial-constraint violations usually are values that occur once (a typo).  Detection runs on the device, so
+    such a value is still in the target's dictionary when its cell is NULLed -- a class without rows.  The run used to throw the
+    device work away and start over with the pandas detectors; now the detected cells are handed back, the dead values leave the
+    dictionaries on the host side of the (cached) encoding, and the run goes on without a second detection.  Same frame as the
+    value-space path."""
+    import os
+    df, _, _, _ = _synthetic_frame(3000, 6, seed=47, null_ratio=0.0)
+    df["c5"] = ["g%02d" % (int(v[4:]) % 7) for v in df["c4"]]             # c4 -> c5 holds exactly ...
+    for i, r in enumerate([5, 77, 901, 1500, 2222]):                      # ... until five cells get values nobody else has
+        df.loc[r, "c5"] = "typo-%d" % i
+
+    def model(engine):
+        m = RepairModel().setInput(df).setRowId("tid").setErrorDetectors([ConstraintErrorDetector(constraints="c4->c5")])
+        for k, v in {"model.hp.max_evals": "1", "model.lgb.n_estimators": "8", "model.lgb.learning_rate": "0.2"}.items():
+            m = m.option(k, v)
+        m._engine_override = engine
+        return m
+    os.environ["REPAIR_RESIDENT"] = "0"
+    try:
+        slow = model(None).run()
+    finally:
+        os.environ.pop("REPAIR_RESIDENT", None)
+    fast_m = model(OracleEngine())
+    fast = fast_m.run()
+    assert fast_m._last_detection_on_device and getattr(fast_m, "_last_resident_info", None) is not None     # never left the device path
+    pd.testing.assert_frame_equal(_sorted(slow), _sorted(fast))
+    typos = fast[fast["current_value"].astype(str).str.startswith("typo-")]
+    assert len(typos) == 5 and not typos["repaired"].astype(str).str.startswith("typo-").any()
