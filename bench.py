@@ -49,7 +49,7 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(cols, seed, targets, steps_full, budget_s=25.0):
+def cpu_baseline(cols, seed, targets, steps_full, budget_s=25.0, full_rows=0, full_iters=5):
     """CPU legs on a bounded sample of the same workload, timed on this box's host cores.
 
     "port": oracle/rgbm_oracle.c, the plain-C restatement of the LightGBM 3.3.1 path (the real Spark + LightGBM stack cannot be
@@ -119,6 +119,26 @@ def cpu_baseline(cols, seed, targets, steps_full, budget_s=25.0):
                                  "scaled by iterations x%.1f and by their %.0f %% share of the class trees" % (done, t_fit, t_pred, iters, steps_full, scale, 100 * share))
     except Exception as e:  # noqa: BLE001 - the secondary leg never fails the bench
         out["hgb"] = dict(value=None, error=str(e))
+    # ---- one target at FULL size (hygiene): the binary target c0 of the whole table, a few boosting iterations, every core
+    # the feature-parallel histograms can use -- unscaled, next to the GPU's time for the same target and iteration count
+    try:
+        if full_rows and full_rows * cols <= 400_000_000:
+            fd, _, fcards = make_table(full_rows, cols, seed=seed)
+            t = targets[0]
+            r = fd[t] >= 0
+            K = int(fcards[t])
+            cw = balanced_class_weight(np.bincount(fd[t][r], minlength=K))
+            Xf = np.ascontiguousarray(fd[feats_of[t]][:, r]); yf = fd[t][r]
+            del fd
+            O.lib().orc_set_threads(min(nproc, 64))
+            t0 = time.perf_counter()
+            O.train(Xf, fcards[feats_of[t]], yf, K, class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=full_iters, **BASE_PARAMS)
+            dt = time.perf_counter() - t0
+            O.lib().orc_set_threads(1)
+            out["full_size_target"] = dict(target="c%d (K=%d)" % (t, K), rows=int(r.sum()), iterations=full_iters, train_sec=dt, threads=min(nproc, 64),
+                                           note="binning + %d boosting iterations of ONE target model on the whole table, not scaled" % full_iters)
+    except Exception as e:  # noqa: BLE001
+        out["full_size_target"] = dict(error=str(e))
     return out
 
 
@@ -336,6 +356,9 @@ def main():
     hist_ms_all, hist_bytes_all, launches_all = agg("hist_ms"), agg("hist_bytes"), agg("hist_launches")
     root_ms = sum(s["root_ms"] for s in res_roof["stats"]); root_bytes = sum(s["root_rows"] * (cols - 1 + 8) for s in res_roof["stats"])
     n_root = rdist.sum_over_ranks(roof_steps * len(res_roof["stats"]))       # one root launch per boosting iteration and trained model (nchunk = 1 workloads)
+    # level launches of a target x 9 B x (training-table rows of this rank) x class trees (an upper bound: finished class trees are skipped)
+    level_stream_bytes = rdist.sum_over_ranks(sum((s_["hist_launches"] - roof_steps) * 9.0 * float(getattr(row_tab if shard_only else train_tab, "n", 0)) *
+                                                  (1 if int(cards[s_["target"]]) <= 2 else int(cards[s_["target"]])) for s_ in res_roof["stats"]))
     train_s = rdist.max_over_ranks(res["times"]["train"]); infer_s = rdist.max_over_ranks(res["times"]["infer"])
 
     fixed_shards = 0.0
@@ -368,6 +391,8 @@ def main():
         for name, ms, nbytes, nl in (("root", root_ms, root_bytes, n_root_l), ("level", hist_ms_all - root_ms, hist_bytes_all - root_bytes, max(1, int(launches_all) - n_root_l))):
             c = {"kernel": "rg::k_level_root" if name == "root" else "rg::k_level_mt", "launches": int(nl), "avg_launch_us": ms * 1e3 / nl, "alg_bytes_per_launch": nbytes / nl,
                  "achieved": nbytes / max(ms, 1e-9) * 1e-6, "frac": nbytes / max(ms, 1e-9) * 1e-6 / HBM_PEAK_GBS}
+            if name == "level":   # what a level pass streams by construction: 1 B node id + 8 B (g, h) of every (row, class tree) of its target
+                c["stream_bytes_per_launch"] = level_stream_bytes / nl
             if traffic and name in traffic["classes"]:
                 tc = traffic["classes"][name]
                 c["traffic"] = {"fetch_bytes_per_launch": tc["fetch_bytes_per_launch"], "write_bytes_per_launch": tc["write_bytes_per_launch"],
@@ -410,7 +435,12 @@ def main():
         if row_sharding_note:
             out["config"]["row_sharding"] = row_sharding_note
         if not a.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (the other ranks would sit in the barrier below)
-            out["cpu_baseline"] = cpu_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS)
+            out["cpu_baseline"] = cpu_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS, full_rows=rows if not (0 < a.train_rows < rows) else 0)
+            fst = out["cpu_baseline"].get("full_size_target")
+            if fst and "train_sec" in fst:      # the GPU's wall time for the same target and iteration count (sequential roofline pass, setup included pro rata)
+                g = [s_ for s_ in res_roof["stats"] if s_.get("target") == targets[0]]
+                if g:
+                    fst["gpu_total_ms_same_target_%d_iterations" % roof_steps] = g[0].get("total_ms")
     # tear the communicators down first, flush whatever the C side (RCCL prints a version banner through stdio)
     # still holds, and only then print the ONE JSON line, as the last thing this process writes
     if row_tab is not None:

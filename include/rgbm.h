@@ -161,6 +161,7 @@ int rgbm_table_train(const rgbm_table* t, int32_t target_col, const int32_t* fea
  * for bit; what changes is the schedule: all fits of the batch advance through their boosting iterations TOGETHER, three kernel
  * launches per iteration for the whole batch (csrc/rgbm_small.h: one workgroup grows one class tree of one fit).  Fits the fused
  * kernels do not cover (tables above RGBM_SMALL_ROWS = 65536 rows, more than 256 leaves, row-sharded calls) run one by one inside.
+ * A fit with a valid_table always takes the batched path's scoring (its table must then be small enough for the fused kernels).
  * out_status[i] = RGBM_OK or fit i's error code (out_models[i] = NULL then): one failing fit does not fail the batch, which is the
  * reference's contract (train.py:227-229: a failing build yields PoorModel).  All tables must live on one device. */
 typedef struct {
@@ -170,6 +171,13 @@ typedef struct {
     const double* y_value;        /* regression dictionary or NULL */
     const double* class_weight;   /* [n_codes[target]] or NULL */
     const rgbm_params* params;
+    /* optional: score a validation table while the fit trains (cross_val_score, train.py:171-172, without building a predictor): the
+     * rows of valid_table get the label / value model.predict would give them -- the same bits, the trees are added to their scores
+     * in the predictor's order.  valid_label_out [rows of valid_table]: arg-max class index (-1 for regression);
+     * valid_value_out [rows]: its probability / the regression value.  NULL valid_table: nothing is scored. */
+    const rgbm_table* valid_table;
+    int32_t* valid_label_out;
+    double* valid_value_out;
 } rgbm_fit_spec;
 int rgbm_table_train_batch(const rgbm_fit_spec* fits, int32_t n_fits, rgbm_model** out_models /* [n_fits] */, int32_t* out_status /* [n_fits] */);
 /* Chained repair of rows [row_begin, row_begin+n_rows) of the resident table, in place in HBM.
@@ -241,6 +249,8 @@ int rgbm_table_shape(const rgbm_table* t, int64_t* n_out, int32_t* c_out, int32_
  * position (the shards must hold consecutive row ranges in rank order), so the model is the single-device one. */
 #define RGBM_COMM_ID_BYTES 128
 #define RGBM_FLAG_ROW_SHARDED 1 /* rgbm_params.reserved: this call is one rank of a row-sharded training */
+#define RGBM_FLAG_NO_MODEL 2    /* rgbm_params.reserved, rgbm_table_train_batch only: the fit is wanted for its validation scores (a CV fold); no model
+                                   is built, out_models[i] stays NULL with status RGBM_OK */
 int rgbm_comm_unique_id(void* id_out /* [RGBM_COMM_ID_BYTES], call on one rank, hand to all */);
 int rgbm_comm_init(const void* id, int32_t rank, int32_t nranks, int32_t device_id);
 int rgbm_comm_finalize(void);

@@ -597,12 +597,16 @@ void fit_setup(const rgbm_table& tab, const double* y_value_in, const double* cl
 
 // the trees as the trainer leaves them in its flat device arrays (TreeOut), copied to the host: -> the model's tree list
 struct HostTrees { const int32_t *L, *feat, *theta, *dleft, *left, *right, *cnt; const double *gain, *val; const int32_t* any; };
-void model_from_trees(rgbm_model* model, const HostTrees& h, int NE, int K, int NL) {
+// two steps, so that the (many) trees of a batch of fits can be filled by several host threads: size the list, then fill ranges of it
+size_t model_trees_begin(rgbm_model* model, const HostTrees& h, int NE, int K) {
     int n_iter = NE;
     for (int it = 0; it < NE; ++it) if (!h.any[it]) { n_iter = it > 0 ? it : 1; break; }   // "no more leaves that meet the split requirements"
     model->n_iter = n_iter;
     model->trees.resize((size_t)n_iter * K);
-    for (size_t t = 0; t < (size_t)n_iter * K; ++t) {
+    return model->trees.size();
+}
+void model_trees_fill(rgbm_model* model, const HostTrees& h, int NL, size_t t0, size_t t1) {
+    for (size_t t = t0; t < t1; ++t) {
         Tree& tr = model->trees[t];
         tr.L = h.L[t]; const int n = tr.L - 1;
         const size_t nb = t * (NL - 1), lb = t * NL;
@@ -611,6 +615,10 @@ void model_from_trees(rgbm_model* model, const HostTrees& h, int NE, int K, int 
         tr.right.assign(h.right + nb, h.right + nb + n); tr.gain.assign(h.gain + nb, h.gain + nb + n);
         tr.leaf_value.assign(h.val + lb, h.val + lb + tr.L); tr.leaf_count.assign(h.cnt + lb, h.cnt + lb + tr.L);
     }
+}
+void model_from_trees(rgbm_model* model, const HostTrees& h, int NE, int K, int NL) {
+    const size_t n = model_trees_begin(model, h, NE, K);
+    model_trees_fill(model, h, NL, 0, n);
 }
 
 // per-tree feature masks (ColSampler::ResetByTree), generated in LightGBM's draw order: [n_estimators * K][F]
@@ -1237,6 +1245,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
 }
 
 
+struct PredictScratch;
+void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_codes, long long Ntab, long long row0, long long n,
+                    const int32_t* d_feat_cols, double* d_proba, int32_t* d_label, double* d_top, PredictScratch* scratch);
+
 // ---------------------------------------------------------------------------------------------
 // The batched small-table trainer (rgbm_small.h): many fits, three launches per boosting iteration for all of them.
 // Replaces the loop over fits of python/repair/train.py:158-209 (cross_val_score inside the hyper-parameter search: folds x
@@ -1250,10 +1262,25 @@ struct SmallFitDev {   // device state of one fit of a batch
     DevBuf<uint4> rec; DevBuf<float2> gh; DevBuf<double> score, init, upd, cw, yv;
     DevBuf<int32_t> idx0, idx1, base, tree_L, any, sorted_rows, oob; DevBuf<rg::HistBin> pool;
     DevBuf<unsigned int> blk, rand, bagcnt;
+    DevBuf<rg::ScanLane> scan_map; std::vector<rg::ScanLane> h_scan; int scan_waves = 0;
+    DevBuf<uint4> vrec; DevBuf<double> vscore, vtop; DevBuf<int32_t> vlabel; DevBuf<uint8_t> vlut, vmiss; std::vector<uint8_t> h_vlut, h_vmiss; long long n_valid = 0;
     DevBuf<int32_t> t_L, t_feat, t_theta, t_dleft, t_left, t_right, t_cnt; DevBuf<double> t_gain, t_val;
     std::vector<int32_t> hL, hfeat, htheta, hdleft, hleft, hright, hcnt, hany; std::vector<double> hgain, hval;
     std::vector<uint8_t> h_used; std::vector<unsigned int> h_rand;      // host sources of asynchronous uploads: alive until the batch has drained
 };
+
+// validation rows of a fit that trained outside the fused kernels: the predictor on its model (same labels / values)
+void score_valid_with_model(const rgbm_fit_spec& sp, rgbm_model* m) {
+    if (!sp.valid_table || !m || sp.valid_table->n <= 0 || (!sp.valid_label_out && !sp.valid_value_out)) return;
+    const rgbm_table& vt = *sp.valid_table;
+    StreamGuard sg_; hipStream_t s = sg_.s;
+    DevBuf<int32_t> d_fc(sp.n_features), d_lab(vt.n); DevBuf<double> d_top(vt.n);
+    d_fc.upload(sp.feat_cols, sp.n_features, s);
+    predict_device(m, vt.device, s, vt.codes.p, vt.n, 0, vt.n, d_fc.p, nullptr, d_lab.p, d_top.p, nullptr);
+    if (sp.valid_label_out) d_lab.download(sp.valid_label_out, vt.n, s);
+    if (sp.valid_value_out) d_top.download(sp.valid_value_out, vt.n, s);
+    HIPCHK(hipStreamSynchronize(s));
+}
 
 bool small_fit_eligible(const rgbm_table& tab, int32_t F, const rgbm_params& p, long long small_rows) {
     if (tab.n > small_rows || tab.n >= (1ll << 31) - 4096) return false;
@@ -1273,7 +1300,10 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
     auto record_error = [&](int i, const std::exception& e, int code) { status[i] = code; rgh::last_error() = e.what(); };
     auto run_single = [&](int i) {
         const rgbm_fit_spec& sp = specs[i];
-        try { out[i] = train_core(*sp.table, sp.target_col, sp.feat_cols, sp.n_features, sp.y_value, sp.class_weight, nullptr, nullptr, *sp.params, nullptr); status[i] = RGBM_OK; }
+        try {
+            out[i] = train_core(*sp.table, sp.target_col, sp.feat_cols, sp.n_features, sp.y_value, sp.class_weight, nullptr, nullptr, *sp.params, nullptr); status[i] = RGBM_OK;
+            score_valid_with_model(sp, out[i]);
+        }
         catch (const std::invalid_argument& e) { record_error(i, e, RGBM_ERR_PARAM); }
         catch (const std::out_of_range& e) { record_error(i, e, RGBM_ERR_LABEL); }
         catch (const std::domain_error& e) { record_error(i, e, RGBM_ERR_NO_DEVICE); }
@@ -1328,15 +1358,31 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
     HIPCHK(hipStreamSynchronize(s));
     // ---- B. per fit: bins, tables, records, state
     std::vector<int> ok;
-    int NE_max = 0; size_t lds_max = 0; long long N_max = 1, ntrain_max = 1, nrb_max = 1; bool any_bag = false;
+    int NE_max = 0; size_t lds_max = 0; long long N_max = 1, ntrain_max = 1, nrb_max = 1, nvalid_max = 0; bool any_bag = false;
     for (int i : live) {
         const rgbm_fit_spec& sp = specs[i]; const rgbm_table& tab = *sp.table; const rgbm_params& p = *sp.params;
         SmallFitDev& d = *dev[i]; FitHost& h = d.h; const int F = d.F, K = d.K, NL = d.NL, NE = d.NE; const long long N = tab.n;
         try { fit_setup(tab, sp.y_value, sp.class_weight, nullptr, p, F, h); }
         catch (const std::invalid_argument& e) { record_error(i, e, RGBM_ERR_PARAM); dev[i].reset(); continue; }
         catch (const std::out_of_range& e) { record_error(i, e, RGBM_ERR_LABEL); dev[i].reset(); continue; }
-        const size_t lds = sm_lds_bytes(h.lds_hist, NL, F);
-        if (lds > 160 * 1024) { dev[i].reset(); run_single(i); continue; }          // (histogram working set of one chunk + leaves exceed the LDS)
+        // lane map of the packed threshold scan (rgbm_small.h): a lane owns 4 bins of one feature, a feature does not straddle waves;
+        // used when a child's features fit half of the workgroup's waves (both children are scanned at once) and the two compact
+        // histograms fit next to the rest in LDS -- otherwise one wave per feature (split_find_body)
+        {
+            std::vector<ScanLane> sm; int lanes_used = 0;
+            for (int f = 0; f < F; ++f) {
+                const int nl_f = std::max(1, (h.fmeta[f].V + 3) / 4);
+                if (lanes_used % 64 + nl_f > 64) while (lanes_used % 64) { sm.push_back(ScanLane{-1, 0, 1, 0}); ++lanes_used; }
+                const int first = lanes_used % 64;
+                for (int q = 0; q < nl_f; ++q) { sm.push_back(ScanLane{f, 4 * q, q == 0 ? 1 : 0, first + nl_f - 1}); ++lanes_used; }
+            }
+            while (lanes_used % 64) { sm.push_back(ScanLane{-1, 0, 1, 0}); ++lanes_used; }
+            const int Wn = lanes_used / 64;
+            const bool off_switch = getenv("RGBM_SMALL_PACKED") && atoi(getenv("RGBM_SMALL_PACKED")) == 0;
+            if (!off_switch && 2 * Wn <= SM_WAVES && h.tc.totbins <= 2048 && sm_lds_bytes(h.lds_hist, NL, F, h.tc.totbins) <= 150 * 1024) { d.scan_waves = Wn; d.h_scan = std::move(sm); }
+        }
+        const size_t lds = sm_lds_bytes(h.lds_hist, NL, F, d.scan_waves > 0 ? h.tc.totbins : 0);
+        if (lds > 160 * 1024 - 2048) { dev[i].reset(); run_single(i); continue; }          // (histogram working set of one chunk + leaves exceed the LDS)
         const int nchunk = h.nchunk; const long long n_train = h.n_train;
         d.fmeta.alloc(F); d.cmeta.alloc(nchunk); d.lut_off.alloc(F + 1); d.lut.alloc(std::max<size_t>(h.lut.size(), 1)); d.miss.alloc(F);
         d.fmeta.upload(h.fmeta.data(), F, s); d.cmeta.upload(h.cmeta.data(), nchunk, s); d.lut_off.upload(h.lut_off.data(), F + 1, s);
@@ -1359,6 +1405,25 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
         const int n_y = h.ncod[F];
         if (sp.class_weight) { d.cw.alloc(n_y); d.cw.upload(sp.class_weight, n_y, s); }
         if (p.objective == 2) { d.yv.alloc(n_y); d.yv.upload(h.yv32.data(), n_y, s); }
+        if (d.scan_waves > 0) { d.scan_map.alloc(d.h_scan.size()); d.scan_map.upload(d.h_scan.data(), d.h_scan.size(), s); }
+        if (sp.valid_table && sp.valid_table->n > 0 && (sp.valid_label_out || sp.valid_value_out)) {
+            // the validation rows' bin records, in the predictor's convention: a NULL cell, a code outside the dictionary and a category
+            // no training row held (Feat::unseen) are MISSING = bin 255 (device_model's lookup table)
+            const rgbm_table& vt = *sp.valid_table;
+            if (vt.c != tab.c) throw std::invalid_argument("rgbm_table_train_batch: valid_table must have the columns of the training table");
+            d.n_valid = vt.n;
+            d.h_vlut.assign(std::max<size_t>(h.lut.size(), 1), 0); d.h_vmiss.assign(F, 255);
+            for (int f = 0; f < F; ++f) {
+                const Feat& ft = h.model->feats[f]; int b = 0;
+                for (int cde = 0; cde < h.ncod[f]; ++cde) { while (b < ft.V - 1 && cde > ft.ub[b]) ++b; d.h_vlut[h.lut_off[f] + cde] = ft.is_unseen(cde) ? (uint8_t)255 : (uint8_t)(ft.V > 0 ? b : 0); }
+            }
+            d.vlut.alloc(d.h_vlut.size()); d.vlut.upload(d.h_vlut.data(), d.h_vlut.size(), s); d.vmiss.alloc(F); d.vmiss.upload(d.h_vmiss.data(), F, s);
+            d.vrec.alloc((size_t)nchunk * vt.n);
+            hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((vt.n + 255) / 256)), dim3(256), 0, s, vt.codes.p, (long long)vt.n, 0ll, (long long)vt.n, d.cols.p, d.ncod.p, d.lut_off.p, d.vlut.p, d.vmiss.p, F, nchunk, d.vrec.p);
+            d.vscore.alloc((size_t)K * vt.n); d.vlabel.alloc(vt.n); d.vtop.alloc(vt.n);
+            hipLaunchKernelGGL(k_init_score, dim3((unsigned)((vt.n + 255) / 256)), dim3(256), 0, s, d.vscore.p, (long long)vt.n, K, d.init.p);
+            nvalid_max = std::max<long long>(nvalid_max, vt.n);
+        }
         d.h_used = make_used_masks(p, NT, F, h.trivial);
         d.used.alloc(d.h_used.size()); d.used.upload(d.h_used.data(), d.h_used.size(), s);
         if (d.bag) {   // GBDT::Bagging state: stable training-row order, one LCG per 1024 positions
@@ -1394,8 +1459,12 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
         f.rand_state = d.rand.p; f.sorted_rows = d.sorted_rows.p; f.inbag = d.inbag.p; f.bagcnt = d.bagcnt.p; f.oob = d.oob.p;
         f.bag_fraction = p.bagging_fraction; f.bag_nrb = d.bag_nrb; f.bag_freq = d.bag ? p.bagging_freq : 0;
         f.tree0 = (int32_t)tree2fit.size(); f.n_estimators = d.NE; f.lds_hist = (unsigned long long)h.lds_hist;
+        f.scan_map = d.scan_map.p; f.scan_waves = d.scan_waves;
+        f.vrec = d.vrec.p; f.vscore = d.vscore.p; f.n_valid = d.n_valid;
         for (int k = 0; k < d.K; ++k) tree2fit.push_back((int32_t)j);
     }
+    DevBuf<unsigned long long> d_prof(8); d_prof.zero(s);
+    for (auto& f : fits) f.prof = d_prof.p;
     DevBuf<SmallFit> d_fits(fits.size()); DevBuf<int32_t> d_t2f(tree2fit.size());
     d_fits.upload(fits.data(), fits.size(), s); d_t2f.upload(tree2fit.data(), tree2fit.size(), s);
     {
@@ -1415,13 +1484,24 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
         hipLaunchKernelGGL(k_small_grad, dim3(gx_rows, nf), dim3(256), 0, s, d_fits.p, it);
         hipLaunchKernelGGL(k_small_tree, dim3(KT), dim3(SM_THREADS), lds_max, s, d_fits.p, d_t2f.p, it);
         if (any_bag) hipLaunchKernelGGL(k_small_oob, dim3(gx_train, KT), dim3(256), 0, s, d_fits.p, d_t2f.p, it);
+        if (nvalid_max > 0) hipLaunchKernelGGL(k_small_valid, dim3((unsigned)std::min<long long>((nvalid_max + 255) / 256, 64), KT), dim3(256), 0, s, d_fits.p, d_t2f.p, it);
+    }
+    for (int i : ok) {   // ConvertOutput + arg-max of the validation rows (what model.predict returns for them)
+        SmallFitDev& d = *dev[i]; const rgbm_fit_spec& sp = specs[i];
+        if (d.n_valid <= 0) continue;
+        hipLaunchKernelGGL(k_softmax_argmax, dim3((unsigned)((d.n_valid + 255) / 256)), dim3(256), 0, s, d.vscore.p, d.n_valid, sp.params->objective,
+                           d.h.model->num_class, (double*)nullptr, d.vlabel.p, d.vtop.p);
+        if (sp.valid_label_out) d.vlabel.download(sp.valid_label_out, d.n_valid, s);
+        if (sp.valid_value_out) d.vtop.download(sp.valid_value_out, d.n_valid, s);
     }
     HIPCHK(hipGetLastError());
     const double t_enq = now();
     if (timing) HIPCHK(hipStreamSynchronize(s));
     const double t_iter = now();
     // ---- E. trees back to the host, one model per fit
-    for (int i : ok) {
+    std::vector<int> want;                                            // fits whose model is wanted (a CV fold is wanted for its scores only)
+    for (int i : ok) if (!((specs[i].params->reserved & RGBM_FLAG_NO_MODEL) && dev[i]->n_valid > 0)) want.push_back(i);
+    for (int i : want) {
         SmallFitDev& d = *dev[i]; const size_t NT = d.NT; const int NL = d.NL;
         d.hL.resize(NT); d.hfeat.resize(NT * (NL - 1)); d.htheta.resize(NT * (NL - 1)); d.hdleft.resize(NT * (NL - 1)); d.hleft.resize(NT * (NL - 1)); d.hright.resize(NT * (NL - 1));
         d.hcnt.resize(NT * NL); d.hany.resize(d.NE); d.hgain.resize(NT * (NL - 1)); d.hval.resize(NT * NL);
@@ -1432,21 +1512,32 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
     }
     HIPCHK(hipStreamSynchronize(s));
     {   // the tree lists of the models: host work proportional to fits x iterations x class trees, spread over a few threads
+        struct Item { int fit; size_t t0, t1; };
+        std::vector<Item> items; std::vector<HostTrees> hts(n_fits);
+        for (int i : want) {
+            SmallFitDev& d = *dev[i];
+            hts[i] = HostTrees{d.hL.data(), d.hfeat.data(), d.htheta.data(), d.hdleft.data(), d.hleft.data(), d.hright.data(), d.hcnt.data(), d.hgain.data(), d.hval.data(), d.hany.data()};
+            const size_t n = model_trees_begin(d.h.model.get(), hts[i], d.NE, d.K);
+            for (size_t t0 = 0; t0 < n; t0 += 1024) items.push_back(Item{i, t0, std::min(n, t0 + 1024)});
+        }
         std::atomic<size_t> next{0};
         auto work = [&]() {
-            for (size_t j = next.fetch_add(1); j < ok.size(); j = next.fetch_add(1)) {
-                SmallFitDev& d = *dev[ok[j]];
-                HostTrees ht{d.hL.data(), d.hfeat.data(), d.htheta.data(), d.hdleft.data(), d.hleft.data(), d.hright.data(), d.hcnt.data(), d.hgain.data(), d.hval.data(), d.hany.data()};
-                model_from_trees(d.h.model.get(), ht, d.NE, d.K, d.NL);
-            }
+            for (size_t j = next.fetch_add(1); j < items.size(); j = next.fetch_add(1))
+                model_trees_fill(dev[items[j].fit]->h.model.get(), hts[items[j].fit], dev[items[j].fit]->NL, items[j].t0, items[j].t1);
         };
-        const size_t nth = std::min<size_t>(std::min<size_t>(ok.size(), 16), std::max(1u, std::thread::hardware_concurrency()));
+        const size_t nth = std::min<size_t>(std::min<size_t>(std::max<size_t>(items.size(), 1), 16), std::max(1u, std::thread::hardware_concurrency()));
         std::vector<std::thread> th;
         for (size_t q = 1; q < nth; ++q) th.emplace_back(work);
         work();
         for (auto& t : th) t.join();
     }
-    for (int i : ok) { out[i] = dev[i]->h.model.release(); status[i] = RGBM_OK; }
+    for (int i : ok) status[i] = RGBM_OK;
+    for (int i : want) out[i] = dev[i]->h.model.release();
+#if defined(SM_PROF)
+    { unsigned long long hp[8]; d_prof.download(hp, 8, s); HIPCHK(hipStreamSynchronize(s)); unsigned long long tot = 0; for (int q = 0; q < 8; ++q) tot += hp[q];
+      fprintf(stderr, "[rgbm] k_small_tree phases (%% of thread-0 cycles): zero %.1f | accumulate %.1f | flush %.1f | split_find %.1f | reduce+pick %.1f | partition %.1f | finish %.1f | score %.1f\n",
+              100.0 * hp[0] / tot, 100.0 * hp[1] / tot, 100.0 * hp[2] / tot, 100.0 * hp[3] / tot, 100.0 * hp[4] / tot, 100.0 * hp[5] / tot, 100.0 * hp[6] / tot, 100.0 * hp[7] / tot); }
+#endif
     if (timing) fprintf(stderr, "[rgbm] batch of %zu fits, %u class trees, %d iterations: setup %.1f ms, enqueue %.1f ms, iterations drained after %.1f ms, download + models %.1f ms\n",
                         ok.size(), KT, NE_max, t_setup - t_start, t_enq - t_setup, t_iter - t_setup, now() - t_iter);
 }

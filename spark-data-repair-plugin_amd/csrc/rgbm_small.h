@@ -36,6 +36,134 @@ constexpr int SM_WAVES = SM_THREADS / 64;
 constexpr int SM_MAX_LEAVES = 256;
 constexpr int SM_MAX_FEATS = 255;
 
+// Packed threshold scan: on a small table one split is a chain of latencies, and the two longest links were (measured, -DSM_PROF:
+// profiles/r04m_*) the flush of the LDS histogram feature by feature (33-38 % of the kernel) and FindBestThreshold with one wave per
+// feature, two children one after the other (35-43 %).  A feature of the synthetic tables has 3-65 bins, so most of a wave's 256 bin
+// slots sat idle.  Here the features of a child share waves: a lane owns 4 consecutive bins of ONE feature (ScanLane), the prefix
+// sums and the arg-max become SEGMENTED wave scans, and both children are scanned at once by different waves.  Every candidate is
+// evaluated by the same expressions, in the same order, as scan_child; a feature's winner is picked by the same total order
+// (scan_better), so the Cand of every (child, feature) is the one scan_child writes -- bit for bit.
+struct ScanLane { int32_t feat /* -1: idle lane */, bin0 /* first of the lane's 4 bins inside the feature */, seg_first /* 1: first lane of its feature */, seg_last /* last lane of its feature */; };
+
+__device__ __forceinline__ long long seg_incl_scan(long long v, bool first) {
+    const int lane = lane_id();
+    int f = first ? 1 : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long o = __shfl_up(v, off); const int fo = __shfl_up(f, off);
+        if (lane >= off && !f) { v += o; f = fo; }
+    }
+    return v;
+}
+
+template <bool REVERSE>
+__device__ __forceinline__ ScanBest seg_best_scan(ScanBest v, bool first) {
+    const int lane = lane_id();
+    int f = first ? 1 : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double g2 = __shfl_up(v.gain, off); const int t2 = __shfl_up(v.theta, off);
+        const long long a2 = __shfl_up(v.lg, off), b2 = __shfl_up(v.lh, off); const int fo = __shfl_up(f, off);
+        if (lane >= off && !f) {
+            if (scan_better<REVERSE>(g2, t2, v.gain, v.theta)) { v.gain = g2; v.theta = t2; v.lg = a2; v.lh = b2; }
+            f = fo;
+        }
+    }
+    return v;   // the LAST lane of a segment holds the segment's best
+}
+
+// one wave: the features of its lane map, for the child whose compact histogram is `hist` (indexed by FeatMeta::hoff + bin; LDS)
+__device__ void scan_child_packed(const HistBin* hist, const FeatMeta* __restrict__ fmeta, const ScanLane sl, long long Gq, long long Hq, long long num_data,
+                                  const TrainConst& c, const uint8_t* __restrict__ used_k, Cand* ck /* [F] of this child */) {
+    const int lane = lane_id();
+    const bool on = sl.feat >= 0;
+    FeatMeta fm; fm.V = 0; fm.has_nan = 0; fm.nbins = 0; fm.hoff = 0; fm.fast_base = 0; fm.rep_shift = 0; fm.wide_off = 0; fm.pad = 0;
+    if (on) fm = fmeta[sl.feat];
+    const int V = fm.V;
+    const double keps = k_eps();
+    const double sum_gradient = (double)Gq * c.inv_sg;
+    const double sum_hessian = (double)Hq * c.inv_sh + 2 * keps;
+    const double gain_shift = leaf_gain(sum_gradient, sum_hessian, c.l1, c.l2);
+    const double min_gain_shift = gain_shift + c.min_gain_to_split;
+    const double cnt_factor = (double)num_data / sum_hessian;
+    const bool two_way = fm.has_nan && V >= 1;
+    long long lg[4], lh[4], lc[4];
+    long long tg = 0, th = 0, tc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = sl.bin0 + j;
+        const bool val = on && b < V;
+        HistBin hb; hb.g = 0; hb.h = 0;
+        if (val) hb = hist[fm.hoff + b];
+        lg[j] = hb.g; lh[j] = hb.h;
+        lc[j] = val ? round_int((double)hb.h * c.inv_sh * cnt_factor) : 0;
+        tg += lg[j]; th += lh[j]; tc += lc[j];
+    }
+    const bool first = !on || sl.seg_first != 0;
+    const long long ig = seg_incl_scan(tg, first), ih = seg_incl_scan(th, first), ic = seg_incl_scan(tc, first);
+    const int last = on ? sl.seg_last : lane;
+    const long long TG = __shfl(ig, last), TH = __shfl(ih, last), TC = __shfl(ic, last);     // totals over the VALUE bins of the lane's feature
+    long long pg = ig - tg, ph = ih - th, pc = ic - tc;   // exclusive prefix at the lane's first bin
+    ScanBest rv = {-INFINITY, 0, 0, 0}, fw = {-INFINITY, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = sl.bin0 + j;
+        if (on && b < V) {
+            {   // REVERSE candidate theta = b-1: right = value bins >= b (NaN rows stay left)
+                const long long rg = TG - pg, rh = TH - ph, right_count = TC - pc;
+                const double sum_right_hessian = (double)rh * c.inv_sh + keps;
+                const long long left_count = num_data - right_count;
+                const long long lhq = Hq - rh, lgq = Gq - rg;
+                const double sum_left_hessian = (double)lhq * c.inv_sh + keps;
+                const bool ok = !(right_count < c.min_data_in_leaf || sum_right_hessian < c.min_sum_hessian) &&
+                                !(left_count < c.min_data_in_leaf) && !(sum_left_hessian < c.min_sum_hessian);
+                if (ok) {
+                    const double cur = leaf_gain((double)lgq * c.inv_sg, sum_left_hessian, c.l1, c.l2) +
+                                       leaf_gain((double)rg * c.inv_sg, sum_right_hessian, c.l1, c.l2);
+                    if (cur > min_gain_shift && scan_better<true>(cur, b - 1, rv.gain, rv.theta)) { rv.gain = cur; rv.theta = b - 1; rv.lg = lgq; rv.lh = lhq; }
+                }
+            }
+            pg += lg[j]; ph += lh[j]; pc += lc[j];   // now inclusive through b
+            if (two_way) {   // FORWARD candidate theta = b: left = value bins <= b (NaN rows go right)
+                const long long lgq = pg, lhq = ph, left_count = pc;
+                const double sum_left_hessian = (double)lhq * c.inv_sh + keps;
+                const long long right_count = num_data - left_count;
+                const long long rh = Hq - lhq, rg = Gq - lgq;
+                const double sum_right_hessian = (double)rh * c.inv_sh + keps;
+                const bool ok = !(left_count < c.min_data_in_leaf || sum_left_hessian < c.min_sum_hessian) &&
+                                !(right_count < c.min_data_in_leaf) && !(sum_right_hessian < c.min_sum_hessian);
+                if (ok) {
+                    const double cur = leaf_gain((double)lgq * c.inv_sg, sum_left_hessian, c.l1, c.l2) +
+                                       leaf_gain((double)rg * c.inv_sg, sum_right_hessian, c.l1, c.l2);
+                    if (cur > min_gain_shift && scan_better<false>(cur, b, fw.gain, fw.theta)) { fw.gain = cur; fw.theta = b; fw.lg = lgq; fw.lh = lhq; }
+                }
+            }
+        }
+    }
+    rv = seg_best_scan<true>(rv, first);
+    fw = seg_best_scan<false>(fw, first);
+    if (on && lane == sl.seg_last) {     // the same finish as scan_child's lane 0
+        Cand o; o.gain = -INFINITY; o.theta = 0; o.dleft = 1; o.left_gq = 0; o.left_hq = 0; o.left_out = 0.0; o.right_out = 0.0;
+        if (used_k[sl.feat]) {
+            if (rv.gain > -INFINITY && rv.gain > o.gain + min_gain_shift) {
+                o.theta = rv.theta; o.dleft = 1; o.left_gq = rv.lg; o.left_hq = rv.lh;
+                const double lH = (double)rv.lh * c.inv_sh + keps, rH = (double)(Hq - rv.lh) * c.inv_sh + keps;
+                o.left_out = leaf_output((double)rv.lg * c.inv_sg, lH, c.l1, c.l2);
+                o.right_out = leaf_output((double)(Gq - rv.lg) * c.inv_sg, rH, c.l1, c.l2);
+                o.gain = rv.gain - min_gain_shift;
+            }
+            if (fw.gain > -INFINITY && fw.gain > o.gain + min_gain_shift) {
+                o.theta = fw.theta; o.dleft = 0; o.left_gq = fw.lg; o.left_hq = fw.lh;
+                const double lH = (double)fw.lh * c.inv_sh + keps, rH = (double)(Hq - fw.lh) * c.inv_sh + keps;
+                o.left_out = leaf_output((double)fw.lg * c.inv_sg, lH, c.l1, c.l2);
+                o.right_out = leaf_output((double)(Gq - fw.lg) * c.inv_sg, rH, c.l1, c.l2);
+                o.gain = fw.gain - min_gain_shift;
+            }
+        }
+        ck[sl.feat] = o;
+    }
+}
+
 struct SmallFit {   // one fit of a batch; lives in device memory, indexed by fit id
     TrainConst c;
     const uint4* rec;            // [nchunk][N] bin records of THIS fit
@@ -55,6 +183,13 @@ struct SmallFit {   // one fit of a batch; lives in device memory, indexed by fi
     double bag_fraction; long long bag_nrb;
     int32_t bag_freq, tree0 /* first class tree of this fit in the batch's tree numbering */, n_estimators, pad;
     unsigned long long lds_hist;
+    // validation rows scored while the fit trains (cross_val_score without a predictor: every new tree is added to their scores)
+    const uint4* vrec;           // [nchunk][n_valid] bin records in the PREDICTOR's convention (NULL / unseen category = 255)
+    double* vscore;              // [K][n_valid] raw scores, start at the initial scores
+    long long n_valid;
+    const ScanLane* scan_map;    // [scan_waves][64] lane -> (feature, first bin) of the packed threshold scan; scan_waves = 0: one wave per feature
+    int32_t scan_waves, pad2;
+    unsigned long long* prof;    // -DSM_PROF builds: [8] cycles per phase of k_small_tree, summed over this fit's class trees (else unused)
 };
 
 // the histogram area doubles as the leaf-delta table of the final score update: at least num_leaves doubles
@@ -62,11 +197,13 @@ __host__ __device__ inline size_t sm_hist_area(size_t lds_hist, int num_leaves) 
     const size_t a = lds_hist > (size_t)num_leaves * 8 ? lds_hist : (size_t)num_leaves * 8;
     return (a + 15) & ~(size_t)15;
 }
-__host__ __device__ inline size_t sm_lds_bytes(size_t lds_hist, int num_leaves, int F) {
+__host__ __device__ inline size_t sm_lds_bytes(size_t lds_hist, int num_leaves, int F, int packed_totbins = 0) {
     size_t b = sm_hist_area(lds_hist, num_leaves);
     b += (size_t)num_leaves * sizeof(Leaf);
     b = (b + 15) & ~(size_t)15;
     b += (size_t)2 * F * sizeof(Cand);
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)2 * packed_totbins * sizeof(HistBin);     // packed scan: compact histograms of the two children just built / derived
     return b + 64;
 }
 
@@ -148,6 +285,32 @@ __global__ __launch_bounds__(256) void k_small_oob(const SmallFit* __restrict__ 
     }
 }
 
+// The tree of class k just grown by fit f is added to the scores of the fit's VALIDATION rows (LightGBM's valid ScoreUpdater; the
+// reference scores a CV fold with model.predict after the fit, python/repair/train.py:171-172): the same leaf values in the same order
+// as the predictor adds them, so the final scores are the predictor's bits.  grid (row tiles, class trees of the batch), block 256.
+__global__ __launch_bounds__(256) void k_small_valid(const SmallFit* __restrict__ fits, const int32_t* __restrict__ tree2fit, int it) {
+    const SmallFit& sf = fits[tree2fit[blockIdx.y]];
+    if (sf.n_valid <= 0 || it >= sf.n_estimators) return;
+    const int k = (int)blockIdx.y - sf.tree0;
+    if (sf.tree_L[k] <= 1) return;                         // no split: the tree adds nothing (its constant is the initial score)
+    const TrainConst& c = sf.c;
+    const long long nv = sf.n_valid;
+    const long long tbase = (long long)it * c.K + k;
+    const long long nb = tbase * (c.num_leaves - 1);
+    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(sf.vrec);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        int node = 0;
+        for (;;) {
+            const int f = sf.out.feat[nb + node];
+            const int bin = rec8[((long long)(f >> 4) * nv + i) * 16 + (f & 15)];
+            const bool go_left = (bin == 255) ? (sf.out.dleft[nb + node] != 0) : (bin <= sf.out.theta[nb + node]);     // k_predict_raw's rule
+            const int nx = go_left ? sf.out.left[nb + node] : sf.out.right[nb + node];
+            if (nx < 0) { sf.vscore[(long long)k * nv + i] += sf.upd[(long long)k * c.num_leaves + (~nx)]; break; }
+            node = nx;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_small_tree: grid (class trees of the batch), block SM_THREADS; dynamic LDS = the largest sm_lds_bytes() of the batch
 // ------------------------------------------------------------------------------------------------
@@ -164,6 +327,10 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
     Leaf* lk = reinterpret_cast<Leaf*>(smem + off);
     off = (off + (size_t)NL * sizeof(Leaf) + 15) & ~(size_t)15;
     Cand* ck = reinterpret_cast<Cand*>(smem + off);
+    off = (off + (size_t)2 * F * sizeof(Cand) + 15) & ~(size_t)15;
+    const int W = sf.scan_waves;                                    // packed threshold scan: waves per child (0: one wave per feature)
+    HistBin* histL = reinterpret_cast<HistBin*>(smem + off);        // [totbins] compact histogram of the left child / the root (packed scan only)
+    HistBin* histR = histL + c.totbins;                             // [totbins] ... of the right child
     const long long N = c.N;
     const long long n_in = sf.bag_freq > 0 ? (long long)sf.bagcnt[0] : c.n_train;
     const long long tbase = (long long)it * c.K + k;
@@ -176,6 +343,12 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
     const FeatMeta* fmeta = sf.fmeta; const ChunkMeta* cmeta = sf.cmeta;
     const uint8_t* used_k = sf.used + ((long long)it * c.K + k) * F;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(sf.rec);
+#if defined(SM_PROF)
+    unsigned long long pt_ = __builtin_readcyclecounter();
+#define SM_T(i) { if (tid == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(sf.prof + (i), n_ - pt_); pt_ = n_; } }
+#else
+#define SM_T(i)
+#endif
 
     // ---- k_init_iter
     if (tid == 0) {
@@ -212,6 +385,7 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
                     if (j < cm.nfeat) { fbase[j] = fm[j].fast_base; fshift[j] = fm[j].rep_shift; } else { fbase[j] = 0; fshift[j] = 0; }
                 }
                 __syncthreads();
+                SM_T(0)
                 const uint4* recc = sf.rec + (long long)ch * N;
                 for (long long p = tid; p < cnt; p += SM_THREADS) {
                     const long long row = is_root ? p : (long long)idx[hbeg + p];
@@ -232,7 +406,30 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
                     }
                 }
                 __syncthreads();
+                SM_T(1)
                 // this workgroup owns the whole histogram: plain stores of every bin (no zeroing, no global atomics)
+                if (W > 0) {
+                    // ONE pass, a thread per bin of the chunk: replicas -> the built child's bin; the sibling = parent - built (exact
+                    // integers); both children go to their pool slots (the parents of later splits) and, compact, into LDS for the scan
+                    const bool sm_left = st.smaller_is_left != 0;
+                    HistBin* pl = pk + (long long)st.split_leaf * c.totbins; HistBin* pr = pk + (long long)st.right_leaf * c.totbins;
+                    for (int wbin = tid; wbin < cm.wide_bins; wbin += SM_THREADS) {
+                        int j = 0;
+                        for (int q = 1; q < cm.nfeat; ++q) j += (wbin >= fm[q].wide_off) ? 1 : 0;
+                        const int b = wbin - fm[j].wide_off, sh = fm[j].rep_shift, s0 = fm[j].fast_base + (b << sh), gb = fm[j].hoff + b;
+                        HistBin par; par.g = 0; par.h = 0;
+                        if (!is_root) par = pl[gb];
+                        long long tg = 0, th = 0;
+                        for (int r2 = 0; r2 < (1 << sh); ++r2) { tg += (long long)fast_g[s0 + r2]; th += (long long)fast_h[s0 + r2]; }
+                        HistBin built; built.g = tg; built.h = th;
+                        if (is_root) { pk[gb] = built; histL[gb] = built; }
+                        else {
+                            HistBin sib; sib.g = par.g - built.g; sib.h = par.h - built.h;
+                            const HistBin l = sm_left ? built : sib, r = sm_left ? sib : built;
+                            pl[gb] = l; pr[gb] = r; histL[gb] = l; histR[gb] = r;
+                        }
+                    }
+                } else
                 for (int j = 0; j < cm.nfeat; ++j) {
                     const int sh = fm[j].rep_shift;
                     for (int b = tid; b < fm[j].nbins; b += SM_THREADS) {
@@ -245,10 +442,33 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
                 }
                 __syncthreads();
             }
+            SM_T(2)
+            if (W > 0) {
+                // ---- FindBestThreshold, packed: the features of a child share waves; both children at once
+                const int child = wv / W, slot = wv - child * W;
+                if (wv < (is_root ? W : 2 * W)) {
+                    const ScanLane sl = sf.scan_map[slot * 64 + lane];
+                    if (is_root) {
+                        // leaf totals = sum over all bins of any one feature (every row sits in exactly one bin)
+                        const FeatMeta f0 = fmeta[0];
+                        long long sg_ = 0, sh_ = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int b = lane * 4 + j; if (b < f0.nbins) { const HistBin v = histL[f0.hoff + b]; sg_ += v.g; sh_ += v.h; } }
+#pragma unroll
+                        for (int o2 = 32; o2 >= 1; o2 >>= 1) { sg_ += __shfl_xor(sg_, o2); sh_ += __shfl_xor(sh_, o2); }
+                        if (wv == 0 && lane == 0) { lk[0].Gq = sg_; lk[0].Hq = sh_; }
+                        scan_child_packed(histL, fmeta, sl, sg_, sh_, (long long)lk[0].count, c, used_k, ck);
+                    } else {
+                        const Leaf lf = lk[child == 0 ? st.split_leaf : st.right_leaf];
+                        scan_child_packed(child == 0 ? histL : histR, fmeta, sl, lf.Gq, lf.Hq, (long long)lf.count, c, used_k, ck + child * F);
+                    }
+                }
+            } else
             // ---- k_split_find: one wave per feature
             for (int f = wv; f < F; f += SM_WAVES) split_find_body(pk, st, lk, fmeta, used_k, ck, f, c);
         }
         __syncthreads();
+        SM_T(3)
         // ---- k_tree_step
         if (st.do_hist) {
             if (st.hist_is_root) { if (wv == 0) reduce_leaf_best(ck, F, &lk[0]); }
@@ -260,6 +480,7 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
         __syncthreads();
         if (wv == 0) tree_step_pick<false>(&st, lk, pk, fmeta, out, tbase, c);
         __syncthreads();
+        SM_T(4)
         if (st.done) break;
         // ---- k_partition: lefts fill the parent's range from the front, rights from the back, in the other buffer
         int nl_total = 0;
@@ -306,9 +527,11 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
             nl_total = curl;
         }
         __syncthreads();
+        SM_T(5)
         // ---- k_finish_split
         if (tid == 0) finish_split_body(&st, lk, out, tbase, nl_total, c);
         __syncthreads();
+        SM_T(6)
     }
 
     // ---- k_finalize_tree + k_score_update
@@ -336,6 +559,8 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
         const double d = suv[l];
         for (int p = tid; p < lf.count; p += SM_THREADS) { const int row = src[lf.begin + p]; sk[row] += d; }
     }
+    SM_T(7)
+#undef SM_T
 }
 
 }  // namespace rg

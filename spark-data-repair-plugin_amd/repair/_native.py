@@ -46,6 +46,7 @@ PARAM_DEFAULTS = dict(objective=1, num_class=2, n_estimators=300, num_leaves=31,
 
 
 FLAG_ROW_SHARDED = 1
+FLAG_NO_MODEL = 2
 
 
 def make_params(**kw):
@@ -53,6 +54,8 @@ def make_params(**kw):
     kw = dict(kw)
     if kw.pop("row_sharded", False):
         d["reserved"] = d.get("reserved", 0) | FLAG_ROW_SHARDED
+    if not kw.pop("want_model", True):
+        d["reserved"] = d.get("reserved", 0) | FLAG_NO_MODEL
     for k, v in kw.items():
         if k not in d:
             raise TypeError("unknown parameter %r" % k)
@@ -236,7 +239,8 @@ def train(X, n_codes, y_code, n_y_codes, y_value=None, class_weight=None, sample
 
 class RgbmFitSpec(C.Structure):
     _fields_ = [("table", C.c_void_p), ("target_col", C.c_int32), ("n_features", C.c_int32), ("feat_cols", C.POINTER(C.c_int32)),
-                ("y_value", C.POINTER(C.c_double)), ("class_weight", C.POINTER(C.c_double)), ("params", C.POINTER(RgbmParams))]
+                ("y_value", C.POINTER(C.c_double)), ("class_weight", C.POINTER(C.c_double)), ("params", C.POINTER(RgbmParams)),
+                ("valid_table", C.c_void_p), ("valid_label_out", C.POINTER(C.c_int32)), ("valid_value_out", C.POINTER(C.c_double))]
 
 
 def train_batch(fits):
@@ -244,7 +248,10 @@ def train_batch(fits):
     ``Table.train`` plus ``table`` -- dict(table=Table, target_col=int, feat_cols=[...], y_value=None, class_weight=None, **params).
     Returns one entry per fit: the ``Model``, or the ``RepairGbmError`` of a fit that failed (a failing fit does not fail the
     batch: the reference turns a failing build into PoorModel, python/repair/train.py:227-229).  Every model is the one
-    ``Table.train`` returns for the same arguments, bit for bit."""
+    ``Table.train`` returns for the same arguments, bit for bit.
+    A fit with ``valid_table=Table`` is scored on that table WHILE it trains (cross_val_score, train.py:171-172, without a predictor):
+    its entry is ``(Model, labels [rows] int32, values [rows] float64)`` -- what ``repair_chain`` of the model gives for those rows;
+    with ``want_model=False`` no model is built for such a fit (``None`` in its place)."""
     n = len(fits)
     if n == 0:
         return []
@@ -256,9 +263,15 @@ def train_batch(fits):
         fc = _i32(f.pop("feat_cols"))
         yv, cw = _f64(f.pop("y_value", None)), _f64(f.pop("class_weight", None))
         target = int(f.pop("target_col"))
+        vtab = f.pop("valid_table", None)
+        vlab = np.zeros(vtab.n, np.int32) if vtab is not None else None
+        vval = np.zeros(vtab.n, np.float64) if vtab is not None else None
         f.setdefault("device_id", tab.device_id)
         p = make_params(**f)
-        keep.append((tab, fc, yv, cw, p))
+        keep.append((tab, fc, yv, cw, p, vtab, vlab, vval))
+        specs[i].valid_table = vtab.h if vtab is not None else None
+        specs[i].valid_label_out = _p(vlab, C.c_int32)
+        specs[i].valid_value_out = _p(vval, C.c_double)
         specs[i].table = tab.h
         specs[i].target_col = target
         specs[i].n_features = len(fc)
@@ -271,8 +284,9 @@ def train_batch(fits):
     _check(lib().rgbm_table_train_batch(specs, C.c_int32(n), handles, _p(status, C.c_int32)), "rgbm_table_train_batch")
     out = []
     for i in range(n):
-        if status[i] == 0 and handles[i]:
-            out.append(Model(C.c_void_p(handles[i])))
+        if status[i] == 0 and (handles[i] or (keep[i][5] is not None and keep[i][4].reserved & FLAG_NO_MODEL)):
+            m = Model(C.c_void_p(handles[i])) if handles[i] else None          # want_model=False: a CV fold, wanted for its scores only
+            out.append(m if keep[i][5] is None else (m, keep[i][6], keep[i][7]))
         else:
             out.append(RepairGbmError("fit %d of the batch failed (%d): %s" % (i, int(status[i]), lib().rgbm_last_error().decode("utf-8", "replace"))))
     return out

@@ -50,9 +50,10 @@ class HipEngine:
 
     def train_many(self, fits):
         """Many fits in one batched call (rgbm_table_train_batch; include/rgbm.h): fits = [(table, target, feats, class_weight,
-        params, y_value), ...] -> [model or the exception of that fit].  Every model equals `train` on the same arguments."""
-        return _native.train_batch([dict(table=tab, target_col=t, feat_cols=feats, y_value=yv, class_weight=cw, **params)
-                                    for tab, t, feats, cw, params, yv in fits])
+        params, y_value[, valid_table]), ...] -> [model or the exception of that fit].  Every model equals `train` on the same
+        arguments; a fit with a valid_table comes back as (model, labels, values) of that table's rows, scored while it trained."""
+        return _native.train_batch([dict(table=f[0], target_col=f[1], feat_cols=f[2], y_value=f[5], class_weight=f[3],
+                                         **(dict(valid_table=f[6]) if len(f) > 6 and f[6] is not None else {}), **f[4]) for f in fits])
 
     def train_row_sharded(self, shard_table, target, feats, class_weight, params, y_value=None, want_stats=False):
         """Collective: every rank calls this for the same target with its own row shard (needs dist.init_row_comm)."""

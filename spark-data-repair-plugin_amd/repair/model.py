@@ -649,7 +649,7 @@ class RepairModel():
         # Error cells OUTSIDE the discretizable candidates must be seen by the pandas detectors: with noisy cells there and none in a
         # candidate the reference raises "At least one valid discretizable feature ..." (model.py `_run`), which the device path --
         # detecting in the candidates only -- would report as "already clean" (ADVICE r3).  Cheap host checks, before anything is uploaded.
-        others = [c for c in (self.targets if self.targets else cols) if c not in cands]
+        others = [c for c in (self.targets if self.targets else cols) if c in cols and c not in cands]
         if others and has_null and bool(input_df[others].isna().to_numpy().any()):
             return None
         if others and any(a in others for xs, y in cons for a in list(xs) + [y]):

@@ -108,16 +108,22 @@ def search_on_table(engine, table, t, n_codes, base_params, opts, y_value=None, 
     def batch_scores(jobs):
         """All fold fits of a batch of evaluations through ONE batched training call (engine.train_many ->
         rgbm_table_train_batch); a fit that fails yields its exception, like the fold_score future would."""
-        fits, vtabs = [], []
+        fits, truths = [], []
         for point, (tr, va) in jobs:
-            ttab, vtab = table.gather_rows(np.sort(rows[tr])), table.gather_rows(np.sort(rows[va]))
-            cnt = ttab.count_codes(t)[0]
-            fits.append((ttab, t, feats, balanced_class_weight(cnt), model_params(int(n_codes[t]), core(point), continuous=not discrete), y_value))
-            vtabs.append(vtab)
+            rtr, rva = np.sort(rows[tr]), np.sort(rows[va])
+            ttab, vtab = table.gather_rows(rtr), table.gather_rows(rva)
+            cnt = np.bincount(col[rtr], minlength=int(n_codes[t]))        # the fold's label counts (the host holds the column already)
+            fits.append((ttab, t, feats, balanced_class_weight(cnt), dict(model_params(int(n_codes[t]), core(point), continuous=not discrete), want_model=False), y_value, vtab))
+            truths.append(col[rva])
         out = []
-        for m, vtab in zip(engine.train_many(fits), vtabs):
+        for res, truth in zip(engine.train_many(fits), truths):     # the validation rows were scored while the fits trained
             try:
-                out.append(m if isinstance(m, Exception) else score(m, vtab))
+                if isinstance(res, Exception):
+                    out.append(res)
+                elif discrete:
+                    out.append(float(f1_score(truth, res[1], average="macro")))
+                else:
+                    out.append(-float(mean_squared_error(np.asarray(y_value, np.float64)[truth], res[2])))
             except Exception as e:   # noqa: BLE001
                 out.append(e)
         return out

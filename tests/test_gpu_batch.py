@@ -129,3 +129,40 @@ def test_search_on_table_hip_engine_equals_the_oracle_engine():
         cw = balanced_class_weight(np.bincount(dirty[t][dirty[t] >= 0], minlength=int(cards[t])))
         p = model_params(int(cards[t]), dict(base, **ph))
         assert hip.train(th, t, feats, cw, p).save() == orc.train(to, t, feats, cw, p).save()
+
+
+def test_validation_rows_scored_while_training_equal_the_predictor():
+    """cross_val_score (train.py:171-172) without a predictor: a fit with a valid_table returns, for that table's rows, the labels and
+    values `repair_chain` of its finished model gives -- bit for bit (the trees are added to the validation scores in the predictor's
+    order).  Multiclass with bagging, binary, regression; the validation fold holds NULL feature cells and a category no training row
+    of the fold has (missing for the model)."""
+    from repair import _native as N
+    dirty, _, cards = make_table(7000, 9, seed=31, null_ratio=0.03)
+    dirty[3, :40] = int(cards[3]) - 1
+    dirty[3, 40:][dirty[3, 40:] == int(cards[3]) - 1] = 0            # the last category of c3 only occurs in rows 0..39
+    tab = N.Table(dirty, cards)
+    tab.set_column_kind(3, True)
+    n = dirty.shape[1]
+    va = np.arange(0, n, 3).astype(np.int64)                          # holds rows 0, 3, ..., 39: the unseen category
+    tr = np.setdiff1d(np.arange(n), va).astype(np.int64)
+    ttab, vtab = tab.gather_rows(tr), tab.gather_rows(va)
+    yv = np.arange(int(cards[7]), dtype=np.float64) * 1.5 - 3.0
+    specs = [dict(target_col=5, objective=1, num_class=int(cards[5]), bagging_fraction=0.7, bagging_freq=2, num_leaves=20),
+             dict(target_col=0, objective=0, num_class=2, feature_fraction=0.7),
+             dict(target_col=7, objective=2, y_value=yv, num_leaves=12)]
+    fits = []
+    for sp in specs:
+        t = sp["target_col"]
+        feats = [c for c in range(9) if c != t]
+        cw = None if sp["objective"] == 2 else balanced_weights(dirty[t][tr], int(cards[t]))
+        fits.append(dict(table=ttab, feat_cols=feats, class_weight=cw, valid_table=vtab, n_estimators=10, learning_rate=0.2, **sp))
+    out = N.train_batch(fits)
+    for sp, f, res in zip(specs, fits, out):
+        assert isinstance(res, tuple), "fit failed: %r" % (res,)
+        m, lab, val = res
+        check = tab.gather_rows(va)                                   # repair_chain fills NULL target cells in place: a fresh copy
+        ref_lab, ref_val = check.repair_chain([m], [sp["target_col"]], [f["feat_cols"]])
+        assert np.array_equal(lab, ref_lab[0]) and np.array_equal(val, ref_val[0]), "objective %d: validation scores differ from the predictor" % sp["objective"]
+        single = ttab.train(sp["target_col"], f["feat_cols"], class_weight=f["class_weight"], y_value=sp.get("y_value"),
+                            **{k: v for k, v in sp.items() if k not in ("target_col", "y_value")}, n_estimators=10, learning_rate=0.2)
+        assert m.save() == single.save()

@@ -44,21 +44,25 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000); ap.add_argument("--cols", type=int, default=16)
     ap.add_argument("--reps", type=int, default=2, help="training calls per target in the profiled command (tools/probe.py runs every target twice)")
     ap.add_argument("--iters", type=int, default=1)
+    ap.add_argument("--targets", default="", help="comma-separated target columns of the profiled command (default: every column)")
     a = ap.parse_args()
     from repair.synth import CARDS
     cards = [CARDS[c % len(CARDS)] for c in range(a.cols)]
     fetch, write = load(a.fetch_dir, "FETCH_SIZE"), load(a.write_dir, "WRITE_SIZE")
     # calibration on k_grad_mc: the multiclass targets with 16 <= K <= 112 use it, one launch per boosting iteration
-    ks = [k for k in cards if 16 <= k <= 112]
+    tcols = [int(x) for x in a.targets.split(",")] if a.targets else list(range(a.cols))
+    ks = [cards[c] for c in tcols if 16 <= cards[c] <= 112]
     n_launch = len(ks) * a.reps * a.iters
     exp_read = sum(8.0 * k * a.rows + 4.0 * a.rows for k in ks) * a.reps * a.iters
+    ns = (a.rows + 255) // 256 * 256          # node-id / (g, h) rows are padded to whole wave tiles (numerics v2.1 build); the padding is never written
     exp_write = sum(8.0 * k * a.rows * 0.99 + 1.0 * k * a.rows for k in ks) * a.reps * a.iters
+    del ns
     assert fetch["grad_mc"][1] == n_launch == write["grad_mc"][1], ("k_grad_mc launches", fetch.get("grad_mc"), n_launch)
     f_cal = exp_read / (fetch["grad_mc"][0] * 1024.0)
     w_cal = exp_write / (write["grad_mc"][0] * 1024.0)
     out = {"source": "profiles/%s_hbm_traffic_pmc.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over python tools/probe.py --iters %d "
-                     "--targets 0..%d --stats 0 (every target model of the %dM x %d workload, one after another); counters x calibration factor (FETCH %.3f, WRITE %.3f: known "
-                     "reads / writes of rg::k_grad_mc in the same run)" % (a.tag, a.iters, a.cols - 1, a.rows // 1_000_000, a.cols, f_cal, w_cal),
+                     "--targets %s --stats 0 (every target model of the %dM x %d workload, one after another); counters x calibration factor (FETCH %.3f, WRITE %.3f: known "
+                     "reads / writes of rg::k_grad_mc in the same run)" % (a.tag, a.iters, a.targets or "0..%d" % (a.cols - 1), a.rows // 1_000_000, a.cols, f_cal, w_cal),
            "calibration": {"fetch_factor": f_cal, "write_factor": w_cal, "kernel": "rg::k_grad_mc", "launches": n_launch}, "classes": {}}
     for cls in ("root", "level"):
         fb, fl = fetch[cls][0] * 1024.0 * f_cal, fetch[cls][1]

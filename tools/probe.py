@@ -12,10 +12,16 @@ ap.add_argument("--cols", type=int, default=16)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--targets", type=str, default="0,4,10")
 ap.add_argument("--stats", type=int, default=1)
+ap.add_argument("--seed", type=int, default=42)
+ap.add_argument("--parallel", type=int, default=0, help="1: the chunked generator bench.py uses for the 100M-row table (make_table_parallel)")
 ap.add_argument("--sort", type=int, default=0, help="1: cluster the rows on the host first (lexicographic by descending cardinality)")
 a = ap.parse_args()
 t0 = time.time()
-dirty, clean, cards = make_table(a.rows, a.cols, seed=42)
+if a.parallel:
+    from repair.synth import make_table_parallel
+    dirty, _, cards = make_table_parallel(a.rows, a.cols, seed=a.seed, threads=min(32, os.cpu_count() or 1))
+else:
+    dirty, clean, cards = make_table(a.rows, a.cols, seed=a.seed)
 print("gen %.1fs" % (time.time() - t0), flush=True)
 if a.sort:
     t0 = time.time()
