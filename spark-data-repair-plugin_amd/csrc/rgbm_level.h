@@ -394,7 +394,19 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                 if (w0 & (1u << 24)) {
                     const int ls = (int)((w1 >> 16) & 0xFFu) - c.mt_slot0, rs = (int)(w1 >> 24) - c.mt_slot0;
                     const bool lb = ((w1 >> 16) & 0xFFu) != 0xFFu && ls >= 0 && ls < t.nb, rbb = (w1 >> 24) != 0xFFu && rs >= 0 && rs < t.nb;
-                    e = make_uint2(w0, (w1 & 0xFFFFu) | (lb ? (uint32_t)(t.slot0 + ls) : 0xFFu) << 16 | (rbb ? (uint32_t)(t.slot0 + rs) : 0xFFu) << 24);
+                    // The test  left = (bin == NaN bin) ? default-left : (bin <= theta)  as ONE byte compare in the row loop:
+                    //   left = ((bin - off) & 0xFF) <= thr.
+                    // A node that sends missing values right, or whose feature has no NaN bin: off = 0, thr = theta (the NaN bin is the
+                    // last bin, above every threshold).  A node that sends them LEFT: off = NaN bin V, thr = (theta - V) & 0xFF -- the
+                    // NaN bin wraps to 0 (always <= thr), a value bin b < V to 256 + b - V, which is <= 256 + theta - V iff b <= theta.
+                    // theta = -1 without the default-left case cannot come out of the split search; it maps to "never left" (off 255).
+                    const uint32_t theta1 = (w0 >> 8) & 0xFFu, nanbin = (w0 >> 16) & 0xFFu, dleft = (w0 >> 25) & 1u;
+                    uint32_t offb, thr;
+                    if (nanbin != 255u && dleft) { offb = nanbin; thr = (theta1 - 1u - nanbin) & 0xFFu; }
+                    else if (theta1 == 0u) { offb = 255u; thr = 0u; }
+                    else { offb = 0u; thr = theta1 - 1u; }
+                    e = make_uint2((w0 & 0xFFu) | thr << 8 | offb << 16 | 1u << 24,
+                                   (w1 & 0xFFFFu) | (lb ? (uint32_t)(t.slot0 + ls) : 0xFFu) << 16 | (rbb ? (uint32_t)(t.slot0 + rs) : 0xFFu) << 24);
                 } else e = make_uint2(0u, (uint32_t)n | (uint32_t)n << 8 | 0xFFFF0000u);
             } else {
                 // children are numbered child_first + 2 ei (left), + 1 (right); one of the two is built, in slot ei
@@ -411,24 +423,29 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     unsigned long long* hist_h = hist_g + (size_t)total * spn;
     for (int i = tid; i < 2 * total * spn; i += THREADS) hist_g[i] = 0ull;
     // per accumulated feature: replication shift (scalar) and this lane's byte offset inside a node's slots (first slot + replica)
-    int sh3[NACC][16], cj[NACC][16];
+    // the shifts, 4 bits each, packed into one 64-bit SCALAR per chunk (16 separate scalars cost the row loop ~80 spill reloads per step)
+    unsigned long long sh3p[NACC];
+    int cj[NACC][16];
     {
         int o = 0;
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
             const FeatMeta* fa = a == 0 ? fm : fm1;
             const int na = a == 0 ? nfeat : nfeat1;
+            unsigned long long pk = 0ull;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 int shj = 0, fb = 0;
                 if (j < na) { shj = lv_shift(fa[j].nbins, s); fb = o; o += fa[j].nbins << shj; }
-                sh3[a][j] = shj + 3; cj[a][j] = (fb + (lane & ((1 << shj) - 1))) * 8;
+                pk |= (unsigned long long)(shj + 3) << (4 * j); cj[a][j] = (fb + (lane & ((1 << shj) - 1))) * 8;
                 if (tid == 0) {
                     const int q = a * 16 + j;
                     const int wide = (a == 0 ? 0 : cm.wide_bins) + (j < na ? fa[j].wide_off : 0);
                     ftab[q] = j < na ? wide : 0x7FFFFFFF; ftab[32 + q] = fb; ftab[64 + q] = shj; ftab[96 + q] = j < na ? fa[j].hoff - wide : 0;
                 }
             }
+            sh3p[a] = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pk) |
+                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pk >> 32)) << 32;
         }
     }
     const int hdelta = total * spn;
@@ -461,6 +478,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         if (ACC2) r1 = ring_rec1_all[pos];
         unsigned li;
         if (li_in_rec) li = (ACC2 ? r1.w : r.w) >> 24; else li = ring_li_all[pos];
+        // (the packed shifts pass through an empty asm so that the compiler extracts them here, with scalar bit-field ops next to their
+        // use, instead of hoisting 16 unpacked scalars out of the row loop and spilling them)
+        unsigned long long shp[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) { shp[a] = sh3p[a]; asm volatile("" : "+s"(shp[a])); }
         if (on) {
             const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), c.sg), hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), c.sh);
             if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], 1);
@@ -472,7 +494,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
 #else
 #define MT_ATOMIC_ADD(p, v) atomicAdd(p, v)
 #endif
-#define MT_ATOM(A, W, j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[A][j] + (int)(((W[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[A][j])); \
+#define MT_ATOM(A, W, j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[A][j] + (int)(((W[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << (int)((shp[A] >> (4 * (j))) & 15ull))); \
                            MT_ATOMIC_ADD(p_, gq); MT_ATOMIC_ADD(p_ + hdelta, hq); }
             if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
                 MT_ATOM(0, w, 0); MT_ATOM(0, w, 1); MT_ATOM(0, w, 2); MT_ATOM(0, w, 3); MT_ATOM(0, w, 4); MT_ATOM(0, w, 5); MT_ATOM(0, w, 6); MT_ATOM(0, w, 7);
@@ -611,10 +633,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                     const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
                     bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
                 }
-                // left = (bin == nan bin) ? default-left : (bin < theta + 1), without a branch
-                const uint32_t is_nan = (bin == ((ex >> 16) & 0xFFu)) ? 1u : 0u, lt = (bin < ((ex >> 8) & 0xFFu)) ? 1u : 0u;
-                const uint32_t left = (is_nan & (ex >> 25)) | ((is_nan ^ 1u) & lt);
-                const unsigned sel = (left & 1u) ? ey : (ey >> 8);     // child in bits 0..7, workgroup-local built slot in bits 16..23
+                // left = (bin == nan bin) ? default-left : (bin <= theta), as one byte compare (the route entry holds off and thr: see above)
+                const bool left = ((bin - ((ex >> 16) & 0xFFu)) & 0xFFu) <= ((ex >> 8) & 0xFFu);
+                const unsigned sel = left ? ey : (ey >> 8);           // child in bits 0..7, workgroup-local built slot in bits 16..23
                 out4 = expd ? ((out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j))) : out4;
                 li = (sel >> 16) & 0xFFu;
                 built = expd && li != 0xFFu;
