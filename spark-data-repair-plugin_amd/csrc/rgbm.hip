@@ -1654,19 +1654,28 @@ void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_c
                        d_feat_cols ? d_feat_cols : dm->ident.p, dm->n_codes.p, dm->lut_off.p, dm->lut.p, dm->miss.p, F, nchunk, rec.p);
     const char* pe = getenv("RGBM_PREDICTOR"); const bool force_walk = pe && strcmp(pe, "walk") == 0;   // tests: the index-linked walk
     bool qs = dm->qs_MW > 0 && !force_walk;
-    int qs_tb = 8;
-    if (qs) {   // trees per LDS stage: two stages of (masks + leaves) within 48 KB
-        const size_t per_tree = (size_t)dm->qs_S * dm->qs_MW * 4 + (size_t)32 * dm->qs_MW * 8 + 4;
-        while (qs_tb > 1 && 2 * qs_tb * per_tree + 16 > 48 * 1024) --qs_tb;
+    int qs_tb = 8, qs_tw = 0;        // trees per LDS stage; padded mask words per tree (0: the dynamic-stride kernel)
+    if (qs) {
+        const int words = dm->qs_S * dm->qs_MW;
+        // compile-time strides (k_predict_qs<., ., TW, TBN>) for the table sizes that occur: the tree's offset rides in the ds_read
+        struct Fix { int mw, fmax, tw, tbn; };
+        static const Fix fixes[] = {{1, 16, 256, 8}, {1, 16, 512, 8}, {1, 32, 512, 8}, {1, 32, 1024, 4}, {2, 16, 512, 8}, {2, 16, 1024, 4}, {2, 32, 1024, 4}, {2, 32, 2048, 2}};
+        const bool no_fix = getenv("RGBM_QS_FIXED") && atoi(getenv("RGBM_QS_FIXED")) == 0;
+        for (const Fix& fx : fixes)
+            if (!no_fix && fx.mw == dm->qs_MW && fx.fmax == (F <= 16 ? 16 : 32) && words + dm->qs_MW <= fx.tw) { qs_tw = fx.tw; qs_tb = fx.tbn; break; }   // (+ one all-ones pad entry)
+        const size_t per_tree = (size_t)(qs_tw ? qs_tw : words) * 4 + (size_t)32 * dm->qs_MW * 8 + 4;
+        if (!qs_tw) while (qs_tb > 1 && 2 * qs_tb * per_tree + 16 > 48 * 1024) --qs_tb;
         if (2 * qs_tb * per_tree + 16 > 48 * 1024) qs = false;
     }
     if (qs) {   // bit-vector scoring: no tree walk at all
-        const size_t lds = (size_t)2 * qs_tb * ((size_t)dm->qs_S * dm->qs_MW * 4 + (size_t)32 * dm->qs_MW * 8 + 4) + 16;
+        const size_t lds = (size_t)2 * qs_tb * ((size_t)(qs_tw ? qs_tw : dm->qs_S * dm->qs_MW) * 4 + (size_t)32 * dm->qs_MW * 8 + 4) + 16;
         const dim3 grid((unsigned)((n + 256 * QS_ROWS - 1) / (256 * QS_ROWS)), K);
         const uint8_t* r8 = reinterpret_cast<const uint8_t*>(rec.p);
-#define RGBM_QS(MW, FM) hipLaunchKernelGGL((k_predict_qs<MW, FM>), grid, dim3(256), lds, s, r8, n, dm->qs_masks.p, dm->qs_leaves.p, dm->qs_used.p, dm->qs_foff.p, F, dm->qs_S, qs_tb, m->n_iter, K, raw.p)
-        if (dm->qs_MW == 1) { if (F <= 16) RGBM_QS(1, 16); else RGBM_QS(1, 32); }
-        else { if (F <= 16) RGBM_QS(2, 16); else RGBM_QS(2, 32); }
+#define RGBM_QS(MW, FM, TW, TBN) hipLaunchKernelGGL((k_predict_qs<MW, FM, TW, TBN>), grid, dim3(256), lds, s, r8, n, dm->qs_masks.p, dm->qs_leaves.p, dm->qs_used.p, dm->qs_foff.p, F, dm->qs_S, qs_tb, m->n_iter, K, raw.p)
+        if (dm->qs_MW == 1 && F <= 16) { if (qs_tw == 256) RGBM_QS(1, 16, 256, 8); else if (qs_tw == 512) RGBM_QS(1, 16, 512, 8); else RGBM_QS(1, 16, 0, 0); }
+        else if (dm->qs_MW == 1) { if (qs_tw == 512) RGBM_QS(1, 32, 512, 8); else if (qs_tw == 1024) RGBM_QS(1, 32, 1024, 4); else RGBM_QS(1, 32, 0, 0); }
+        else if (F <= 16) { if (qs_tw == 512) RGBM_QS(2, 16, 512, 8); else if (qs_tw == 1024) RGBM_QS(2, 16, 1024, 4); else RGBM_QS(2, 16, 0, 0); }
+        else { if (qs_tw == 1024) RGBM_QS(2, 32, 1024, 4); else if (qs_tw == 2048) RGBM_QS(2, 32, 2048, 2); else RGBM_QS(2, 32, 0, 0); }
 #undef RGBM_QS
     }
     else if (nchunk == 1) hipLaunchKernelGGL(k_predict_raw<true>, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(rec.p), n,

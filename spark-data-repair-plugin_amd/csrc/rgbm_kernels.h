@@ -951,15 +951,20 @@ __global__ __launch_bounds__(256) void k_predict_raw(const uint8_t* __restrict__
 //   grid (ceil(n / (256 QS_ROWS)), K), block 256.  MW = mask words (1: <= 32 leaves, 2: <= 64), FMAX = 16 | 32 features.
 // ------------------------------------------------------------------------------------------------
 constexpr int QS_ROWS = 2;
-template <int MW, int FMAX>
+//   TW / TBN > 0 (round 4): the staged trees sit at COMPILE-TIME strides (TW mask words per tree, padded; TBN trees per stage), the loop
+//   over the trees of a stage is unrolled, and a tree's byte offset becomes the immediate of the ds_read: the per-read address add
+//   (one VALU instruction per feature, row and tree -- a quarter of the loop) is gone.  TW = TBN = 0: strides from the arguments.
+template <int MW, int FMAX, int TW, int TBN>
 __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ rec8, long long n, const uint32_t* __restrict__ masks /* [T][S * MW] */,
                                                     const double* __restrict__ leaves /* [T][32 * MW] */, const uint32_t* __restrict__ used /* [T] features a tree splits on */,
                                                     const int32_t* __restrict__ foff /* [F + 1] */,
-                                                    int F, int S, int tb_n /* trees per LDS stage */, int n_iter, int K, double* __restrict__ raw /* [K][n] */) {
+                                                    int F, int S, int tb_n_arg /* trees per LDS stage */, int n_iter, int K, double* __restrict__ raw /* [K][n] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = 32 * MW;
-    const int tree_words = S * MW;                                   // mask words of a tree
-    uint32_t* sm = reinterpret_cast<uint32_t*>(smem);                // [2][tb_n][S * MW]
+    const int tree_words_src = S * MW;                               // mask words of a tree in global memory
+    const int tree_words = TW > 0 ? TW : tree_words_src;             // ... and its stride in LDS
+    const int tb_n = TBN > 0 ? TBN : tb_n_arg;
+    uint32_t* sm = reinterpret_cast<uint32_t*>(smem);                // [2][tb_n][tree_words]
     double* sl = reinterpret_cast<double*>(sm + 2 * tb_n * tree_words + ((2 * tb_n * tree_words) & 1));   // [2][tb_n][LP], 8-byte aligned
     uint32_t* su = reinterpret_cast<uint32_t*>(sl + 2 * tb_n * LP);  // [2][tb_n] used-feature bits
     const int k = blockIdx.y, tid = threadIdx.x;
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
                 const int fb = foff[f], nb = foff[f + 1] - fb - 1;                                   // nb value bins, entry nb = missing
                 const unsigned bin = rec8[((long long)(f >> 4) * n + row[q]) * 16 + (f & 15)];
                 o = (fb + (int)(bin < (unsigned)nb ? bin : (unsigned)nb)) * MW * 4;                 // byte offset inside a tree's table
-            }
+            } else if (TW > 0) o = S * MW * 4;                         // no such feature: the all-ones pad entry behind the tree's masks
             off[q][f] = o;
         }
     }
@@ -985,7 +990,8 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
             const int it = it0 + tb;
             if (it >= n_iter) break;
             const long long t = (long long)it * K + k;
-            for (int i = tid; i < tree_words; i += 256) sm[(buf * tb_n + tb) * tree_words + i] = masks[t * tree_words + i];
+            for (int i = tid; i < tree_words_src; i += 256) sm[(buf * tb_n + tb) * tree_words + i] = masks[t * tree_words_src + i];
+            if (TW > 0 && tid < MW) sm[(buf * tb_n + tb) * tree_words + tree_words_src + tid] = 0xFFFFFFFFu;
             if (tid < LP) sl[(buf * tb_n + tb) * LP + tid] = leaves[t * LP + tid];
             if (tid == LP) su[buf * tb_n + tb] = used[t];
         }
@@ -996,18 +1002,19 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
     for (int it0 = 0; it0 < n_iter; it0 += tb_n, buf ^= 1) {
         if (it0 + tb_n < n_iter) stage(it0 + tb_n, buf ^ 1);
         const int nt = (n_iter - it0) < tb_n ? (n_iter - it0) : tb_n;
-        for (int tb = 0; tb < nt; ++tb) {
+        auto one_tree = [&](int tb) __attribute__((always_inline)) {
             const unsigned char* tm = reinterpret_cast<const unsigned char*>(sm + (buf * tb_n + tb) * tree_words);
             const double* tl = sl + (buf * tb_n + tb) * LP;
-            // the mask of a feature the tree never splits on is all ones for every bin: its lookup is skipped (a scalar branch per feature;
-            // a 31-leaf tree of the synthetic tables splits on 6-11 of its 15 features)
+            // the mask of a feature the tree never splits on is all ones for every bin
             const uint32_t um = (uint32_t)__builtin_amdgcn_readfirstlane((int)su[buf * tb_n + tb]);
             uint32_t v0[QS_ROWS], v1[QS_ROWS];
 #pragma unroll
             for (int q = 0; q < QS_ROWS; ++q) { v0[q] = 0xFFFFFFFFu; v1[q] = 0xFFFFFFFFu; }
 #pragma unroll
             for (int f = 0; f < FMAX; ++f) {
-                if (f < F && ((um >> f) & 1u)) {                       // uniform
+                // fixed strides: every feature's mask is read, all reads of a tree in flight together (a branch per feature would put a wait
+                // for the LDS behind every read: measured in the ISA, 45 s_waitcnt per tree); dynamic strides: unused features are skipped
+                if (TBN > 0 || (f < F && ((um >> f) & 1u))) {          // uniform
 #pragma unroll
                     for (int q = 0; q < QS_ROWS; ++q) {
                         if (MW == 1) v0[q] &= *reinterpret_cast<const uint32_t*>(tm + off[q][f]);
@@ -1022,6 +1029,13 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
                 else leaf = v0[q] ? __ffs((int)v0[q]) - 1 : 32 + __ffs((int)v1[q]) - 1;
                 s[q] += tl[leaf];
             }
+        
+        };
+        if (TBN > 0) {
+#pragma unroll
+            for (int tb = 0; tb < (TBN > 0 ? TBN : 1); ++tb) if (tb < nt) one_tree(tb);     // (uniform; the last stage may be partial)
+        } else {
+            for (int tb = 0; tb < nt; ++tb) one_tree(tb);
         }
         __syncthreads();
     }
