@@ -1921,12 +1921,39 @@ static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* tar
         for (int t = 0; t < T; ++t) { mr = std::max(mr, (size_t)((models[t]->F + 15) / 16)); mk = std::max(mk, (size_t)models[t]->K); }
         scratch.rec.alloc(mr * (size_t)n); scratch.raw.alloc(mk * (size_t)n);
     }
+    const bool timing = getenv("RGBM_TIMING") != nullptr;
+    double t_model = 0, t_score = 0, t_fill = 0, t_copy = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    {   // predictor tables of all the chain's models, built side by side (host work + small uploads, ~5 ms a model)
+        double t0 = now();
+        std::vector<rgbm_model*> todo;
+        for (int t = 0; t < T; ++t) if (std::find(todo.begin(), todo.end(), models[t]) == todo.end()) todo.push_back(models[t]);
+        const size_t nth = std::min<size_t>(std::min<size_t>(todo.size(), 16), std::max(1u, std::thread::hardware_concurrency()));
+        if (nth <= 1) { for (rgbm_model* m : todo) device_model(m, device, s); }
+        else {
+            std::atomic<size_t> next{0}; std::mutex emu; std::exception_ptr err;
+            auto work = [&]() {
+                try {
+                    use_device(device);
+                    StreamGuard own;
+                    for (size_t j = next.fetch_add(1); j < todo.size(); j = next.fetch_add(1)) device_model(todo[j], device, own.s);
+                } catch (...) { std::lock_guard<std::mutex> lk(emu); if (!err) err = std::current_exception(); }
+            };
+            std::vector<std::thread> th;
+            for (size_t q = 0; q < nth; ++q) th.emplace_back(work);
+            for (auto& x : th) x.join();
+            if (err) std::rethrow_exception(err);
+        }
+        t_model = now() - t0;
+    }
     for (int t = 0; t < T; ++t) {
         rgbm_model* m = models[t];
         const int F = feat_off[t + 1] - feat_off[t];
         if (F != m->F) throw std::invalid_argument("chain: feature list length differs from the model's feature count");
+        double t1 = now();
         DevBuf<int32_t> d_fc(F); d_fc.upload(feat_cols + feat_off[t], F, s);
         predict_device(m, device, s, d_codes, Ntab, row0, n, d_fc.p, nullptr, d_label.p, d_top.p, &scratch);
+        double t2 = now(); t_score += t2 - t1;
         if (m->objective != 2) {
             int ncc = class_off ? class_off[t + 1] - class_off[t] : m->num_class;
             DevBuf<int32_t> d_cc(std::max(ncc, 1));
@@ -1936,9 +1963,12 @@ static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* tar
             hipLaunchKernelGGL(k_fill_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes + (long long)target_col[t] * Ntab + row0, n, d_label.p, d_cc.p, ncc);
             HIPCHK(hipStreamSynchronize(s));
         }
+        double t3 = now(); t_fill += t3 - t2;
         if (out_label) HIPCHK(hipMemcpy(out_label + (size_t)t * n, d_label.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (out_prob) HIPCHK(hipMemcpy(out_prob + (size_t)t * n, d_top.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        t_copy += now() - t3;
     }
+    if (timing) fprintf(stderr, "[rgbm] chain of %d models over %lld rows: tables %.1f ms, score %.1f ms, fill %.1f ms, copy out %.1f ms\n", T, n, t_model * 1e3, t_score * 1e3, t_fill * 1e3, t_copy * 1e3);
     return RGBM_OK;
 }
 

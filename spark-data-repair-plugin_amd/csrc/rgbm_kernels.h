@@ -998,15 +998,15 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
     };
     stage(0, 0);
     __syncthreads();
-    int buf = 0;
-    for (int it0 = 0; it0 < n_iter; it0 += tb_n, buf ^= 1) {
-        if (it0 + tb_n < n_iter) stage(it0 + tb_n, buf ^ 1);
+    // the trees of LDS buffer `buf` (a compile-time constant in the fixed-stride variant: with the tree's stride it folds into the
+    // immediate of the ds_read -- a run-time buffer base was one v_add per read, 256 of the 711 VALU instructions of a stage)
+    auto score_stage = [&](const int buf, const int it0) __attribute__((always_inline)) {
         const int nt = (n_iter - it0) < tb_n ? (n_iter - it0) : tb_n;
         auto one_tree = [&](int tb) __attribute__((always_inline)) {
             const unsigned char* tm = reinterpret_cast<const unsigned char*>(sm + (buf * tb_n + tb) * tree_words);
             const double* tl = sl + (buf * tb_n + tb) * LP;
             // the mask of a feature the tree never splits on is all ones for every bin
-            const uint32_t um = (uint32_t)__builtin_amdgcn_readfirstlane((int)su[buf * tb_n + tb]);
+            const uint32_t um = TBN > 0 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)su[buf * tb_n + tb]);
             uint32_t v0[QS_ROWS], v1[QS_ROWS];
 #pragma unroll
             for (int q = 0; q < QS_ROWS; ++q) { v0[q] = 0xFFFFFFFFu; v1[q] = 0xFFFFFFFFu; }
@@ -1025,11 +1025,11 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
 #pragma unroll
             for (int q = 0; q < QS_ROWS; ++q) {
                 int leaf;
-                if (MW == 1) leaf = __ffs((int)v0[q]) - 1;
-                else leaf = v0[q] ? __ffs((int)v0[q]) - 1 : 32 + __ffs((int)v1[q]) - 1;
+                // (the AND always keeps the exit leaf's bit: count-trailing-zeros needs no zero case)
+                if (MW == 1) leaf = __builtin_ctz(v0[q]);
+                else leaf = v0[q] ? __builtin_ctz(v0[q]) : 32 + __builtin_ctz(v1[q]);
                 s[q] += tl[leaf];
             }
-        
         };
         if (TBN > 0) {
 #pragma unroll
@@ -1037,7 +1037,24 @@ __global__ __launch_bounds__(256) void k_predict_qs(const uint8_t* __restrict__ 
         } else {
             for (int tb = 0; tb < nt; ++tb) one_tree(tb);
         }
-        __syncthreads();
+    };
+    if (TBN > 0) {
+        for (int it0 = 0; it0 < n_iter; it0 += 2 * tb_n) {
+            if (it0 + tb_n < n_iter) stage(it0 + tb_n, 1);
+            score_stage(0, it0);
+            __syncthreads();
+            if (it0 + tb_n >= n_iter) break;
+            if (it0 + 2 * tb_n < n_iter) stage(it0 + 2 * tb_n, 0);
+            score_stage(1, it0 + tb_n);
+            __syncthreads();
+        }
+    } else {
+        int buf = 0;
+        for (int it0 = 0; it0 < n_iter; it0 += tb_n, buf ^= 1) {
+            if (it0 + tb_n < n_iter) stage(it0 + tb_n, buf ^ 1);
+            score_stage(buf, it0);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int q = 0; q < QS_ROWS; ++q) if (base + q * 256 + tid < n) raw[(long long)k * n + row[q]] = s[q];

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/r04u; mkdir -p $O
+( timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_batch.py tests/test_gpu_prep.py tests/test_pipeline.py tests/test_quality.py -q -m gpu -x ) 2>&1 | tail -3 | tee $O/tests.log
+for i in 1 2; do
+  ( timeout 200 python bench.py --train-rows 10000 --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_small_$i.json | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print({k:round(d[k],4) for k in ('model_train_sec','repair_sec','elapsed_sec','repair_accuracy_vs_clean')}, d['models_md5'])" | tee -a $O/repair.log )
+done
