@@ -286,11 +286,21 @@ struct Feat {
     std::vector<uint32_t> unseen;
     bool is_unseen(int32_t c) const { return !unseen.empty() && ((unseen[(size_t)c >> 5] >> (c & 31)) & 1u); }
 };
+// One tree: L leaves, L - 1 internal nodes.  Its eight arrays sit in ONE block -- the tree's own, or a slice of the model's arena
+// (a model is 300 x K trees: eight std::vectors a tree were 576 000 allocations for the 16 models of a default job).
 struct Tree {
     int32_t L = 1;
-    std::vector<int32_t> feat, theta, dleft, left, right;
-    std::vector<double> gain, leaf_value;
-    std::vector<int32_t> leaf_count;
+    double *gain = nullptr, *leaf_value = nullptr;
+    int32_t *feat = nullptr, *theta = nullptr, *dleft = nullptr, *left = nullptr, *right = nullptr, *leaf_count = nullptr;
+    std::unique_ptr<double[]> own;
+    static size_t doubles(int L) { const size_t n = (size_t)L - 1; return n + (size_t)L + (5 * n + (size_t)L + 1) / 2; }
+    void place(double* p, int L_) {
+        L = L_; const size_t n = (size_t)L - 1;
+        gain = p; leaf_value = p + n;
+        int32_t* q = reinterpret_cast<int32_t*>(p + n + L);
+        feat = q; theta = q + n; dleft = q + 2 * n; left = q + 3 * n; right = q + 4 * n; leaf_count = q + 5 * n;
+    }
+    void alloc(int L_) { own.reset(new double[doubles(L_)]); place(own.get(), L_); }
 };
 
 struct DeviceModel {   // predictor mirror of a model on one device
@@ -307,6 +317,7 @@ struct rgbm_model {
     int32_t objective = 0, num_class = 0, K = 1, n_iter = 0, F = 0;
     std::vector<Feat> feats;
     std::vector<Tree> trees;
+    std::unique_ptr<double[]> tree_arena;      // storage of the trees of a trained model (a loaded model's trees own theirs)
     std::mutex mu;
     std::map<int, DeviceModel*> dev;
     ~rgbm_model() { for (auto& kv : dev) { (void)hipSetDevice(kv.first); delete kv.second; } }
@@ -602,18 +613,22 @@ size_t model_trees_begin(rgbm_model* model, const HostTrees& h, int NE, int K) {
     int n_iter = NE;
     for (int it = 0; it < NE; ++it) if (!h.any[it]) { n_iter = it > 0 ? it : 1; break; }   // "no more leaves that meet the split requirements"
     model->n_iter = n_iter;
-    model->trees.resize((size_t)n_iter * K);
-    return model->trees.size();
+    const size_t nt = (size_t)n_iter * K;
+    model->trees.clear(); model->trees.resize(nt);
+    size_t total = 0;
+    for (size_t t = 0; t < nt; ++t) total += Tree::doubles(std::max(h.L[t], 1));
+    model->tree_arena.reset(new double[std::max<size_t>(total, 1)]);
+    size_t off = 0;
+    for (size_t t = 0; t < nt; ++t) { const int L = std::max(h.L[t], 1); model->trees[t].place(model->tree_arena.get() + off, L); off += Tree::doubles(L); }
+    return nt;
 }
 void model_trees_fill(rgbm_model* model, const HostTrees& h, int NL, size_t t0, size_t t1) {
     for (size_t t = t0; t < t1; ++t) {
-        Tree& tr = model->trees[t];
-        tr.L = h.L[t]; const int n = tr.L - 1;
-        const size_t nb = t * (NL - 1), lb = t * NL;
-        tr.feat.assign(h.feat + nb, h.feat + nb + n); tr.theta.assign(h.theta + nb, h.theta + nb + n);
-        tr.dleft.assign(h.dleft + nb, h.dleft + nb + n); tr.left.assign(h.left + nb, h.left + nb + n);
-        tr.right.assign(h.right + nb, h.right + nb + n); tr.gain.assign(h.gain + nb, h.gain + nb + n);
-        tr.leaf_value.assign(h.val + lb, h.val + lb + tr.L); tr.leaf_count.assign(h.cnt + lb, h.cnt + lb + tr.L);
+        Tree& tr = model->trees[t];               // (placed by model_trees_begin)
+        const size_t n = (size_t)tr.L - 1, nb = t * (NL - 1), lb = t * NL;
+        memcpy(tr.feat, h.feat + nb, 4 * n); memcpy(tr.theta, h.theta + nb, 4 * n); memcpy(tr.dleft, h.dleft + nb, 4 * n);
+        memcpy(tr.left, h.left + nb, 4 * n); memcpy(tr.right, h.right + nb, 4 * n); memcpy(tr.gain, h.gain + nb, 8 * n);
+        memcpy(tr.leaf_value, h.val + lb, 8 * (size_t)tr.L); memcpy(tr.leaf_count, h.cnt + lb, 4 * (size_t)tr.L);
     }
 }
 void model_from_trees(rgbm_model* model, const HostTrees& h, int NE, int K, int NL) {
@@ -1291,6 +1306,23 @@ bool small_fit_eligible(const rgbm_table& tab, int32_t F, const rgbm_params& p, 
 
 // status[i] = RGBM_OK or the error code of fit i (its message is the thread's last error when exactly one fit fails; the Python
 // binding raises per fit).  Fits the fused kernel does not cover (large tables, > 256 leaves) run through train_core one by one.
+// page-locked host block for the tree harvest of a batch of fits (see phase E of train_batch_small)
+struct HarvestArena {
+    std::mutex mu; void* p = nullptr; size_t cap = 0; int device = -1;
+    static constexpr size_t KEEP_MAX = (size_t)1 << 30;
+    // a block of at least `bytes` (null: not available -- the caller falls back to pageable memory)
+    void* get(size_t bytes, int dev) {
+        if (bytes == 0 || bytes > KEEP_MAX || getenv("RGBM_NO_PIN") != nullptr) return nullptr;
+        if (p && cap >= bytes && device == dev) return p;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = std::min(KEEP_MAX, bytes + bytes / 4);
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return nullptr; }
+        cap = want; device = dev;
+        return p;
+    }
+};
+HarvestArena& harvest_arena() { static HarvestArena* a = new HarvestArena(); return *a; }
+
 void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** out, int32_t* status) {
     using namespace rg;
     long long small_rows = 65536;
@@ -1501,31 +1533,61 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
     // ---- E. trees back to the host, one model per fit
     std::vector<int> want;                                            // fits whose model is wanted (a CV fold is wanted for its scores only)
     for (int i : ok) if (!((specs[i].params->reserved & RGBM_FLAG_NO_MODEL) && dev[i]->n_valid > 0)) want.push_back(i);
-    for (int i : want) {
-        SmallFitDev& d = *dev[i]; const size_t NT = d.NT; const int NL = d.NL;
-        d.hL.resize(NT); d.hfeat.resize(NT * (NL - 1)); d.htheta.resize(NT * (NL - 1)); d.hdleft.resize(NT * (NL - 1)); d.hleft.resize(NT * (NL - 1)); d.hright.resize(NT * (NL - 1));
-        d.hcnt.resize(NT * NL); d.hany.resize(d.NE); d.hgain.resize(NT * (NL - 1)); d.hval.resize(NT * NL);
-        d.t_L.download(d.hL.data(), d.hL.size(), s); d.t_feat.download(d.hfeat.data(), d.hfeat.size(), s); d.t_theta.download(d.htheta.data(), d.htheta.size(), s);
-        d.t_dleft.download(d.hdleft.data(), d.hdleft.size(), s); d.t_left.download(d.hleft.data(), d.hleft.size(), s); d.t_right.download(d.hright.data(), d.hright.size(), s);
-        d.t_cnt.download(d.hcnt.data(), d.hcnt.size(), s); d.t_gain.download(d.hgain.data(), d.hgain.size(), s); d.t_val.download(d.hval.data(), d.hval.size(), s);
-        d.any.download(d.hany.data(), d.NE, s);
+    // The trees of a batch are tens of MB (72 000 trees, 87 MB for the 16 fits of the 10M x 16 job): into fresh pageable vectors that
+    // was zero-filling + page faults + 160 staged copies = most of 69 ms.  They land in ONE page-locked block kept for the life of the
+    // process (grown on demand, at most 1 GiB kept; a second batch running at the same time uses pageable vectors).
+    std::vector<HostTrees> hts(n_fits);
+    HarvestArena& HA = harvest_arena();
+    std::unique_lock<std::mutex> ha_lock(HA.mu, std::try_to_lock);
+    {
+        size_t need = 0;
+        auto take = [&](size_t bytes) { const size_t o = need; need += (bytes + 63) & ~(size_t)63; return o; };
+        struct Off { size_t L, feat, theta, dleft, left, right, cnt, gain, val, any; };
+        std::vector<Off> offs(n_fits);
+        for (int i : want) {
+            SmallFitDev& d = *dev[i]; const size_t NT = d.NT, nn = NT * (size_t)(d.NL - 1), nl = NT * (size_t)d.NL;
+            Off& o = offs[i];
+            o.L = take(NT * 4); o.feat = take(nn * 4); o.theta = take(nn * 4); o.dleft = take(nn * 4); o.left = take(nn * 4); o.right = take(nn * 4);
+            o.cnt = take(nl * 4); o.gain = take(nn * 8); o.val = take(nl * 8); o.any = take((size_t)d.NE * 4);
+        }
+        char* base = ha_lock.owns_lock() ? (char*)HA.get(need, device) : nullptr;
+        for (int i : want) {
+            SmallFitDev& d = *dev[i]; const size_t NT = d.NT, nn = NT * (size_t)(d.NL - 1), nl = NT * (size_t)d.NL;
+            int32_t *hL, *hfeat, *htheta, *hdleft, *hleft, *hright, *hcnt, *hany; double *hgain, *hval;
+            if (base) {
+                const Off& o = offs[i];
+                hL = (int32_t*)(base + o.L); hfeat = (int32_t*)(base + o.feat); htheta = (int32_t*)(base + o.theta); hdleft = (int32_t*)(base + o.dleft);
+                hleft = (int32_t*)(base + o.left); hright = (int32_t*)(base + o.right); hcnt = (int32_t*)(base + o.cnt); hany = (int32_t*)(base + o.any);
+                hgain = (double*)(base + o.gain); hval = (double*)(base + o.val);
+            } else {
+                d.hL.resize(NT); d.hfeat.resize(nn); d.htheta.resize(nn); d.hdleft.resize(nn); d.hleft.resize(nn); d.hright.resize(nn);
+                d.hcnt.resize(nl); d.hany.resize(d.NE); d.hgain.resize(nn); d.hval.resize(nl);
+                hL = d.hL.data(); hfeat = d.hfeat.data(); htheta = d.htheta.data(); hdleft = d.hdleft.data(); hleft = d.hleft.data(); hright = d.hright.data();
+                hcnt = d.hcnt.data(); hany = d.hany.data(); hgain = d.hgain.data(); hval = d.hval.data();
+            }
+            d.t_L.download(hL, NT, s); d.t_feat.download(hfeat, nn, s); d.t_theta.download(htheta, nn, s);
+            d.t_dleft.download(hdleft, nn, s); d.t_left.download(hleft, nn, s); d.t_right.download(hright, nn, s);
+            d.t_cnt.download(hcnt, nl, s); d.t_gain.download(hgain, nn, s); d.t_val.download(hval, nl, s);
+            d.any.download(hany, d.NE, s);
+            hts[i] = HostTrees{hL, hfeat, htheta, hdleft, hleft, hright, hcnt, hgain, hval, hany};
+        }
     }
     HIPCHK(hipStreamSynchronize(s));
+    const double t_down = now();
     {   // the tree lists of the models: host work proportional to fits x iterations x class trees, spread over a few threads
         struct Item { int fit; size_t t0, t1; };
-        std::vector<Item> items; std::vector<HostTrees> hts(n_fits);
+        std::vector<Item> items;
         for (int i : want) {
             SmallFitDev& d = *dev[i];
-            hts[i] = HostTrees{d.hL.data(), d.hfeat.data(), d.htheta.data(), d.hdleft.data(), d.hleft.data(), d.hright.data(), d.hcnt.data(), d.hgain.data(), d.hval.data(), d.hany.data()};
             const size_t n = model_trees_begin(d.h.model.get(), hts[i], d.NE, d.K);
-            for (size_t t0 = 0; t0 < n; t0 += 1024) items.push_back(Item{i, t0, std::min(n, t0 + 1024)});
+            for (size_t t0 = 0; t0 < n; t0 += 512) items.push_back(Item{i, t0, std::min(n, t0 + 512)});
         }
         std::atomic<size_t> next{0};
         auto work = [&]() {
             for (size_t j = next.fetch_add(1); j < items.size(); j = next.fetch_add(1))
                 model_trees_fill(dev[items[j].fit]->h.model.get(), hts[items[j].fit], dev[items[j].fit]->NL, items[j].t0, items[j].t1);
         };
-        const size_t nth = std::min<size_t>(std::min<size_t>(std::max<size_t>(items.size(), 1), 16), std::max(1u, std::thread::hardware_concurrency()));
+        const size_t nth = std::min<size_t>(std::min<size_t>(std::max<size_t>(items.size(), 1), 32), std::max(1u, std::thread::hardware_concurrency()));
         std::vector<std::thread> th;
         for (size_t q = 1; q < nth; ++q) th.emplace_back(work);
         work();
@@ -1538,13 +1600,52 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
       fprintf(stderr, "[rgbm] k_small_tree phases (%% of thread-0 cycles): zero %.1f | accumulate %.1f | flush %.1f | split_find %.1f | reduce+pick %.1f | partition %.1f | finish %.1f | score %.1f\n",
               100.0 * hp[0] / tot, 100.0 * hp[1] / tot, 100.0 * hp[2] / tot, 100.0 * hp[3] / tot, 100.0 * hp[4] / tot, 100.0 * hp[5] / tot, 100.0 * hp[6] / tot, 100.0 * hp[7] / tot); }
 #endif
-    if (timing) fprintf(stderr, "[rgbm] batch of %zu fits, %u class trees, %d iterations: setup %.1f ms, enqueue %.1f ms, iterations drained after %.1f ms, download + models %.1f ms\n",
-                        ok.size(), KT, NE_max, t_setup - t_start, t_enq - t_setup, t_iter - t_setup, now() - t_iter);
+    if (timing) fprintf(stderr, "[rgbm] batch of %zu fits, %u class trees, %d iterations: setup %.1f ms, enqueue %.1f ms, iterations drained after %.1f ms, download %.1f ms (%s), models %.1f ms\n",
+                        ok.size(), KT, NE_max, t_setup - t_start, t_enq - t_setup, t_iter - t_setup, t_down - t_iter, ha_lock.owns_lock() ? "page-locked block" : "pageable", now() - t_down);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Predictor mirror
 // ---------------------------------------------------------------------------------------------
+// run `fn(t0, t1)` over [0, n) in ranges, on a few host threads when there is enough of it (the table builders below: a
+// 19 200-tree model is ~20 ms of host work on one thread)
+template <class Fn> void parallel_ranges(size_t n, size_t min_per_thread, Fn fn) {
+    const size_t nth = std::min<size_t>(std::min<size_t>(8, std::max<size_t>(1, n / std::max<size_t>(min_per_thread, 1))), std::max(1u, std::thread::hardware_concurrency()));
+    if (nth <= 1) { fn((size_t)0, n); return; }
+    std::exception_ptr err; std::mutex emu; std::vector<std::thread> th;
+    for (size_t q = 0; q < nth; ++q)
+        th.emplace_back([&, q]() { try { fn(n * q / nth, n * (q + 1) / nth); } catch (...) { std::lock_guard<std::mutex> lk(emu); if (!err) err = std::current_exception(); } });
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
+// the index-linked node tables of the tree walk (k_predict_raw): built only for models the bit-vector scorer cannot take, or when
+// a test asks for the walk (the caller holds m->mu)
+void build_walk_tables(rgbm_model* m, DeviceModel* dm, hipStream_t s) {
+    using namespace rg;
+    if (dm->nodes.p) return;
+    int maxL = 2;
+    for (auto& t : m->trees) maxL = std::max(maxL, t.L);
+    dm->node_stride = maxL - 1; dm->leaf_stride = maxL;
+    const size_t NT = m->trees.size();
+    std::vector<PNode> nodes(std::max<size_t>(NT, 1) * dm->node_stride); std::vector<double> lv(std::max<size_t>(NT, 1) * dm->leaf_stride, 0.0);
+    parallel_ranges(NT, 2048, [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; ++t) {
+            const Tree& tr = m->trees[t];
+            PNode* nd = nodes.data() + t * dm->node_stride;
+            if (tr.L <= 1) { nd[0].w0 = 0; nd[0].w1 = 0xFFFFFFFFu; /* both children = ~0 */ }
+            for (int j = 0; j < tr.L - 1; ++j) {
+                nd[j].w0 = (uint32_t)(tr.feat[j] & 0xFFFF) | ((uint32_t)(tr.theta[j] + 1) & 0x1FF) << 16 | (uint32_t)(tr.dleft[j] ? 1 : 0) << 25;
+                nd[j].w1 = ((uint32_t)tr.left[j] & 0xFFFFu) | ((uint32_t)tr.right[j] & 0xFFFFu) << 16;
+            }
+            for (int l = 0; l < tr.L; ++l) lv[t * dm->leaf_stride + l] = tr.leaf_value[l];
+        }
+    });
+    dm->nodes.alloc(nodes.size()); dm->nodes.upload(nodes.data(), nodes.size(), s);
+    dm->leaf_value.alloc(lv.size()); dm->leaf_value.upload(lv.data(), lv.size(), s);
+    HIPCHK(hipStreamSynchronize(s));     // the vectors are locals
+}
+
 DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
     std::lock_guard<std::mutex> lk(m->mu);
     auto it = m->dev.find(device);
@@ -1552,21 +1653,7 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
     using namespace rg;
     auto dm = new DeviceModel();
     std::unique_ptr<DeviceModel> guard(dm);
-    int maxL = 2;
-    for (auto& t : m->trees) maxL = std::max(maxL, t.L);
-    dm->node_stride = maxL - 1; dm->leaf_stride = maxL;
     const size_t NT = m->trees.size();
-    std::vector<PNode> nodes(std::max<size_t>(NT, 1) * dm->node_stride); std::vector<double> lv(std::max<size_t>(NT, 1) * dm->leaf_stride, 0.0);
-    for (size_t t = 0; t < NT; ++t) {
-        const Tree& tr = m->trees[t];
-        PNode* nd = nodes.data() + t * dm->node_stride;
-        if (tr.L <= 1) { nd[0].w0 = 0; nd[0].w1 = 0xFFFFFFFFu; /* both children = ~0 */ }
-        for (int j = 0; j < tr.L - 1; ++j) {
-            nd[j].w0 = (uint32_t)(tr.feat[j] & 0xFFFF) | ((uint32_t)(tr.theta[j] + 1) & 0x1FF) << 16 | (uint32_t)(tr.dleft[j] ? 1 : 0) << 25;
-            nd[j].w1 = ((uint32_t)tr.left[j] & 0xFFFFu) | ((uint32_t)tr.right[j] & 0xFFFFu) << 16;
-        }
-        for (int l = 0; l < tr.L; ++l) lv[t * dm->leaf_stride + l] = tr.leaf_value[l];
-    }
     const int F = m->F;
     std::vector<long long> lut_off(F + 1, 0); std::vector<int32_t> ncod(F), ident(F); std::vector<uint8_t> miss(F, 255);
     for (int f = 0; f < F; ++f) { ncod[f] = m->feats[f].n_codes; ident[f] = f; lut_off[f + 1] = lut_off[f] + std::max(ncod[f], 1); }
@@ -1585,16 +1672,24 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
             std::vector<int32_t> foff(F_ + 1, 0);
             for (int f = 0; f < F_; ++f) foff[f + 1] = foff[f] + std::max(m->feats[f].V, 1) + 1;       // value bins + the missing entry
             const int S = foff[F_];
-            std::vector<uint32_t> mk((size_t)NT * S * MW, 0xFFFFFFFFu), usedf(NT, 0u); std::vector<double> lv2((size_t)NT * LP, 0.0);
+            // (uninitialised blocks, filled by the thread that owns the range: a 20 MB vector constructor is 5 ms of page faults on one thread)
+            const size_t mk_n = (size_t)NT * S * MW, lv2_n = (size_t)NT * LP;
+            std::unique_ptr<uint32_t[]> mk_(new uint32_t[mk_n]); std::unique_ptr<double[]> lv2_(new double[lv2_n]);
+            uint32_t* const mk = mk_.get(); double* const lv2 = lv2_.get();
+            std::vector<uint32_t> usedf(NT, 0u);
+            parallel_ranges(NT, 2048, [&](size_t tr0, size_t tr1) {
+            memset(mk + tr0 * S * MW, 0xFF, (tr1 - tr0) * S * MW * sizeof(uint32_t));
+            std::fill(lv2 + tr0 * LP, lv2 + tr1 * LP, 0.0);
             std::vector<int> lo, mid;                                // per internal node: in-order ids [lo, mid) of the leaves of its left subtree
-            for (size_t t = 0; t < NT; ++t) {
+            std::vector<std::pair<int, int>> st;
+            for (size_t t = tr0; t < tr1; ++t) {
                 const Tree& tr = m->trees[t];
-                uint32_t* tm = mk.data() + t * S * MW; double* tl = lv2.data() + t * LP;
-                if (tr.L <= 1) { tl[0] = tr.leaf_value.empty() ? 0.0 : tr.leaf_value[0]; continue; }
+                uint32_t* tm = mk + t * S * MW; double* tl = lv2 + t * LP;
+                if (tr.L <= 1) { tl[0] = tr.leaf_value ? tr.leaf_value[0] : 0.0; continue; }
                 lo.assign(tr.L - 1, 0); mid.assign(tr.L - 1, 0);
                 // iterative in-order traversal: (ref, state) with state 0 = enter, 1 = left subtree done
                 int next_leaf = 0;
-                std::vector<std::pair<int, int>> st; st.emplace_back(0, 0);
+                st.clear(); st.emplace_back(0, 0);
                 while (!st.empty()) {
                     auto& top = st.back();
                     const int ref = top.first;
@@ -1613,16 +1708,16 @@ DeviceModel* device_model(rgbm_model* m, int device, hipStream_t s) {
                     if (!tr.dleft[j]) for (int q = 0; q < MW; ++q) tm[(size_t)(foff[f] + nb) * MW + q] &= w[q];
                 }
             }
-            dm->qs_masks.alloc(mk.size()); dm->qs_masks.upload(mk.data(), mk.size(), s);
-            dm->qs_leaves.alloc(lv2.size()); dm->qs_leaves.upload(lv2.data(), lv2.size(), s);
+            });
+            dm->qs_masks.alloc(mk_n); dm->qs_masks.upload(mk, mk_n, s);
+            dm->qs_leaves.alloc(lv2_n); dm->qs_leaves.upload(lv2, lv2_n, s);
             dm->qs_used.alloc(usedf.size()); dm->qs_used.upload(usedf.data(), usedf.size(), s);
             dm->qs_foff.alloc(foff.size()); dm->qs_foff.upload(foff.data(), foff.size(), s);
             dm->qs_S = S; dm->qs_MW = MW;
             HIPCHK(hipStreamSynchronize(s));     // the vectors are locals
         }
     }
-    dm->nodes.alloc(nodes.size()); dm->nodes.upload(nodes.data(), nodes.size(), s);
-    dm->leaf_value.alloc(lv.size()); dm->leaf_value.upload(lv.data(), lv.size(), s);
+    if (dm->qs_MW == 0) build_walk_tables(m, dm, s);
     dm->lut.alloc(lut.size()); dm->lut.upload(lut.data(), lut.size(), s);
     dm->lut_off.alloc(F + 1); dm->lut_off.upload(lut_off.data(), F + 1, s);
     dm->n_codes.alloc(F); dm->n_codes.upload(ncod.data(), F, s);
@@ -1667,6 +1762,7 @@ void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_c
         if (!qs_tw) while (qs_tb > 1 && 2 * qs_tb * per_tree + 16 > 48 * 1024) --qs_tb;
         if (2 * qs_tb * per_tree + 16 > 48 * 1024) qs = false;
     }
+    if (!qs) { std::lock_guard<std::mutex> lk(m->mu); build_walk_tables(m, dm, s); }
     if (qs) {   // bit-vector scoring: no tree walk at all
         const size_t lds = (size_t)2 * qs_tb * ((size_t)(qs_tw ? qs_tw : dm->qs_S * dm->qs_MW) * 4 + (size_t)32 * dm->qs_MW * 8 + 4) + 16;
         const dim3 grid((unsigned)((n + 256 * QS_ROWS - 1) / (256 * QS_ROWS)), K);
@@ -1688,27 +1784,35 @@ void predict_device(rgbm_model* m, int device, hipStream_t s, const int32_t* d_c
 }
 
 
-void put(std::vector<uint8_t>& b, const void* p, size_t n) { const uint8_t* c = (const uint8_t*)p; b.insert(b.end(), c, c + n); }
+// version 2 = version 1 + the unseen-category bitmap of every feature; written only when a feature has one
+int32_t blob_version(const rgbm_model& m) { for (const Feat& f : m.feats) if (!f.unseen.empty()) return 2; return 1; }
 
-std::vector<uint8_t> serialise(const rgbm_model& m) {
-    std::vector<uint8_t> b;
-    // version 2 = version 1 + the unseen-category bitmap of every feature; written only when a feature has one
-    int32_t ver = 1;
-    for (const Feat& f : m.feats) if (!f.unseen.empty()) ver = 2;
+size_t serialised_size(const rgbm_model& m) {
+    const int32_t ver = blob_version(m);
+    size_t n = 28;
+    for (const Feat& f : m.feats) n += 12 + 4 * (size_t)f.V + (ver == 2 ? 4 + 4 * f.unseen.size() : 0);
+    for (const Tree& t : m.trees) n += 4 + ((size_t)t.L - 1) * 28 + (size_t)t.L * 12;
+    return n;
+}
+
+// the model blob, written straight into the caller's buffer (a 19 200-tree model is 23 MB: no intermediate vector, one pass)
+void serialise_into(const rgbm_model& m, uint8_t* dst) {
+    uint8_t* p = dst;
+    auto put = [&](const void* src, size_t n) { memcpy(p, src, n); p += n; };
+    const int32_t ver = blob_version(m);
     int32_t hdr[7] = {0x4D424752, ver, m.objective, m.num_class, m.K, m.n_iter, m.F};
-    put(b, hdr, sizeof(hdr));
+    put(hdr, sizeof(hdr));
     for (const Feat& f : m.feats) {
-        int32_t h3[3] = {f.n_codes, f.V, f.has_nan}; put(b, h3, sizeof(h3)); put(b, f.ub.data(), 4 * (size_t)f.V);
-        if (ver == 2) { int32_t nw = (int32_t)f.unseen.size(); put(b, &nw, 4); put(b, f.unseen.data(), 4 * (size_t)nw); }
+        int32_t h3[3] = {f.n_codes, f.V, f.has_nan}; put(h3, sizeof(h3)); put(f.ub.data(), 4 * (size_t)f.V);
+        if (ver == 2) { int32_t nw = (int32_t)f.unseen.size(); put(&nw, 4); put(f.unseen.data(), 4 * (size_t)nw); }
     }
     for (const Tree& t : m.trees) {
         const size_t n = (size_t)t.L - 1;
-        put(b, &t.L, 4);
-        put(b, t.feat.data(), 4 * n); put(b, t.theta.data(), 4 * n); put(b, t.dleft.data(), 4 * n);
-        put(b, t.left.data(), 4 * n); put(b, t.right.data(), 4 * n); put(b, t.gain.data(), 8 * n);
-        put(b, t.leaf_value.data(), 8 * (size_t)t.L); put(b, t.leaf_count.data(), 4 * (size_t)t.L);
+        put(&t.L, 4);
+        put(t.feat, 4 * n); put(t.theta, 4 * n); put(t.dleft, 4 * n);
+        put(t.left, 4 * n); put(t.right, 4 * n); put(t.gain, 8 * n);
+        put(t.leaf_value, 8 * (size_t)t.L); put(t.leaf_count, 4 * (size_t)t.L);
     }
-    return b;
 }
 
 }  // namespace
@@ -2004,10 +2108,10 @@ RGBM_EXPORT int rgbm_table_repair_chain(rgbm_table* t, const rgbm_model* const* 
 RGBM_EXPORT int rgbm_model_save(const rgbm_model* m, void* buf, size_t* len) {
     if (!m || !len) return fail(RGBM_ERR_ARG, "rgbm_model_save: bad argument");
     return guarded([&]() {
-        std::vector<uint8_t> b = serialise(*m);
-        if (!buf) { *len = b.size(); return RGBM_OK; }
-        if (*len < b.size()) { *len = b.size(); return fail(RGBM_ERR_ARG, "rgbm_model_save: buffer too small"); }
-        memcpy(buf, b.data(), b.size()); *len = b.size();
+        const size_t need = serialised_size(*m);
+        if (!buf) { *len = need; return RGBM_OK; }
+        if (*len < need) { *len = need; return fail(RGBM_ERR_ARG, "rgbm_model_save: buffer too small"); }
+        serialise_into(*m, (uint8_t*)buf); *len = need;
         return RGBM_OK;
     });
 }
@@ -2043,12 +2147,13 @@ RGBM_EXPORT int rgbm_model_load(const void* buf, size_t len, rgbm_model** out) {
             }
             m->trees.resize((size_t)m->n_iter * m->K);
             for (Tree& t : m->trees) {
-                need(4); memcpy(&t.L, p, 4); p += 4;
-                if (t.L < 1 || t.L > 32767) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad leaf count");
-                const size_t n = (size_t)t.L - 1;
-                need(n * 28 + (size_t)t.L * 12);
-                auto rd32 = [&](std::vector<int32_t>& v, size_t k) { v.resize(k); memcpy(v.data(), p, 4 * k); p += 4 * k; };
-                auto rd64 = [&](std::vector<double>& v, size_t k) { v.resize(k); memcpy(v.data(), p, 8 * k); p += 8 * k; };
+                int32_t L_; need(4); memcpy(&L_, p, 4); p += 4;
+                if (L_ < 1 || L_ > 32767) return fail(RGBM_ERR_FORMAT, "rgbm_model_load: bad leaf count");
+                const size_t n = (size_t)L_ - 1;
+                need(n * 28 + (size_t)L_ * 12);
+                t.alloc(L_);
+                auto rd32 = [&](int32_t* v, size_t k) { memcpy(v, p, 4 * k); p += 4 * k; };
+                auto rd64 = [&](double* v, size_t k) { memcpy(v, p, 8 * k); p += 8 * k; };
                 rd32(t.feat, n); rd32(t.theta, n); rd32(t.dleft, n); rd32(t.left, n); rd32(t.right, n); rd64(t.gain, n);
                 rd64(t.leaf_value, t.L); rd32(t.leaf_count, t.L);
                 for (size_t j = 0; j < n; ++j) {

@@ -194,9 +194,9 @@ class Model:
     def save(self):
         n = C.c_size_t(0)
         _check(lib().rgbm_model_save(self.h, None, C.byref(n)), "rgbm_model_save")
-        buf = np.zeros(max(n.value, 1), np.uint8)
-        _check(lib().rgbm_model_save(self.h, buf.ctypes.data_as(C.c_void_p), C.byref(n)), "rgbm_model_save")
-        return buf[:n.value].tobytes()
+        buf = bytearray(max(n.value, 1))
+        _check(lib().rgbm_model_save(self.h, (C.c_char * len(buf)).from_buffer(buf), C.byref(n)), "rgbm_model_save")
+        return bytes(buf[:n.value]) if n.value != len(buf) else bytes(buf)
 
     @staticmethod
     def load(b):

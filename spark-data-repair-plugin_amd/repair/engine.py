@@ -181,6 +181,7 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     mine = dist.assign_targets(small, ws)[rank]
     t0 = time.perf_counter()
     blobs, stats, shared = {}, [], {}
+    trained = {}     # target -> the model object this rank trained itself (load(save(m)) is m: no need to parse its own blob again)
 
     def one(t, table, fn):
         feats = [c for c in range(n_cols) if c != t]
@@ -194,6 +195,7 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
             res, st = res
             st["target"] = t
             stats.append(st)
+        trained[t] = res
         return res.save()
 
     # This rank's own (target-sharded) models train CONCURRENTLY, with each other and with the row-sharded ones: every training call
@@ -219,10 +221,16 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
             feats = [c for c in range(n_cols) if c != t]
             fits.append((train_tables.get(t, train_table), t, feats, balanced_class_weight(label_counts[t]),
                          model_params(int(n_codes[t]), dict(base_params), continuous=t in y_values), y_values.get(t)))
-        for t, m in zip(batched, engine.train_many(fits)):
+        ms = engine.train_many(fits)
+        for m in ms:
             if isinstance(m, Exception):
                 raise m
-            blobs[t] = m.save()
+        # the blobs of a batch are tens of MB (300 x K trees a model): serialised side by side (ctypes releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, len(ms))) as ex:
+            for t, m, b in zip(batched, ms, ex.map(lambda m: m.save(), ms)):
+                blobs[t] = b
+                trained[t] = m
     mine_single = [t for t in mine if t not in set(batched)]
     pool, futs = None, {}
     if conc > 1 and len(mine_single) + len(big) > 1 and mine_single:
@@ -250,7 +258,14 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     t0 = time.perf_counter()
     all_blobs = dist.exchange_blobs(blobs)
     all_blobs.update(shared)
-    models = [engine.load_model(all_blobs[t]) for t in targets]
+    todo = [t for t in targets if t not in trained]
+    if len(todo) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+            trained.update(zip(todo, ex.map(lambda t: engine.load_model(all_blobs[t]), todo)))
+    else:
+        trained.update((t, engine.load_model(all_blobs[t])) for t in todo)
+    models = [trained[t] for t in targets]
     t_xchg = time.perf_counter() - t0
     # data-parallel chained inference on this rank's row shard
     t0 = time.perf_counter()
