@@ -1881,6 +1881,31 @@ static void upload_pinned(void* dst, const void* src, size_t bytes) {
     HIPCHK(hipStreamSynchronize(R.s));
 }
 
+// page-locked staging of the chain's outputs (two blocks: model t's labels / probabilities leave the device and are copied into the
+// caller's arrays while model t + 1 is scored); kept for the life of the process, at most 256 MiB a block
+namespace {
+struct ChainStage {
+    std::mutex mu; void* p[2] = {nullptr, nullptr}; size_t cap = 0; int device = -1;
+    static constexpr size_t KEEP_MAX = (size_t)256 << 20;
+    bool get(size_t bytes, int dev) {
+        if (bytes == 0 || bytes > KEEP_MAX || getenv("RGBM_NO_PIN") != nullptr) return false;
+        if (p[0] && cap >= bytes && device == dev) return true;
+        for (int i = 0; i < 2; ++i) if (p[i]) { (void)hipHostFree(p[i]); p[i] = nullptr; }
+        cap = 0;
+        const size_t want = std::min(KEEP_MAX, bytes + bytes / 8);
+        if (hipHostMalloc(&p[0], want, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&p[1], want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int i = 0; i < 2; ++i) if (p[i]) { (void)hipHostFree(p[i]); p[i] = nullptr; }
+            return false;
+        }
+        cap = want; device = dev;
+        return true;
+    }
+};
+ChainStage& chain_stage() { static ChainStage* c = new ChainStage(); return *c; }
+struct ThreadJoiner { std::vector<std::thread> th; ~ThreadJoiner() { for (auto& t : th) if (t.joinable()) t.join(); } };
+}  // namespace
+
 // =============================================================================================
 // C-ABI
 // =============================================================================================
@@ -2018,7 +2043,8 @@ static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* tar
                         const int32_t* class_code, const int32_t* class_off, int32_t* d_codes, long long Ntab, long long row0, long long n,
                         int device, hipStream_t s, int32_t* out_label, double* out_prob) {
     using namespace rg;
-    DevBuf<int32_t> d_label(n); DevBuf<double> d_top(n);
+    for (int t = 0; t < T; ++t)
+        if (feat_off[t + 1] - feat_off[t] != models[t]->F) throw std::invalid_argument("chain: feature list length differs from the model's feature count");
     PredictScratch scratch;
     {   // size the scratch once for the largest model of the chain
         size_t mr = 0, mk = 0;
@@ -2026,37 +2052,49 @@ static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* tar
         scratch.rec.alloc(mr * (size_t)n); scratch.raw.alloc(mk * (size_t)n);
     }
     const bool timing = getenv("RGBM_TIMING") != nullptr;
-    double t_model = 0, t_score = 0, t_fill = 0, t_copy = 0;
+    double t_score = 0, t_fill = 0, t_copy = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    {   // predictor tables of all the chain's models, built side by side (host work + small uploads, ~5 ms a model)
-        double t0 = now();
-        std::vector<rgbm_model*> todo;
-        for (int t = 0; t < T; ++t) if (std::find(todo.begin(), todo.end(), models[t]) == todo.end()) todo.push_back(models[t]);
+    const double t_begin = now();
+    // ---- outputs: double-buffered on the device and in page-locked host memory when the staging blocks are free
+    ChainStage& CS = chain_stage();
+    std::unique_lock<std::mutex> cs_lock(CS.mu, std::try_to_lock);
+    const size_t lab_bytes = ((size_t)n * sizeof(int32_t) + 255) & ~(size_t)255, out_bytes = lab_bytes + (size_t)n * sizeof(double);
+    const bool staged = (out_label || out_prob) && T > 1 && cs_lock.owns_lock() && CS.get(out_bytes, device);
+    DevBuf<int32_t> d_label[2]; DevBuf<double> d_top[2];
+    for (int b = 0; b < (staged ? 2 : 1); ++b) { d_label[b].alloc(n); d_top[b].alloc(n); }
+    StreamGuard copy_stream;
+    hipEvent_t e_copied[2] = {nullptr, nullptr};
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } evg{e_copied};
+    if (staged) for (int b = 0; b < 2; ++b) HIPCHK(hipEventCreateWithFlags(&e_copied[b], hipEventDisableTiming));
+    std::atomic<int> copy_err{0};
+    std::thread helper[2];
+    struct HelperJoin { std::thread* h; ~HelperJoin() { for (int i = 0; i < 2; ++i) if (h[i].joinable()) h[i].join(); } } hj{helper};
+    // ---- predictor tables of the chain's models: built in the background, in chain order, on a few host threads (host work + small
+    // uploads, 1-25 ms a model); predict_device -> device_model waits on the model's mutex for a build in flight, or builds it itself
+    std::vector<rgbm_model*> todo;
+    for (int t = 0; t < T; ++t) if (std::find(todo.begin(), todo.end(), models[t]) == todo.end()) todo.push_back(models[t]);
+    std::atomic<size_t> next{0}; std::mutex emu; std::exception_ptr build_err;
+    ThreadJoiner builders;
+    {
         const size_t nth = std::min<size_t>(std::min<size_t>(todo.size(), 16), std::max(1u, std::thread::hardware_concurrency()));
-        if (nth <= 1) { for (rgbm_model* m : todo) device_model(m, device, s); }
-        else {
-            std::atomic<size_t> next{0}; std::mutex emu; std::exception_ptr err;
-            auto work = [&]() {
-                try {
-                    use_device(device);
-                    StreamGuard own;
-                    for (size_t j = next.fetch_add(1); j < todo.size(); j = next.fetch_add(1)) device_model(todo[j], device, own.s);
-                } catch (...) { std::lock_guard<std::mutex> lk(emu); if (!err) err = std::current_exception(); }
-            };
-            std::vector<std::thread> th;
-            for (size_t q = 0; q < nth; ++q) th.emplace_back(work);
-            for (auto& x : th) x.join();
-            if (err) std::rethrow_exception(err);
-        }
-        t_model = now() - t0;
+        auto work = [&]() {
+            try {
+                use_device(device);
+                StreamGuard own;
+                for (size_t j = next.fetch_add(1); j < todo.size(); j = next.fetch_add(1)) device_model(todo[j], device, own.s);
+            } catch (...) { std::lock_guard<std::mutex> lk(emu); if (!build_err) build_err = std::current_exception(); }
+        };
+        if (todo.size() > 1) for (size_t q = 0; q < nth; ++q) builders.th.emplace_back(work);
     }
     for (int t = 0; t < T; ++t) {
         rgbm_model* m = models[t];
-        const int F = feat_off[t + 1] - feat_off[t];
-        if (F != m->F) throw std::invalid_argument("chain: feature list length differs from the model's feature count");
+        const int F = m->F, b = staged ? (t & 1) : 0;
         double t1 = now();
+        if (helper[b].joinable()) helper[b].join();                  // model t - 2 has left d_label[b] / d_top[b] and the staging block b
+        if (copy_err.load()) throw std::runtime_error("chain: copy of the repaired cells to the host failed");
+        t_copy += now() - t1; t1 = now();
         DevBuf<int32_t> d_fc(F); d_fc.upload(feat_cols + feat_off[t], F, s);
-        predict_device(m, device, s, d_codes, Ntab, row0, n, d_fc.p, nullptr, d_label.p, d_top.p, &scratch);
+        predict_device(m, device, s, d_codes, Ntab, row0, n, d_fc.p, nullptr, d_label[b].p, d_top[b].p, &scratch);
         double t2 = now(); t_score += t2 - t1;
         if (m->objective != 2) {
             int ncc = class_off ? class_off[t + 1] - class_off[t] : m->num_class;
@@ -2064,15 +2102,41 @@ static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* tar
             std::vector<int32_t> cc(std::max(ncc, 1), 0);
             for (int i = 0; i < ncc; ++i) cc[i] = class_code ? class_code[class_off[t] + i] : i;
             d_cc.upload(cc.data(), cc.size(), s);
-            hipLaunchKernelGGL(k_fill_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes + (long long)target_col[t] * Ntab + row0, n, d_label.p, d_cc.p, ncc);
+            hipLaunchKernelGGL(k_fill_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_codes + (long long)target_col[t] * Ntab + row0, n, d_label[b].p, d_cc.p, ncc);
             HIPCHK(hipStreamSynchronize(s));
         }
         double t3 = now(); t_fill += t3 - t2;
-        if (out_label) HIPCHK(hipMemcpy(out_label + (size_t)t * n, d_label.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (out_prob) HIPCHK(hipMemcpy(out_prob + (size_t)t * n, d_top.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        if (staged) {
+            char* pin = (char*)CS.p[b];
+            if (out_label) HIPCHK(hipMemcpyAsync(pin, d_label[b].p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream.s));
+            if (out_prob) HIPCHK(hipMemcpyAsync(pin + lab_bytes, d_top[b].p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, copy_stream.s));
+            HIPCHK(hipEventRecord(e_copied[b], copy_stream.s));
+            int32_t* ol = out_label ? out_label + (size_t)t * n : nullptr; double* op = out_prob ? out_prob + (size_t)t * n : nullptr;
+            hipEvent_t ev = e_copied[b];
+            helper[b] = std::thread([=, &copy_err]() {
+                if (hipEventSynchronize(ev) != hipSuccess) { copy_err.store(1); return; }
+                std::thread second;
+                if (ol && op) second = std::thread([=]() { memcpy(op, pin + lab_bytes, (size_t)n * sizeof(double)); });
+                else if (op) memcpy(op, pin + lab_bytes, (size_t)n * sizeof(double));
+                if (ol) memcpy(ol, pin, (size_t)n * sizeof(int32_t));
+                if (second.joinable()) second.join();
+            });
+        } else {
+            if (out_label) HIPCHK(hipMemcpy(out_label + (size_t)t * n, d_label[b].p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (out_prob) HIPCHK(hipMemcpy(out_prob + (size_t)t * n, d_top[b].p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        }
         t_copy += now() - t3;
     }
-    if (timing) fprintf(stderr, "[rgbm] chain of %d models over %lld rows: tables %.1f ms, score %.1f ms, fill %.1f ms, copy out %.1f ms\n", T, n, t_model * 1e3, t_score * 1e3, t_fill * 1e3, t_copy * 1e3);
+    {
+        const double t4 = now();
+        for (int b = 0; b < 2; ++b) if (helper[b].joinable()) helper[b].join();
+        t_copy += now() - t4;
+        if (copy_err.load()) throw std::runtime_error("chain: copy of the repaired cells to the host failed");
+    }
+    for (auto& x : builders.th) if (x.joinable()) x.join();
+    if (build_err) std::rethrow_exception(build_err);
+    if (timing) fprintf(stderr, "[rgbm] chain of %d models over %lld rows: %.1f ms (score incl. waiting for tables %.1f ms, fill %.1f ms, copy out not hidden %.1f ms, %s)\n",
+                        T, n, (now() - t_begin) * 1e3, t_score * 1e3, t_fill * 1e3, t_copy * 1e3, staged ? "staged" : "direct");
     return RGBM_OK;
 }
 
