@@ -414,7 +414,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // level passes are sized for, default 8), RGBM_JOINT_ROOT=0, RGBM_MT_ACC2=0 (tables of 17..32 features: one level pass per 16-feature chunk
 // instead of one pass that accumulates both).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/32 live rows are swept through their node ids */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -427,6 +427,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_ACC2")) w.mt_acc2 = atoi(e) != 0;
     if (const char* e = getenv("RGBM_MT_THREADS")) w.mt_threads = atoi(e) == 768 ? 768 : 1024;
     if (const char* e = getenv("RGBM_MT_SPEC")) w.mt_spec = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("RGBM_MT_SPARSE")) w.mt_sparse = atoi(e) != 0;
     w.timing = getenv("RGBM_TIMING") != nullptr;
     return w;
 }
@@ -1012,7 +1013,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         ll.xcd_blocks = 0; ll.gx = mt_gx[level]; ll.max_built = 1 << (level - 1);
         for (const MtLaunch& L : mt_plan[level]) {
             LevelConst l1 = ll;
-            l1.mt_T = L.T; l1.mt_G = L.G; l1.mt_ch = L.ch; l1.mt_slot0 = L.slot0; l1.mt_nslots = L.nslots; l1.mt_route = L.route;
+            l1.mt_T = L.T; l1.mt_G = L.G; l1.mt_ch = L.ch; l1.mt_slot0 = L.slot0; l1.mt_nslots = L.nslots; l1.mt_route = L.route; l1.mt_sparse = sw.mt_sparse ? 1 : 0;
             const dim3 grid((unsigned)L.G * (unsigned)L.gx);
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {

@@ -71,7 +71,7 @@ struct SNode {   // speculative node of one class tree
 };
 
 struct LvPlan {   // per class tree; rewritten by k_level_init / k_level_plan
-    int32_t n_nodes, lvl_first, lvl_end, n_exp, n_built, pad0, pad1, pad2, pad3, done, error, child_first, n_hslots, pad4;
+    int32_t n_nodes, lvl_first, lvl_end, n_exp, n_built, live_rows /* rows of the expanded parents (k_level_plan) */, pad1, pad2, pad3, done, error, child_first, n_hslots, pad4;
     long long n_in;
     uint8_t exp[LV_MAX_EXP];           // expanded parents (ascending node id)
     uint8_t built_is_left[LV_MAX_EXP];
@@ -87,6 +87,7 @@ struct LevelConst {
     int32_t xcd_blocks;          // root pass: 1-D grid of K * gx blocks, contiguous row blocks, all class trees of a row block on one XCD
     // k_level_mt launch: class trees per workgroup, tree groups, chunk whose features are accumulated, built-slot window, routing?
     int32_t mt_T, mt_G, mt_ch, mt_slot0, mt_nslots, mt_route;
+    int32_t mt_sparse, mt_pad;   // 1: class trees with few live rows are swept through their node ids (k_level_mt, plain single-chunk pass)
     long long N, NS, NG;         // rows; row stride of the node-id arrays and of the (g, h) arrays (both N rounded up to a whole wave tile of 256 rows)
     double sg, sh;               // 2^e_g, 2^e_h: float32 (g, h) -> fixed point (fx_from_f32)
 };
@@ -123,8 +124,16 @@ constexpr int LV_ROOT_FIXED = 256;
 // bytes k_level_mt needs besides the histogram: tree table | node -> tree map | scalars | per-feature flush table (32 features) | ring
 // heads / tails / done flags | packed
 // tree entries | route entries | built-row counters | per-wave rings (record(s) 16 / 32 B + (g, h) 8 B + slot 2 B per entry) | slack
+constexpr int MT_SP_RING = 128;              // entries of a wave's ring of live row groups (sparse sweep)
+#if !defined(MT_SPARSE_DIV_N)
+#define MT_SPARSE_DIV_N 8
+#endif
+// a class tree is swept sparsely when its live rows are fewer than 1 in MT_SPARSE_DIV: the sweep costs ~25 instructions per 256 rows for the
+// filter + one dense step (~430 with the gathers) per 64 groups of 4 rows that hold a live row, against ~330 per 256 rows tile by tile:
+// break-even near 18 % live rows
+constexpr long long MT_SPARSE_DIV = MT_SPARSE_DIV_N;
 __host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2, bool spec = false) {
-    return (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
+    return ((!acc2 && !spec) ? (long long)MT_MAX_T * 8 + (long long)(threads / 64) * MT_SP_RING * 4 : 0) + (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
            (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * MT_RING * ((acc2 ? 32 : 16) + 8 + 2) + 256;     // (consumer waves have no ring)
 }
 
@@ -297,6 +306,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     constexpr int NCONS = SPEC ? MT_CONSUMERS : 0, NPROD = WAVES - NCONS;     // waves that walk the rows / waves that only run batches
     constexpr int NACC = ACC2 ? 2 : 1;                     // chunks accumulated by this launch
     constexpr int NRINGS = SPEC ? NPROD : WAVES;
+    // SPARSE: class trees whose expanded parents hold a few per cent of the rows (the deep levels of many-class targets: 1.3 % at level 6
+    // of the K = 64 target, profiles/r04z_*) are not walked tile by tile; see "sparse sweep" below
+    constexpr bool SPARSE = (NCHR == 1) && !ACC2 && !SPEC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned id = blockIdx.x;
     const int xl = (int)(id & 7u), bslot = (int)(id >> 3);
@@ -335,6 +347,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + NRINGS * MT_RING);        // [waves][MT_RING]
     size_t off = reinterpret_cast<unsigned char*>(ring_li_all + NRINGS * MT_RING) - smem;
     off = (off + 15) & ~(size_t)15;
+    unsigned long long* xmask = reinterpret_cast<unsigned long long*>(smem + off);            // [MT_MAX_T] sparse sweep: bit i = node base + i of the class tree is live
+    uint32_t* sp_ring_all = reinterpret_cast<uint32_t*>(xmask + MT_MAX_T);                      // [waves][MT_SP_RING] sparse sweep: row groups with a live row
+    if (!ACC2 && !SPEC) off += (size_t)MT_MAX_T * 8 + (size_t)WAVES * MT_SP_RING * 4;           // (reserved for every plain pass: mt_fixed_bytes)
     unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem + off);     // [total][spn] gradient sums, then [total][spn] hessian sums (see k_level_root)
     const long long avail = (long long)c.lds_bytes - (long long)off;
 
@@ -353,6 +368,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             if (nb > c.mt_nslots) nb = c.mt_nslots;
             t.nb = nb < 0 ? 0 : nb;
         }
+        // sparse: a live class tree whose expanded parents hold less than 1/MT_SPARSE_DIV of its rows (and whose table fits a 64-bit node mask)
+        bool sparse_t = false;
+        if (SPARSE && lane < nk && t.live && t.nlev <= 64) {
+            const LvPlan* pp = &plan[k0 + lane];
+            const long long lr = route ? (long long)pp->live_rows : 0ll;     // (later launches of a level: not sparse -- they look for the built children)
+            sparse_t = route && lr * MT_SPARSE_DIV < pp->n_in && c.mt_sparse != 0;
+        }
         int inc_nb = t.nb, inc_rt = t.nlev;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(inc_nb, o), b2 = __shfl_up(inc_rt, o); if (lane >= o) { inc_nb += a; inc_rt += b2; } }
@@ -363,9 +385,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         // not, the pass would silently drop rows: the training call fails instead (err_flag bit 1)
         const bool ok = total <= MT_MAX_NODES && rt_total <= MT_MAX_RT;
         if (!ok) { t.live = 0; t.nb = 0; t.nlev = 0; if (lane == 0) atomicOr(err_flag, 2); }
-        if (lane < nk) ti[lane] = t;
-        tpk[lane] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
+        // the workgroup's class trees in LDS: the dense ones first, then the sparse ones (the row loop walks [0, nkd), the sparse sweep [nkd, nk))
+        const unsigned long long dmask = __ballot(lane < nk && !sparse_t), smask = __ballot(lane < nk && sparse_t);
+        const int nkd_ = __popcll(dmask);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int pos = lane >= nk ? lane : (sparse_t ? nkd_ + __popcll(smask & below) : __popcll(dmask & below));
+        if (lane < nk) ti[pos] = t;
+        tpk[pos] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
         if (lane < 2) tpk[64 + lane] = make_uint2(0u, 0u);
+        if (SPARSE) xmask[lane] = 0ull;
         if (lane == 0) {
             // replication: the largest uniform shift whose histograms fit
             int s = LV_MAX_Q;
@@ -373,14 +401,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             while (s > 0 && (long long)tot * (lv_slots(fm, nfeat, s) + (ACC2 ? lv_slots(fm1, nfeat1, s) : 0)) * 16 > avail) --s;
             const int spn0 = lv_slots(fm, nfeat, s) + (ACC2 ? lv_slots(fm1, nfeat1, s) : 0);
             if ((long long)tot * spn0 * 16 > avail) atomicOr(err_flag, 2);          // (the host's window sizing guarantees the plain layout fits)
-            scal[0] = tot; scal[1] = s; scal[2] = spn0; scal[3] = (ok && livem != 0ull) ? 1 : 0;
+            scal[0] = tot; scal[1] = s; scal[2] = spn0; scal[3] = ((ok && livem != 0ull) ? 1 : 0) | (ok ? nkd_ : nk) << 8;
         }
     }
     __syncthreads();
-    if (!scal[3]) return;
+    if (!(scal[3] & 1)) return;
     // wave-uniform from here on: in SGPRs, so that everything derived from them (shifts, strides) is scalar as well
     const int total = __builtin_amdgcn_readfirstlane(scal[0]), s = __builtin_amdgcn_readfirstlane(scal[1]), spn = __builtin_amdgcn_readfirstlane(scal[2]);
     if (!route && total == 0) return;
+    const int nkd = SPARSE ? __builtin_amdgcn_readfirstlane(scal[3] >> 8) : nk;       // dense class trees: [0, nkd)
     for (int kk = 0; kk < nk; ++kk) {
         const MtTree t = ti[kk];
         const LvPlan* pp = &plan[t.k];
@@ -407,6 +436,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                     else { offb = 0u; thr = theta1 - 1u; }
                     e = make_uint2((w0 & 0xFFu) | thr << 8 | offb << 16 | 1u << 24,
                                    (w1 & 0xFFFFu) | (lb ? (uint32_t)(t.slot0 + ls) : 0xFFu) << 16 | (rbb ? (uint32_t)(t.slot0 + rs) : 0xFFu) << 24);
+                    if (SPARSE && kk >= nkd && i < 64) atomicOr(&xmask[kk], 1ull << i);
                 } else e = make_uint2(0u, (uint32_t)n | (uint32_t)n << 8 | 0xFFFF0000u);
             } else {
                 // children are numbered child_first + 2 ei (left), + 1 (right); one of the two is built, in slot ei
@@ -461,10 +491,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     const unsigned spn8 = (unsigned)spn * 8u;
     // lane kk keeps the packed entry of class tree kk: the row loop fetches it with a readlane instead of an LDS read per step
     const uint2 tpk_v = tpk[lane];
-    auto tree_entry = [&](int kk) __attribute__((always_inline)) -> uint2 {
+    auto tree_entry = [&](int kk) __attribute__((always_inline)) -> uint2 {       // (of the trees the row loop walks: the dense ones in a plain pass)
         const int kc = kk < 64 ? kk : 63;
         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.x, kc), y = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.y, kc);
-        return kk < nk ? make_uint2(x, y) : make_uint2(0u, 0u);
+        return kk < (SPARSE ? nkd : nk) ? make_uint2(x, y) : make_uint2(0u, 0u);
     };
 
     // one FULL (or final, partial) wave of histogram updates from the ring
@@ -580,7 +610,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     // which the other class tree groups of the row block re-read -- out of the XCD's L2).  The rows of both arrays are padded to whole
     // wave tiles (NS, NG), so the loads need neither a bounds check nor an alignment case: straight-line code, exact vmcnt bookkeeping.
     auto load_tree = [&](long long wt, int kk, uint32_t& n4, float4& g0, float4& g1) __attribute__((always_inline)) {
-        const long long row0 = wt * MT_WT_ROWS + lane * 4, kq = k0 + kk;
+        // (the workgroup's class trees are not in class order when some of them are sparse: the class comes from the tree's packed entry)
+        const long long row0 = wt * MT_WT_ROWS + lane * 4, kq = SPARSE ? (long long)(tree_entry(kk).y >> 16) : (long long)(k0 + kk);
         n4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(node + kq * NS + row0));
         const float2* gp = gh + kq * NG + row0;
         const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp)), b2 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp + 2));
@@ -607,10 +638,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         }
     };
     // route the four rows, append the built ones to the ring (and, in the plain pass, run the batches)
-    auto stage_c = [&](long long wt, const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t bagmask, uint32_t n4, const float4 g0, const float4 g1,
+    auto stage_c = [&](const long long row0 /* first of the lane's four rows */, const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t bagmask, uint32_t n4, const float4 g0, const float4 g1,
                        const uint2 (&e)[4], uint32_t inm, const uint2 tq) __attribute__((always_inline)) {
         if (__ballot(inm != 0u) == 0ull) return;               // no row of this wave tile sits in a node of the level (or the tree is finished)
-        const long long row0 = wt * MT_WT_ROWS + lane * 4;
         uint32_t out4 = n4;
         const float gg[4] = {g0.x, g0.z, g1.x, g1.z}, hh[4] = {g0.y, g0.w, g1.y, g1.w};
 #pragma unroll
@@ -701,7 +731,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                 load_rec(wt_b, rn, r1n, bag_n);                                        // stage R
                 load_tree(wt_a, kk_a, n4_c, gc0, gc1);                                 // stage A
                 lookup(n4_b, tree_entry(kk_b), row_mask(wt_b), e_b, in_b);             // stage B
-                stage_c(wt_c, ra, r1, bag_c, n4_a, ga0, ga1, e_a, in_a, tree_entry(kk_c));   // stage C
+                stage_c(wt_c * MT_WT_ROWS + lane * 4, ra, r1, bag_c, n4_a, ga0, ga1, e_a, in_a, tree_entry(kk_c));   // stage C
                 // rotate
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ra[j] = rn[j]; r1[j] = r1n[j]; e_a[j] = e_b[j]; }
@@ -713,6 +743,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         }
     } else {
         // ---- plain pass: per wave tile, a pipeline over the class trees of the workgroup (node ids, g, h requested two trees ahead)
+        const int nkw = SPARSE ? nkd : nk;          // class trees walked tile by tile
+        if (nkw > 0)
         for (long long wt = wt_lo + wave; wt < wt_hi; wt += WAVES) {
             uint4 ra[4], r1[4]; uint32_t bagmask;
             load_rec(wt, ra, r1, bagmask);
@@ -721,20 +753,91 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             ga0 = ga1 = gb0 = gb1 = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 tq_a = tree_entry(0), tq_b = tree_entry(1);
             load_tree(wt, 0, n4_a, ga0, ga1);
-            if (nk > 1) load_tree(wt, 1, n4_b, gb0, gb1);
+            if (nkw > 1) load_tree(wt, 1, n4_b, gb0, gb1);
             uint2 e_a[4]; uint32_t in_a = 0u;
             lookup(n4_a, tq_a, rowmask, e_a, in_a);
-            for (int kk = 0; kk < nk; ++kk) {
+            for (int kk = 0; kk < nkw; ++kk) {
                 // ---- rotate the pipeline
                 const uint32_t n4 = n4_a; const float4 g0 = ga0, g1 = ga1;
                 uint2 e[4]; const uint32_t inm = in_a; const uint2 tq = tq_a;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) e[j] = e_a[j];
                 n4_a = n4_b; ga0 = gb0; ga1 = gb1; tq_a = tq_b;
-                if (kk + 2 < nk) load_tree(wt, kk + 2, n4_b, gb0, gb1); else n4_b = 0xFFFFFFFFu;     // stage A
+                if (kk + 2 < nkw) load_tree(wt, kk + 2, n4_b, gb0, gb1); else n4_b = 0xFFFFFFFFu;     // stage A
                 tq_b = tree_entry(kk + 2);
                 lookup(n4_a, tq_a, rowmask, e_a, in_a);                 // stage B (reads rt only: a table nobody writes during the row loop)
-                stage_c(wt, ra, r1, bagmask, n4, g0, g1, e, inm, tq);   // stage C
+                stage_c(wt * MT_WT_ROWS + lane * 4, ra, r1, bagmask, n4, g0, g1, e, inm, tq);   // stage C
+            }
+        }
+        // ---- sparse sweep: the class trees [nkd, nk) of the workgroup, whose expanded parents hold < 1/MT_SPARSE_DIV of the rows.  Per class tree the wave
+        // streams ONLY the node ids of its rows (1 B per row: sixteen rows per lane and step), tests them against the tree's 64-bit mask of
+        // live nodes and appends the 4-row groups that hold a live row to a small ring; 64 such groups are one dense step: every lane
+        // fetches its group's records, node ids and (g, h) and goes through the same lookup + route + append code as the row loop.  A pass
+        // over a class tree with 1 % live rows costs its node-id stream instead of records + (g, h) + ~330 instructions per 256 rows.
+        if (SPARSE && nkd < nk) {
+            uint32_t* sp_ring = sp_ring_all + wave * MT_SP_RING;
+            const long long row_lo = wt_lo * MT_WT_ROWS, row_hi = (wt_hi * MT_WT_ROWS < N) ? wt_hi * MT_WT_ROWS : N;
+            const long long nst = (wt_hi * MT_WT_ROWS - row_lo + 1023) / 1024;        // super tiles of 1024 rows (the block's rows are whole wave tiles)
+            for (int kk = nkd; kk < nk; ++kk) {
+                const uint32_t tq0 = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.x, kk < 64 ? kk : 63), tq1 = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.y, kk < 64 ? kk : 63);
+                const uint2 tq = make_uint2(tq0, tq1);
+                const uint32_t base = tq0 & 0xFFu, nlev = (tq0 >> 8) & 0x1FFu;
+                const unsigned long long xm_v = xmask[kk];
+                const unsigned long long xm = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xm_v) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xm_v >> 32)) << 32;
+                const uint8_t* nd_k = node + (long long)(tq1 >> 16) * NS;
+                const float2* gh_k = gh + (long long)(tq1 >> 16) * NG;
+                int sp_head = 0, sp_cnt = 0;                          // wave-uniform
+                auto sparse_batch = [&](int nb) __attribute__((always_inline)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    const bool on = lane < nb;
+                    const uint32_t g = sp_ring[(sp_head + lane) & (MT_SP_RING - 1)];
+                    const long long row0 = on ? (long long)g * 4 : row_lo;
+                    uint4 ra[4], r1[4]; uint32_t bagmask = BAG ? 0u : 0xFu, rowmask = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        long long rr = row0 + j; if (rr >= N) rr = N - 1;
+                        ra[j] = rec_acc[rr]; r1[j] = make_uint4(0, 0, 0, 0);
+                        if (BAG) bagmask |= (inbag[rr] ? 1u : 0u) << j;
+                        if (on && row0 + j < N) rowmask |= 1u << j;
+                    }
+                    const uint32_t n4 = *reinterpret_cast<const uint32_t*>(nd_k + row0);
+                    const float4 g0 = *reinterpret_cast<const float4*>(gh_k + row0), g1 = *reinterpret_cast<const float4*>(gh_k + row0 + 2);
+                    uint2 e[4]; uint32_t inm = 0u;
+                    lookup(n4, tq, rowmask, e, inm);
+                    stage_c(row0, ra, r1, bagmask, n4, g0, g1, e, inm, tq);
+                    sp_head = (sp_head + nb) & (MT_SP_RING - 1); sp_cnt -= nb;
+                };
+                auto load16 = [&](long long st) __attribute__((always_inline)) -> uint4 {
+                    const long long r16 = row_lo + st * 1024 + lane * 16;
+                    uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                    if (st < nst && r16 < row_hi) v = *reinterpret_cast<const uint4*>(nd_k + r16);      // (rows are padded to whole wave tiles: NS)
+                    return v;
+                };
+                uint4 n16 = load16(wave);
+                for (long long st = wave; st < nst; st += WAVES) {
+                    const long long r16 = row_lo + st * 1024 + lane * 16;          // this lane's sixteen rows
+                    const uint4 nxt = load16(st + WAVES);                          // (requested one step ahead)
+                    const long long left = row_hi - r16;
+                    const int nvalid = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+                    const uint32_t w4[4] = {n16.x, n16.y, n16.z, n16.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        bool hit = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t idx = ((w4[d] >> (8 * j)) & 0xFFu) - base;
+                            hit = hit || (idx < nlev && ((xm >> (idx & 63u)) & 1ull) != 0ull && d * 4 + j < nvalid);
+                        }
+                        const unsigned long long m = __ballot(hit);
+                        if (m != 0ull) {                                  // uniform
+                            if (hit) sp_ring[(sp_head + sp_cnt + (int)__popcll(m & lane_lt)) & (MT_SP_RING - 1)] = (uint32_t)((r16 + d * 4) >> 2);
+                            sp_cnt += (int)__popcll(m);
+                            if (sp_cnt >= 64) sparse_batch(64);
+                        }
+                    }
+                    n16 = nxt;
+                }
+                while (sp_cnt > 0) sparse_batch(sp_cnt < 64 ? sp_cnt : 64);
             }
         }
     }
@@ -1028,7 +1131,13 @@ __global__ __launch_bounds__(256) void k_level_plan(LvPlan* __restrict__ plan, S
         pp->route1[n] = (uint32_t)l | (uint32_t)r << 8 | ls << 16 | rs << 24;
     }
     const int n_built = with_hist ? n_exp : 0;
+    // rows the pass of this level has to touch: those of the expanded parents (k_level_mt sweeps a class tree whose share is small
+    // through its node ids only)
+    long long live = expand ? (long long)nk[first + lane].count : 0ll;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) live += __shfl_xor(live, o);
     if (lane == 0) {
+        pp->live_rows = (int32_t)(live > 0x7FFFFFFFll ? 0x7FFFFFFFll : live);
         pp->n_exp = n_exp; pp->n_built = n_built;
         pp->child_first = child_first; pp->n_nodes = child_first + 2 * n_exp;
         pp->lvl_first = child_first; pp->lvl_end = child_first + 2 * n_exp;

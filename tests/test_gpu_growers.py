@@ -41,7 +41,7 @@ class _env:
 # windows per level) with odd row-block counts; the leaf-wise grower
 VARIANTS = [("level", dict(RGBM_GROWER="level")),
             ("level, 1 class tree per workgroup", dict(RGBM_GROWER="level", RGBM_MT_TREES=1)),
-            ("level, 2 class trees, small LDS, 24 row blocks", dict(RGBM_GROWER="level", RGBM_MT_TREES=2, RGBM_LV_LDS=90000, RGBM_MT_BLOCKS=24, RGBM_LV_BLOCKS=24)),
+            ("level, 2 class trees, small LDS, 24 row blocks", dict(RGBM_GROWER="level", RGBM_MT_TREES=2, RGBM_LV_LDS=99000, RGBM_MT_BLOCKS=24, RGBM_LV_BLOCKS=24)),
             ("leafwise", dict(RGBM_GROWER="leafwise"))]
 
 
@@ -203,7 +203,7 @@ def test_random_configurations_stress_wide_and_sampled():
             assert mo.save() == mg.save(), "trial %d differs (%s): n=%d F=%d %r" % (trial, g, n, F, kw)
 
 
-@pytest.mark.parametrize("lds,trees,blocks", [(None, None, None), (90000, None, 16), (88000, 1, 8), (None, 3, 40)])
+@pytest.mark.parametrize("lds,trees,blocks", [(None, None, None), (99000, None, 16), (97000, 1, 8), (None, 3, 40)])
 def test_level_pass_shapes_stay_bit_exact(lds, trees, blocks):
     """Binary (the largest gradients), K = 24 and a two-chunk regression table through several shapes of the level pass: class trees
     per workgroup, LDS pool (built-slot windows), row blocks."""
@@ -286,3 +286,23 @@ def test_regression_with_thousands_of_distinct_targets_and_small_max_bin():
         mo = O.train(X, [700, 40, 9, 300], y, 3000, y_value=vals, **kw)
         mg = N.train(X, [700, 40, 9, 300], y, 3000, y_value=vals, **kw)
         assert mo.save() == mg.save(), "max_bin=%d" % max_bin
+
+
+@pytest.mark.parametrize("rows,cols,tgt", [(600, 4, 2), (40000, 11, 10)])
+def test_sparse_sweep_of_the_level_pass_changes_nothing(rows, cols, tgt, monkeypatch):
+    """k_level_mt sweeps class trees whose expanded parents hold few rows through their node ids only (RGBM_MT_SPARSE, default on):
+    same routing, same built rows -- the model bytes (leaf counts included) must not depend on it.  A many-class target (deep levels
+    with a few per cent live rows next to dense class trees in the same workgroup) and a tiny table."""
+    from repair import _native as N
+    from tests.synth import make_table, balanced_weights
+    dirty, clean, cards = make_table(rows, cols, seed=29)
+    feats = [c for c in range(cols) if c != tgt]
+    r = dirty[tgt] >= 0
+    X = np.ascontiguousarray(dirty[feats][:, r]); y = dirty[tgt][r]; K = int(cards[tgt])
+    for kw in (dict(), dict(bagging_fraction=0.7, bagging_freq=1), dict(num_leaves=60, min_data_in_leaf=3)):
+        blobs = []
+        for v in ("0", "1"):
+            monkeypatch.setenv("RGBM_MT_SPARSE", v)
+            blobs.append(N.train(X, cards[feats], y, K, class_weight=balanced_weights(y, K), objective=0 if K == 2 else 1, num_class=max(K, 2),
+                                 n_estimators=14, learning_rate=0.2, **kw).save())
+        assert blobs[0] == blobs[1], kw

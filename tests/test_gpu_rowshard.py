@@ -22,7 +22,7 @@ def level_pass_kind(request, monkeypatch):
     launches per level)."""
     if request.param == "one_tree_small_lds":
         monkeypatch.setenv("RGBM_MT_TREES", "1")
-        monkeypatch.setenv("RGBM_LV_LDS", "90000")
+        monkeypatch.setenv("RGBM_LV_LDS", "99000")
     return request.param
 
 
