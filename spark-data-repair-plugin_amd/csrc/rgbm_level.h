@@ -124,16 +124,15 @@ constexpr int LV_ROOT_FIXED = 256;
 // bytes k_level_mt needs besides the histogram: tree table | node -> tree map | scalars | per-feature flush table (32 features) | ring
 // heads / tails / done flags | packed
 // tree entries | route entries | built-row counters | per-wave rings (record(s) 16 / 32 B + (g, h) 8 B + slot 2 B per entry) | slack
-constexpr int MT_SP_RING = 128;              // entries of a wave's ring of live row groups (sparse sweep)
 #if !defined(MT_SPARSE_DIV_N)
-#define MT_SPARSE_DIV_N 8
+#define MT_SPARSE_DIV_N 16
 #endif
 // a class tree is swept sparsely when its live rows are fewer than 1 in MT_SPARSE_DIV: the sweep costs ~25 instructions per 256 rows for the
 // filter + one dense step (~430 with the gathers) per 64 groups of 4 rows that hold a live row, against ~330 per 256 rows tile by tile:
 // break-even near 18 % live rows
 constexpr long long MT_SPARSE_DIV = MT_SPARSE_DIV_N;
 __host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2, bool spec = false) {
-    return ((!acc2 && !spec) ? (long long)MT_MAX_T * 8 + (long long)(threads / 64) * MT_SP_RING * 4 : 0) + (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
+    return ((!acc2 && !spec) ? (long long)MT_MAX_T * 8 /* live-node masks of the sparse sweep */ : 0) + (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
            (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * MT_RING * ((acc2 ? 32 : 16) + 8 + 2) + 256;     // (consumer waves have no ring)
 }
 
@@ -348,8 +347,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     size_t off = reinterpret_cast<unsigned char*>(ring_li_all + NRINGS * MT_RING) - smem;
     off = (off + 15) & ~(size_t)15;
     unsigned long long* xmask = reinterpret_cast<unsigned long long*>(smem + off);            // [MT_MAX_T] sparse sweep: bit i = node base + i of the class tree is live
-    uint32_t* sp_ring_all = reinterpret_cast<uint32_t*>(xmask + MT_MAX_T);                      // [waves][MT_SP_RING] sparse sweep: row groups with a live row
-    if (!ACC2 && !SPEC) off += (size_t)MT_MAX_T * 8 + (size_t)WAVES * MT_SP_RING * 4;           // (reserved for every plain pass: mt_fixed_bytes)
+    if (!ACC2 && !SPEC) off += (size_t)MT_MAX_T * 8;                                            // (reserved for every plain pass: mt_fixed_bytes)
     unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem + off);     // [total][spn] gradient sums, then [total][spn] hessian sums (see k_level_root)
     const long long avail = (long long)c.lds_bytes - (long long)off;
 
@@ -771,11 +769,12 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         }
         // ---- sparse sweep: the class trees [nkd, nk) of the workgroup, whose expanded parents hold < 1/MT_SPARSE_DIV of the rows.  Per class tree the wave
         // streams ONLY the node ids of its rows (1 B per row: sixteen rows per lane and step), tests them against the tree's 64-bit mask of
-        // live nodes and appends the 4-row groups that hold a live row to a small ring; 64 such groups are one dense step: every lane
+        // live nodes and collects the 4-row groups that hold a live row in a REGISTER of the wave (lanes [0, sp_cnt) hold pending groups; new
+        // ones are pushed to the next free lanes with one ds_permute: no LDS memory -- 8 KB of rings cost the K = 64 passes 5 % through the
+        // histograms' replication, profiles/r05d_*); 64 such groups are one dense step: every lane
         // fetches its group's records, node ids and (g, h) and goes through the same lookup + route + append code as the row loop.  A pass
         // over a class tree with 1 % live rows costs its node-id stream instead of records + (g, h) + ~330 instructions per 256 rows.
         if (SPARSE && nkd < nk) {
-            uint32_t* sp_ring = sp_ring_all + wave * MT_SP_RING;
             const long long row_lo = wt_lo * MT_WT_ROWS, row_hi = (wt_hi * MT_WT_ROWS < N) ? wt_hi * MT_WT_ROWS : N;
             const long long nst = (wt_hi * MT_WT_ROWS - row_lo + 1023) / 1024;        // super tiles of 1024 rows (the block's rows are whole wave tiles)
             for (int kk = nkd; kk < nk; ++kk) {
@@ -786,11 +785,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                 const unsigned long long xm = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xm_v) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xm_v >> 32)) << 32;
                 const uint8_t* nd_k = node + (long long)(tq1 >> 16) * NS;
                 const float2* gh_k = gh + (long long)(tq1 >> 16) * NG;
-                int sp_head = 0, sp_cnt = 0;                          // wave-uniform
-                auto sparse_batch = [&](int nb) __attribute__((always_inline)) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                int sp_cnt = 0;                                       // wave-uniform: lanes [0, sp_cnt) hold a pending group in `pend`
+                uint32_t pend = 0u;
+                auto sparse_batch = [&](int nb) __attribute__((always_inline)) {      // all pending groups: nb = sp_cnt (<= 64)
                     const bool on = lane < nb;
-                    const uint32_t g = sp_ring[(sp_head + lane) & (MT_SP_RING - 1)];
+                    const uint32_t g = pend;
                     const long long row0 = on ? (long long)g * 4 : row_lo;
                     uint4 ra[4], r1[4]; uint32_t bagmask = BAG ? 0u : 0xFu, rowmask = 0u;
 #pragma unroll
@@ -805,7 +804,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                     uint2 e[4]; uint32_t inm = 0u;
                     lookup(n4, tq, rowmask, e, inm);
                     stage_c(row0, ra, r1, bagmask, n4, g0, g1, e, inm, tq);
-                    sp_head = (sp_head + nb) & (MT_SP_RING - 1); sp_cnt -= nb;
+                    sp_cnt = 0;
                 };
                 auto load16 = [&](long long st) __attribute__((always_inline)) -> uint4 {
                     const long long r16 = row_lo + st * 1024 + lane * 16;
@@ -829,15 +828,26 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                             hit = hit || (idx < nlev && ((xm >> (idx & 63u)) & 1ull) != 0ull && d * 4 + j < nvalid);
                         }
                         const unsigned long long m = __ballot(hit);
-                        if (m != 0ull) {                                  // uniform
-                            if (hit) sp_ring[(sp_head + sp_cnt + (int)__popcll(m & lane_lt)) & (MT_SP_RING - 1)] = (uint32_t)((r16 + d * 4) >> 2);
-                            sp_cnt += (int)__popcll(m);
-                            if (sp_cnt >= 64) sparse_batch(64);
+                        if (m != 0ull) {                                  // uniform: every lane takes part in the permute
+                            // one permutation of the 64 lanes: the np hit lanes push their group to the lanes sp_cnt .. sp_cnt + np - 1 (mod 64), the
+                            // others fill the rest (their values are never taken)
+                            const int np = (int)__popcll(m), r_hit = (int)__popcll(m & lane_lt);
+                            const int dest = hit ? sp_cnt + r_hit : sp_cnt + np + (lane - r_hit);
+                            const uint32_t rx = (uint32_t)__builtin_amdgcn_ds_permute((dest & 63) << 2, (int)(uint32_t)((r16 + d * 4) >> 2));
+                            const int rel = (lane - sp_cnt) & 63;         // lane receives the rel-th new group if rel < np
+                            if (sp_cnt + np < 64) { if (rel < np) pend = rx; sp_cnt += np; }
+                            else {
+                                const int rem = sp_cnt + np - 64;          // groups that wrapped around to the lanes [0, rem)
+                                if (rel < 64 - sp_cnt) pend = rx;
+                                sparse_batch(64);
+                                if (lane < rem) pend = rx;
+                                sp_cnt = rem;
+                            }
                         }
                     }
                     n16 = nxt;
                 }
-                while (sp_cnt > 0) sparse_batch(sp_cnt < 64 ? sp_cnt : 64);
+                if (sp_cnt > 0) sparse_batch(sp_cnt);
             }
         }
     }
