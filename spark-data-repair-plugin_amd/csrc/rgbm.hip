@@ -412,7 +412,8 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // (shrinks the LDS pool of the level passes: more built-slot windows per level), RGBM_LV_BLOCKS / RGBM_MT_BLOCKS (row blocks per class
 // tree of the root / level passes), RGBM_MT_TREES (cap on the class trees per level-pass workgroup), RGBM_MT_REP (LDS replication the
 // level passes are sized for, default 8), RGBM_JOINT_ROOT=0, RGBM_MT_ACC2=0 (tables of 17..32 features: one level pass per 16-feature chunk
-// instead of one pass that accumulates both).
+// instead of one pass that accumulates both), RGBM_MT_SPEC=0|1 (wave-specialised level pass), RGBM_MT_SPARSE=0 (no sparse sweep: class trees
+// with few live rows are walked tile by tile like the others).
 constexpr int LV_THREADS_DEFAULT = 1024;
 struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/32 live rows are swept through their node ids */; };
 RunSwitches read_switches() {
