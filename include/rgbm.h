@@ -87,7 +87,8 @@ typedef struct {
 /* Number of usable HIP devices (0 if none). */
 int rgbm_device_count(void);
 /* The library parks freed device blocks in a caching pool (at most RGBM_POOL_MB, default 65536; 0 disables it).
- * rgbm_release_cache gives all of them back to the driver, e.g. before another allocator needs the memory. */
+ * rgbm_release_cache gives all of them back to the driver, e.g. before another allocator needs the memory, together with the
+ * page-locked host blocks the library keeps for the tree harvest of batched fits and for the outputs of repair chains. */
 int rgbm_release_cache(void);
 /* Message of the last failing call on this thread. */
 const char* rgbm_last_error(void);

@@ -1917,7 +1917,23 @@ extern "C" {
 RGBM_EXPORT int rgbm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 RGBM_EXPORT const char* rgbm_last_error(void) { return g_err.c_str(); }
 RGBM_EXPORT int rgbm_version(void) { return RGBM_VERSION; }
-RGBM_EXPORT int rgbm_release_cache(void) { return guarded([&]() { rgh::pool_trim(0); return RGBM_OK; }); }
+RGBM_EXPORT int rgbm_release_cache(void) {
+    return guarded([&]() {
+        rgh::pool_trim(0);
+        // the page-locked blocks kept for the tree harvest of a batch and for the outputs of a repair chain (not while a call uses them)
+        {
+            HarvestArena& a = harvest_arena();
+            std::unique_lock<std::mutex> lk(a.mu, std::try_to_lock);
+            if (lk.owns_lock() && a.p) { (void)hipHostFree(a.p); a.p = nullptr; a.cap = 0; a.device = -1; }
+        }
+        {
+            ChainStage& c = chain_stage();
+            std::unique_lock<std::mutex> lk(c.mu, std::try_to_lock);
+            if (lk.owns_lock()) { for (int i = 0; i < 2; ++i) if (c.p[i]) { (void)hipHostFree(c.p[i]); c.p[i] = nullptr; } c.cap = 0; c.device = -1; }
+        }
+        return RGBM_OK;
+    });
+}
 
 RGBM_EXPORT int rgbm_table_create(const int32_t* codes, int64_t n, int32_t c, const int32_t* n_codes, int32_t device_id, rgbm_table** out) {
     if (!codes || !n_codes || !out || n <= 0 || c <= 0) return fail(RGBM_ERR_ARG, "rgbm_table_create: bad argument");
