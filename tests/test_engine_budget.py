@@ -40,3 +40,35 @@ def test_search_fan_out_shrinks_the_outer_concurrency():
 def test_fits_in_flight_follow_the_options():
     assert search_fits_in_flight({}) == 8 * 3
     assert search_fits_in_flight({"model.hp.batch_size": "2", "model.cv.n_splits": "5"}) == 10
+
+
+def test_a_rank_parses_only_the_blobs_it_did_not_train():
+    """engine.run_job keeps the model objects it trained (load(save(m)) is m: a default job's 16 models are 87 MB of blobs) and calls
+    load_model only for models that came from other ranks; the repaired cells are those of a job that parses every blob."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from repair.engine import run_job
+    from tests.helpers import OracleEngine
+    from tests.synth import make_table
+
+    class Counting(OracleEngine):
+        loads = 0
+
+        def load_model(self, blob):
+            Counting.loads += 1
+            return super().load_model(blob)
+
+    dirty, clean, cards = make_table(3000, 5, seed=33, null_ratio=0.04)
+    targets = [0, 2, 4]
+    counts = {t: np.bincount(dirty[t][dirty[t] >= 0], minlength=int(cards[t])) for t in targets}
+    mask = (dirty[targets] < 0).any(axis=0)
+    params = dict(n_estimators=6, learning_rate=0.2, num_leaves=15, min_data_in_leaf=5)
+    eng = Counting()
+    res = run_job(eng, eng.upload(dirty, cards), eng.upload(np.ascontiguousarray(dirty[:, mask]), cards), cards, targets, counts, params)
+    assert Counting.loads == 0                                   # a single rank trained all three
+    # the same job through the blobs only
+    eng2 = OracleEngine()
+    models = [eng2.load_model(res["models"][t]) for t in targets]
+    tab = eng2.upload(np.ascontiguousarray(dirty[:, mask]), cards)
+    lab, prob = eng2.repair_chain(tab, models, targets, [[c for c in range(5) if c != t] for t in targets], 0, tab.n)
+    assert np.array_equal(lab, res["labels"]) and np.array_equal(prob, res["probs"])
