@@ -18,7 +18,10 @@
 //     PROVABLY cannot be split by best-first growth: with pm(X) = min gain on the path root..X,
 //     every known node Y with pm(Y) > pm(X) is split before X (induction on the best-first
 //     queue), so X is dead once num_leaves-1 such nodes exist.  Expansion is a superset of the
-//     final tree, never a subset;
+//     final tree, never a subset (how much of a superset: DESIGN.md section 5, "How much of a level pass is
+//     needed at all"); it also publishes the rows of the expanded parents, and a class tree whose share
+//     is below 1 in 16 -- the deep levels of many-class targets -- is swept through its node ids only
+//     (k_level_mt, sparse sweep);
 //   * k_level_replay runs LightGBM's best-first selection (ArrayArgs::ArgMax + Tree::Split
 //     numbering) over the speculative nodes and emits the tree in exactly the leaf-wise order.
 //
