@@ -415,7 +415,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // instead of one pass that accumulates both), RGBM_MT_SPEC=0|1 (wave-specialised level pass), RGBM_MT_SPARSE=0 (no sparse sweep: class trees
 // with few live rows are walked tile by tile like the others).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/32 live rows are swept through their node ids */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -598,7 +598,13 @@ void fit_setup(const rgbm_table& tab, const double* y_value_in, const double* cl
     // fixed-point grid of the histogram sums (numerics v2.1, rgbm_numerics.h): |g_i| <= (bound_g / w_max) * w_i and h_i <= (bound_h / w_max) * w_i
     // hold for every row i, so with e = min(50 - ceil_log2(bound), 62 - ceil_log2(bound * sum_w / w_max)) every converted value is at most
     // 2^50 in magnitude (the range of the rint trick) and an int64 sum over all training rows (of all ranks) stays below 2^62
-    const int e_g = rg::fx_exponent(bound_g, sumw / w_max), e_h = rg::fx_exponent(bound_h, sumw / w_max);
+    int e_g = rg::fx_exponent(bound_g, sumw / w_max), e_h = rg::fx_exponent(bound_h, sumw / w_max);
+    // test hook (tests/test_numerics_bound.py; the oracle reads the same variable): RGBM_FX_E = E caps the grid at E bits for a value equal to
+    // the bound -- what a table of 2^(62 - E) equally weighted rows gets (E = 38: 10M rows, E = 35: 100M rows) -- on a table of any size
+    if (const char* ev = std::getenv("RGBM_FX_E")) {
+        const int E = std::atoi(ev);
+        if (E >= 8 && E <= 50) { e_g = std::min(e_g, E - rg::fx_ceil_log2(bound_g)); e_h = std::min(e_h, E - rg::fx_ceil_log2(bound_h)); }
+    }
 
     TrainConst& tc = h.tc; memset(&tc, 0, sizeof(tc));
     tc.sg = std::ldexp(1.0, e_g); tc.sh = std::ldexp(1.0, e_h); tc.inv_sg = std::ldexp(1.0, -e_g); tc.inv_sh = std::ldexp(1.0, -e_h);
@@ -1374,6 +1380,7 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
         }
         catch (const std::invalid_argument& e) { record_error(i, e, RGBM_ERR_PARAM); continue; }
         catch (const std::out_of_range& e) { record_error(i, e, RGBM_ERR_LABEL); continue; }
+        catch (const std::exception& e) { record_error(i, e, RGBM_ERR_HIP); continue; }
         dev[i].reset(new SmallFitDev());
         SmallFitDev& d = *dev[i]; FitHost& h = d.h;
         d.F = F; d.K = p.objective == 1 ? p.num_class : 1; d.NL = p.num_leaves; d.NE = p.n_estimators; d.NT = (size_t)d.NE * d.K;
@@ -1396,9 +1403,11 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
     for (int i : live) {
         const rgbm_fit_spec& sp = specs[i]; const rgbm_table& tab = *sp.table; const rgbm_params& p = *sp.params;
         SmallFitDev& d = *dev[i]; FitHost& h = d.h; const int F = d.F, K = d.K, NL = d.NL, NE = d.NE; const long long N = tab.n;
-        try { fit_setup(tab, sp.y_value, sp.class_weight, nullptr, p, F, h); }
-        catch (const std::invalid_argument& e) { record_error(i, e, RGBM_ERR_PARAM); dev[i].reset(); continue; }
-        catch (const std::out_of_range& e) { record_error(i, e, RGBM_ERR_LABEL); dev[i].reset(); continue; }
+        // one failing fit does not fail the batch: whatever this fit's set-up throws (arguments, labels, HIP) is ITS status; uploads queued from
+        // its host vectors are drained before they are destroyed
+        auto drop_fit = [&](const std::exception& e, int code) { (void)hipStreamSynchronize(s); record_error(i, e, code); dev[i].reset(); };
+        try {
+        fit_setup(tab, sp.y_value, sp.class_weight, nullptr, p, F, h);
         // lane map of the packed threshold scan (rgbm_small.h): a lane owns 4 bins of one feature, a feature does not straddle waves;
         // used when a child's features fit half of the workgroup's waves (both children are scanned at once) and the two compact
         // histograms fit next to the rest in LDS -- otherwise one wave per feature (split_find_body)
@@ -1476,6 +1485,11 @@ void train_batch_small(const rgbm_fit_spec* specs, int32_t n_fits, rgbm_model** 
         }
         NE_max = std::max(NE_max, NE); lds_max = std::max(lds_max, lds); N_max = std::max(N_max, N); ntrain_max = std::max(ntrain_max, n_train);
         ok.push_back(i);
+        }
+        catch (const std::invalid_argument& e) { drop_fit(e, RGBM_ERR_PARAM); continue; }
+        catch (const std::out_of_range& e) { drop_fit(e, RGBM_ERR_LABEL); continue; }
+        catch (const std::domain_error& e) { drop_fit(e, RGBM_ERR_NO_DEVICE); continue; }
+        catch (const std::exception& e) { drop_fit(e, RGBM_ERR_HIP); continue; }
     }
     if (ok.empty()) return;
     if (timing) HIPCHK(hipStreamSynchronize(s));
@@ -2009,7 +2023,11 @@ RGBM_EXPORT int rgbm_table_train_batch(const rgbm_fit_spec* fits, int32_t n_fits
     if (!fits || n_fits <= 0 || !out_models || !out_status || !fits[0].table) return fail(RGBM_ERR_ARG, "rgbm_table_train_batch: bad argument");
     return guarded([&]() {
         use_device(fits[0].table->device);
-        train_batch_small(fits, n_fits, out_models, out_status);
+        for (int32_t i = 0; i < n_fits; ++i) { out_models[i] = nullptr; out_status[i] = RGBM_OK; }
+        // a failure of the batch as a whole (not of one fit) returns no models: the ones already trained are released here, the caller
+        // only sees the error code
+        try { train_batch_small(fits, n_fits, out_models, out_status); }
+        catch (...) { for (int32_t i = 0; i < n_fits; ++i) { delete out_models[i]; out_models[i] = nullptr; } throw; }
         return RGBM_OK;
     });
 }

@@ -207,12 +207,19 @@ __host__ __device__ inline size_t sm_lds_bytes(size_t lds_hist, int num_leaves, 
     return b + 64;
 }
 
+// A fit is FROZEN from the first boosting iteration in which no class tree could split: the model ends there (model_trees_begin: n_iter =
+// the first iteration with any_split == 0; GBDT::TrainOneIter returns "finished"), so nothing later may reach the validation scores
+// either -- with bagging or feature_fraction < 1 a later iteration could split again, and its trees would be in the CV scores but not
+// in the model.  any_split[it - 1] is final when iteration it's kernels start (stream order); a frozen iteration leaves
+// its own flag at zero, which freezes the next one.
+__device__ __forceinline__ bool small_fit_frozen(const SmallFit& sf, int it) { return it > 0 && sf.any_split[it - 1] == 0; }
+
 // ------------------------------------------------------------------------------------------------
 // gradients of every fit: grid (row tiles, fits), block 256
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_small_grad(const SmallFit* __restrict__ fits, int it) {
     const SmallFit& sf = fits[blockIdx.y];
-    if (it >= sf.n_estimators) return;
+    if (it >= sf.n_estimators || small_fit_frozen(sf, it)) return;
     const TrainConst c = sf.c;
     const uint8_t* inbag = sf.bag_freq > 0 ? sf.inbag : nullptr;
     const long long first = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256) void k_small_bag_lists(const SmallFit* __restr
 // out-of-bag rows take the new tree's output by traversal (ScoreUpdater::AddScore(tree, oob)): grid (row tiles, class trees of the batch)
 __global__ __launch_bounds__(256) void k_small_oob(const SmallFit* __restrict__ fits, const int32_t* __restrict__ tree2fit, int it) {
     const SmallFit& sf = fits[tree2fit[blockIdx.y]];
-    if (sf.bag_freq <= 0 || it >= sf.n_estimators) return;
+    if (sf.bag_freq <= 0 || it >= sf.n_estimators || small_fit_frozen(sf, it)) return;
     const int k = (int)blockIdx.y - sf.tree0;
     if (sf.tree_L[k] <= 1) return;
     const TrainConst& c = sf.c;
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256) void k_small_oob(const SmallFit* __restrict__ 
 // as the predictor adds them, so the final scores are the predictor's bits.  grid (row tiles, class trees of the batch), block 256.
 __global__ __launch_bounds__(256) void k_small_valid(const SmallFit* __restrict__ fits, const int32_t* __restrict__ tree2fit, int it) {
     const SmallFit& sf = fits[tree2fit[blockIdx.y]];
-    if (sf.n_valid <= 0 || it >= sf.n_estimators) return;
+    if (sf.n_valid <= 0 || it >= sf.n_estimators || small_fit_frozen(sf, it)) return;
     const int k = (int)blockIdx.y - sf.tree0;
     if (sf.tree_L[k] <= 1) return;                         // no split: the tree adds nothing (its constant is the initial score)
     const TrainConst& c = sf.c;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
     __shared__ TreeState st;
     __shared__ int wl[SM_WAVES], wr[SM_WAVES];
     const SmallFit& sf = fits[tree2fit[blockIdx.x]];
-    if (it >= sf.n_estimators) return;
+    if (it >= sf.n_estimators || small_fit_frozen(sf, it)) return;
     const TrainConst c = sf.c;
     const int k = (int)blockIdx.x - sf.tree0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NL = c.num_leaves, F = c.F;

@@ -283,12 +283,16 @@ def train_batch(fits):
     status = np.zeros(n, np.int32)
     _check(lib().rgbm_table_train_batch(specs, C.c_int32(n), handles, _p(status, C.c_int32)), "rgbm_table_train_batch")
     out = []
+    # rgbm_last_error() is ONE thread-local string: it describes the LAST failing fit of the batch; the others report their status code only
+    failing = [i for i in range(n) if status[i] != 0]
+    last_msg = lib().rgbm_last_error().decode("utf-8", "replace") if failing else ""
     for i in range(n):
         if status[i] == 0 and (handles[i] or (keep[i][5] is not None and keep[i][4].reserved & FLAG_NO_MODEL)):
             m = Model(C.c_void_p(handles[i])) if handles[i] else None          # want_model=False: a CV fold, wanted for its scores only
             out.append(m if keep[i][5] is None else (m, keep[i][6], keep[i][7]))
         else:
-            out.append(RepairGbmError("fit %d of the batch failed (%d): %s" % (i, int(status[i]), lib().rgbm_last_error().decode("utf-8", "replace"))))
+            why = last_msg if (failing and i == failing[-1]) else ("status %d" % int(status[i]) if status[i] != 0 else "no model returned")
+            out.append(RepairGbmError("fit %d of the batch failed (%d): %s" % (i, int(status[i]), why)))
     return out
 
 

@@ -423,7 +423,13 @@ def repair_frame(engine, df, row_id, targets=None, constraints=(), base_params=N
         # with the cells as GIVEN -- no second detection, no pandas detectors, no value-space fallback.
         _logger.info("%s: re-encoding the target dictionaries without them" % e)
         cells = (e.rows, e.cols)
+        first = given_current
         given_current = null_known_cells(cells[0], cells[1])
+        if first is not None:
+            # cells of a user-given error_cells frame were NULLed before the first attempt: the second pass sees None there, the first
+            # one knows what they held
+            fresh = ~np.isin(given_current[0], first[0])
+            given_current = (np.concatenate([first[0], given_current[0][fresh]]), np.concatenate([first[1], given_current[1][fresh]]))
         cont, res = build_and_run(cells, False, ())
     rows, ccols = res["rows"], res["cols"]
 

@@ -39,18 +39,22 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--targets", default="10,0")
+    ap.add_argument("--cols", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--out", default=OUT, help="bench_job_digests.json (10M x 16) or bench_shard_digests.json (--rows 12500000 --cols 32 --seed 43)")
     a = ap.parse_args()
-    dirty, clean, cards = make_table(a.rows, 16, seed=42)
+    OUT_ = a.out if os.path.isabs(a.out) else os.path.join(os.path.dirname(os.path.abspath(__file__)), a.out)
+    dirty, clean, cards = make_table(a.rows, a.cols, seed=a.seed)
     del clean
-    doc = {"table": {"rows": a.rows, "cols": 16, "seed": 42, "null_ratio": 0.01}, "iters": a.iters,
+    doc = {"table": {"rows": a.rows, "cols": a.cols, "seed": a.seed, "null_ratio": 0.01}, "iters": a.iters,
            "numerics_version": 210, "generator": "tests/golden/make_bench_job_golden.py", "targets": {}}
-    if os.path.exists(OUT):
-        old = json.load(open(OUT))
+    if os.path.exists(OUT_):
+        old = json.load(open(OUT_))
         if old.get("table") == doc["table"] and old.get("iters") == a.iters and old.get("numerics_version") == 210:
             doc["targets"] = old["targets"]
     O.lib().orc_set_threads(a.threads)
     for t in [int(x) for x in a.targets.split(",")]:
-        feats = [c for c in range(16) if c != t]
+        feats = [c for c in range(a.cols) if c != t]
         K = int(cards[t])
         rows = dirty[t] >= 0
         cw = balanced_weights(dirty[t], K)
@@ -59,7 +63,7 @@ def main():
         blob = O.train(np.ascontiguousarray(dirty[feats][:, rows]), cards[feats], dirty[t][rows], K, class_weight=cw, **kw).save()
         doc["targets"]["c%d" % t] = {"K": K, "train_rows": int(rows.sum()), "digests": iteration_digests(blob),
                                       "oracle_seconds": round(time.time() - t0, 1), "threads": a.threads}
-        with open(OUT, "w") as f:
+        with open(OUT_, "w") as f:
             json.dump(doc, f, indent=1)
         print("c%d (K=%d): %d iterations in %.0f s" % (t, K, a.iters, time.time() - t0), flush=True)
 

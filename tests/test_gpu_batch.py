@@ -166,3 +166,41 @@ def test_validation_rows_scored_while_training_equal_the_predictor():
         single = ttab.train(sp["target_col"], f["feat_cols"], class_weight=f["class_weight"], y_value=sp.get("y_value"),
                             **{k: v for k, v in sp.items() if k not in ("target_col", "y_value")}, n_estimators=10, learning_rate=0.2)
         assert m.save() == single.save()
+
+
+def test_a_fit_is_frozen_after_its_first_iteration_without_a_split():
+    """the model ends at the first boosting iteration in which no class tree could split (LightGBM stops training
+    there), but with feature_fraction < 1 a LATER iteration draws other features and could split again -- its trees must not reach the
+    validation scores of a CV fold, or cross_val_score would score a model that does not exist.  One informative feature among noise,
+    min_gain_to_split high enough that noise never splits, two of six features per tree: most seeds stop within a few iterations.
+    Every fit: validation labels / values == repair_chain of the returned model, model == the single-fit trainer's."""
+    from repair import _native as N
+    rng = np.random.default_rng(5)
+    n = 6000
+    codes = np.empty((7, n), np.int32)
+    codes[1] = rng.integers(0, 4, n)
+    codes[0] = ((codes[1] >= 2) ^ (rng.random(n) < 0.1)).astype(np.int32)
+    for c in range(2, 7):
+        codes[c] = rng.integers(0, 5, n)
+    cards = np.asarray([2, 4, 5, 5, 5, 5, 5], np.int32)
+    tab = N.Table(codes, cards)
+    va = np.arange(0, n, 4).astype(np.int64)
+    tr = np.setdiff1d(np.arange(n), va).astype(np.int64)
+    ttab, vtab = tab.gather_rows(tr), tab.gather_rows(va)
+    feats = list(range(1, 7))
+    NE = 12
+    kw = dict(objective=0, num_class=2, n_estimators=NE, learning_rate=0.3, feature_fraction=0.34, min_gain_to_split=25.0, min_data_in_leaf=50)
+    fits = [dict(table=ttab, target_col=0, feat_cols=feats, class_weight=None, valid_table=vtab, seed=sd, **kw) for sd in range(1, 9)]
+    out = N.train_batch(fits)
+    stopped = 0
+    for f, res in zip(fits, out):
+        assert isinstance(res, tuple), "fit failed: %r" % (res,)
+        m, lab, val = res
+        n_iter = m.info()["n_iter"]
+        stopped += 1 if n_iter < NE else 0
+        check = tab.gather_rows(va)
+        ref_lab, ref_val = check.repair_chain([m], [0], [feats])
+        assert np.array_equal(lab, ref_lab[0]) and np.array_equal(val, ref_val[0]), "seed %d (model of %d iterations): CV scores are not the model's" % (f["seed"], n_iter)
+        single = ttab.train(0, feats, class_weight=None, seed=f["seed"], **kw)
+        assert m.save() == single.save()
+    assert stopped >= 1, "no seed stopped early: the case this test is about did not occur"
