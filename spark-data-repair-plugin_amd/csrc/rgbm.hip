@@ -415,7 +415,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // instead of one pass that accumulates both), RGBM_MT_SPEC=0|1 (wave-specialised level pass), RGBM_MT_SPARSE=0 (no sparse sweep: class trees
 // with few live rows are walked tile by tile like the others).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = 8; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -429,6 +429,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_THREADS")) w.mt_threads = atoi(e) == 768 ? 768 : 1024;
     if (const char* e = getenv("RGBM_MT_SPEC")) w.mt_spec = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RGBM_MT_SPARSE")) w.mt_sparse = atoi(e) != 0;
+    if (const char* e = getenv("RGBM_FUSE_GRAD")) w.fuse_grad = atoi(e) != 0;
     w.timing = getenv("RGBM_TIMING") != nullptr;
     return w;
 }
@@ -755,6 +756,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     LevelConst lc; memset(&lc, 0, sizeof(lc));
     DevBuf<uint8_t> d_node; DevBuf<LvPlan> d_plan; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
+    DevBuf<FinEntry> d_fin;   // fused last pass + next gradients (k_level_final_grad_*)
+    bool fuse_grad = false; size_t fuse_lds = 0; int fuse_grid = 1;
     int n_hnodes = 1;
     bool use_reduce = false;   // root pass: sum the per-workgroup partials in a separate kernel (many workgroups per class tree, joint bins, or row-sharded)
     // joint bins for the root pass (rgbm_level.h, k_pack_joint): a second record whose bytes hold GROUPS of low-cardinality features
@@ -810,12 +813,12 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             // records of a row in registers and in the ring) instead of one pass per chunk that streams every (node id, g, h) again
             bool acc2 = nchunk == 2 && sw.mt_acc2;
             if (acc2) {   // ... when one node's histograms of both chunks fit the LDS of the 768-thread workgroup (else: one pass per chunk, as for > 32 features)
-                const long long nb2 = ((long long)lv_slots(fmeta.data() + cmeta[0].first_feat, cmeta[0].nfeat, 0) + lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0)) * 16;
+                const long long nb2 = ((long long)lv_slots(fmeta.data() + cmeta[0].first_feat, cmeta[0].nfeat, 0) + lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0) + MT_ROT_DUMMY) * 16;
                 if (nb2 > lc.lds_bytes - mt_fixed_bytes(MT_THREADS_ACC2, true, sw.mt_spec != 0)) acc2 = false;
             }
             for (int ch = 0; ch < (acc2 ? 1 : nchunk); ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
-                long long node_bytes = (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 16;
+                long long node_bytes = (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 16 + MT_ROT_DUMMY * 16;
                 if (acc2) node_bytes += (long long)lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0) * 16;
                 const int mt_thr = acc2 ? MT_THREADS_ACC2 : ((nchunk == 1 && sw.mt_threads == 768 && sw.mt_spec != 1) ? 768 : LV_THREADS);
                 const bool spec = acc2 ? sw.mt_spec != 0 : (nchunk == 1 && sw.mt_spec == 1);
@@ -862,6 +865,15 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const int max_built_all = 1 << std::max(0, p.max_depth - 2);
         d_part_red.alloc((size_t)K * max_built_all * tc.totbins + (size_t)K * 128 /* K*256 int64 counts */);
         d_leafnode.alloc((size_t)K * LV_MAX_LEAVES); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
+        // The last pass of an iteration fused with the gradients of the next one (rgbm_level.h, k_level_final_grad_*): not with bagging (the next
+        // bag is drawn in between), and for the softmax shapes its two layouts cover (K <= 112: k_grad_mc's bound).  RGBM_FUSE_GRAD=0 keeps
+        // k_level_final + the gradient kernel (same models: tests/test_gpu_growers.py runs both).
+        {
+            const bool mc_tile = obj == 1 && K >= 16;
+            fuse_lds = mc_tile ? (size_t)(K * 64 + 320) * 8 : (obj == 1 ? (size_t)K * 256 * 8 : 0);
+            fuse_grad = sw.fuse_grad && !use_bagging && NE > 1 && (obj != 1 || K <= 112) && fuse_lds <= 64 * 1024 && N < (1ll << 28);
+            if (fuse_grad) { d_fin.alloc((size_t)K * 256); fuse_grid = (int)(mc_tile ? (N + 63) / 64 : (N + 255) / 256); }
+        }
         // Joint bins for the root pass (the tables where the root pass runs at the LDS-atomic rate).  Best-fit-decreasing packing of the
         // features into groups whose bin counts multiply to <= 256; worth it when it saves at least two atomics per row and the groups
         // fit one 16-byte record.  RGBM_JOINT_ROOT=0 disables it (same models either way: the sums are exact integers).
@@ -1072,7 +1084,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         trace_copy("lpool", level, d_lpool.p, (size_t)K * n_hnodes * tc.totbins * 16);
     };
     // one boosting iteration of the level grower after the gradients: an iteration-invariant launch sequence
-    auto enqueue_level_growth = [&]() {
+    auto enqueue_level_growth = [&](bool fuse_next /* also emit the NEXT iteration's gradients (k_level_final_grad_*) */) {
             hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, n_in_ptr, (long long)n_train, lc);
             int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
             // partials of this rank -> compact buffer (-> integer all-reduce when row-sharded); the split kernel then sees ONE partial
@@ -1109,7 +1121,22 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
             hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_snodes.p, d_lcand.p, d_fmeta.p, p.max_depth, tc, lc);
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
-            hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
+            if (fuse_next) {
+                const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw_ = sample_weight_host ? d_sw.p : nullptr;
+                // the exact counts of the deepest children first (it reads the node ids the fused pass resets), then table + fused pass
+                hipLaunchKernelGGL(k_level_final<true>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, (const uint8_t*)nullptr,
+                                   d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
+                hipLaunchKernelGGL(k_level_fin_table, dim3(K), dim3(256), 0, s, d_plan.p, to, d_ndelta.p, d_fin.p, d_it.p, lc);
+                if (obj == 1 && K >= 16)
+                    hipLaunchKernelGGL(k_level_final_grad_mc, dim3(fuse_grid), dim3(256), fuse_lds, s, d_rec.p, d_node.p, d_fin.p, d_score.p, d_ycol, cw, sw_, d_gh.p, lc, tc);
+                else if (obj == 1)
+                    hipLaunchKernelGGL((k_level_final_grad_rows<1, 256>), dim3(fuse_grid), dim3(256), fuse_lds, s, d_rec.p, d_node.p, d_fin.p, d_score.p, d_ycol, yv, cw, sw_, d_gh.p, lc, tc);
+                else if (obj == 0)
+                    hipLaunchKernelGGL((k_level_final_grad_rows<0, 256>), dim3(fuse_grid), dim3(256), fuse_lds, s, d_rec.p, d_node.p, d_fin.p, d_score.p, d_ycol, yv, cw, sw_, d_gh.p, lc, tc);
+                else
+                    hipLaunchKernelGGL((k_level_final_grad_rows<2, 256>), dim3(fuse_grid), dim3(256), fuse_lds, s, d_rec.p, d_node.p, d_fin.p, d_score.p, d_ycol, yv, cw, sw_, d_gh.p, lc, tc);
+            } else
+            hipLaunchKernelGGL(k_level_final<false>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
             if (dp) { hipLaunchKernelGGL(k_copy_i32, dim3(K), dim3(256), 0, s, d_count.p, d_count_g.p, (long long)K * 256); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
             hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, d_it.p, tc);
@@ -1149,11 +1176,11 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     for (int it = 0; it < NE; ++it) {
         if (use_bagging && it % p.bagging_freq == 0) enqueue_bagging();
         cur_it = it;
-        enqueue_grad();
+        if (!(level_mode && fuse_grad && it > 0)) enqueue_grad();     // (fused: the previous iteration's last pass wrote these gradients)
         trace_sum("gh", d_gh.p, (size_t)K * tc.NG * 8);
         const uint8_t* usedp = d_used.p + (size_t)it * K * F;
         if (level_mode) {
-            enqueue_level_growth();
+            enqueue_level_growth(fuse_grad && it + 1 < NE);
             hipLaunchKernelGGL(k_next_iteration, dim3(1), dim3(1), 0, s, d_it.p);
             continue;
         }

@@ -57,6 +57,7 @@ constexpr int MT_WT_ROWS = 256;              // rows of one wave tile: 4 consecu
 #endif
 constexpr int MT_RING = MT_RING_N;                 // entries of a wave's built-row ring: <= 63 waiting + <= 64 appended per row step
 constexpr int MT_CNT_REP = 8;
+
 constexpr int MT_THREADS_ACC2 = 768;
 #ifndef MT_CONSUMERS_N
 #define MT_CONSUMERS_N 4
@@ -121,6 +122,31 @@ __host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int q) {
     for (int j = 0; j < nfeat; ++j) t += fm[j].nbins << lv_shift(fm[j].nbins, q);
     return t;
 }
+
+// FEATURE ROTATION of the level pass's histogram updates (round 5).  A batch of 64 built rows is one wave of LDS atomics per feature, and at
+// the deep levels the LDS has no room for replicas: the rows of a batch come from one class tree, mostly from one or two of its nodes and --
+// on clustered data -- hold the SAME bin in most features, so the 64 lanes of an instruction pile up on a handful of addresses (the
+// micro-benchmark: 32 lanes on one address cost 7x a conflict-free instruction; levels 4-5 of the K = 64 target took 3.4 / 4.4 ms where
+// routing + conflict-free atomics are 2.4 / 2.0).  With rotation lane l works on feature (j + l) mod 16 in step j: the lanes of one instruction
+// spread over all 16 feature histograms of their nodes, and only the four lanes l, l + 16, l + 32, l + 48 can meet on an address -- which
+// at most four replicas (indexed by l / 16) resolve completely.  The record of an entry is rotated by (l mod 16) bytes once (12 VALU), after
+// which step j reads byte j exactly as before; feature slots a lane does not have (beyond nfeat, or byte 15 = the slot id) are masked to
+// bin 0 of a per-replica dummy slot.  Replication under rotation is one uniform shift <= 2 for every feature.
+// Measured (profiles/r5c_*): it helps where the LDS holds ONE copy (level 5 of K = 64: 3.88 -> 3.46 ms) and costs 35-60 % at levels 1-4,
+// where the replicated layout is better than conflict-free: rows of a cluster hold the same bin, replica = lane index puts the lanes of an
+// instruction on CONSECUTIVE 8-byte slots -- no bank conflict at all -- while the rotated lanes land on pseudo-random banks.  Off by default;
+// kept as a compile-time experiment (tools/build_variants.sh rot1 "-DMT_ROT=1").
+#ifndef MT_ROT
+#define MT_ROT 0
+#endif
+constexpr int MT_ROT_DUMMY = MT_ROT ? 4 : 0;         // dummy slots per node (one per replica index): where masked-off lanes add
+__host__ __device__ inline int mt_shift(int nbins, int q) { return MT_ROT ? (q < 0 ? 0 : (q > 2 ? 2 : q)) : lv_shift(nbins, q); }
+__host__ __device__ inline int mt_slots(const FeatMeta* fm, int nfeat, int q) {
+    int t = 0;
+    for (int j = 0; j < nfeat; ++j) t += fm[j].nbins << mt_shift(fm[j].nbins, q);
+    return t;
+}
+constexpr int MT_MAX_Q = MT_ROT ? 2 : LV_MAX_Q;
 
 // bytes the root pass needs besides the histogram: nothing but alignment slack
 constexpr int LV_ROOT_FIXED = 256;
@@ -397,10 +423,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         if (SPARSE) xmask[lane] = 0ull;
         if (lane == 0) {
             // replication: the largest uniform shift whose histograms fit
-            int s = LV_MAX_Q;
+            int s = MT_MAX_Q;
             const int tot = ok ? total : 0;
-            while (s > 0 && (long long)tot * (lv_slots(fm, nfeat, s) + (ACC2 ? lv_slots(fm1, nfeat1, s) : 0)) * 16 > avail) --s;
-            const int spn0 = lv_slots(fm, nfeat, s) + (ACC2 ? lv_slots(fm1, nfeat1, s) : 0);
+            while (s > 0 && (long long)tot * (mt_slots(fm, nfeat, s) + (ACC2 ? mt_slots(fm1, nfeat1, s) : 0) + MT_ROT_DUMMY) * 16 > avail) --s;
+            const int spn0 = mt_slots(fm, nfeat, s) + (ACC2 ? mt_slots(fm1, nfeat1, s) : 0) + MT_ROT_DUMMY;
             if ((long long)tot * spn0 * 16 > avail) atomicOr(err_flag, 2);          // (the host's window sizing guarantees the plain layout fits)
             scal[0] = tot; scal[1] = s; scal[2] = spn0; scal[3] = ((ok && livem != 0ull) ? 1 : 0) | (ok ? nkd_ : nk) << 8;
         }
@@ -467,7 +493,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 int shj = 0, fb = 0;
-                if (j < na) { shj = lv_shift(fa[j].nbins, s); fb = o; o += fa[j].nbins << shj; }
+                if (j < na) { shj = mt_shift(fa[j].nbins, s); fb = o; o += fa[j].nbins << shj; }
                 pk |= (unsigned long long)(shj + 3) << (4 * j); cj[a][j] = (fb + (lane & ((1 << shj) - 1))) * 8;
                 if (tid == 0) {
                     const int q = a * 16 + j;
@@ -481,6 +507,28 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     }
     const int hdelta = total * spn;
     __syncthreads();
+    // feature rotation (MT_ROT): lane l works on feature slot (j + l) mod 16 in step j.  cj[a][j] becomes the byte offset of THAT feature's
+    // first slot (+ the lane's replica l / 16), or of the lane's dummy slot when the chunk has no such feature; rmask[a] zeroes the bytes of
+    // the rotated record that are not features, so that a masked lane adds to bin 0 of its dummy slot.
+    uint32_t rmask[NACC][4];
+    const int rot_sh = mt_shift(1, s) + 3;            // uniform under rotation
+    if (MT_ROT) {
+        const int r16 = lane & 15, c4 = lane >> 4;
+        const int spn_valid = spn - MT_ROT_DUMMY;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            const int na = a == 0 ? nfeat : nfeat1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) rmask[a][w] = 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int f = (j + r16) & 15;
+                const bool fv = f < na;
+                cj[a][j] = fv ? (ftab[32 + a * 16 + f] + (c4 & ((1 << (rot_sh - 3)) - 1))) * 8 : (spn_valid + c4) * 8;
+                rmask[a][j >> 2] |= fv ? (0xFFu << (8 * (j & 3))) : 0u;
+            }
+        }
+    }
 
     const int my_ring = wave < NRINGS ? wave : 0;               // (consumer waves never append)
     uint4* ring_rec = ring_rec_all + my_ring * MT_RING;
@@ -518,15 +566,36 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), c.sg), hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), c.sh);
             if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], 1);
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g) + li * spn8;
-            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-            const uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w};
+            uint32_t w[4] = {r.x, r.y, r.z, r.w};
+            uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w};
+            if (MT_ROT) {   // rotate the 16-byte record right by (lane mod 16) bytes: byte j of the result = byte (j + lane) mod 16 of the record
+                auto rot16 = [&](uint32_t (&x)[4], const uint32_t (&mk)[4]) __attribute__((always_inline)) {
+                    const bool d1 = (lane & 4) != 0, d2 = (lane & 8) != 0;
+                    const uint32_t a0 = d1 ? x[1] : x[0], a1 = d1 ? x[2] : x[1], a2 = d1 ? x[3] : x[2], a3 = d1 ? x[0] : x[3];
+                    const uint32_t b0 = d2 ? a2 : a0, b1 = d2 ? a3 : a1, b2 = d2 ? a0 : a2, b3 = d2 ? a1 : a3;
+                    const uint32_t sb = (uint32_t)(lane & 3);
+                    x[0] = __builtin_amdgcn_alignbyte(b1, b0, sb) & mk[0]; x[1] = __builtin_amdgcn_alignbyte(b2, b1, sb) & mk[1];
+                    x[2] = __builtin_amdgcn_alignbyte(b3, b2, sb) & mk[2]; x[3] = __builtin_amdgcn_alignbyte(b0, b3, sb) & mk[3];
+                };
+                rot16(w, rmask[0]);
+                if (ACC2) rot16(w1, rmask[NACC - 1]);
+            }
 #if defined(MT_DBL_ATOM)   /* timing experiment: twice the LDS atomics, same sums */
 #define MT_ATOMIC_ADD(p, v) { atomicAdd(p, (v) - 1ull); atomicAdd(p, 1ull); }
 #else
 #define MT_ATOMIC_ADD(p, v) atomicAdd(p, v)
 #endif
-#define MT_ATOM(A, W, j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[A][j] + (int)(((W[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << (int)((shp[A] >> (4 * (j))) & 15ull))); \
+#define MT_ATOM(A, W, j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[A][j] + (int)(((W[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << (MT_ROT ? rot_sh : (int)((shp[A] >> (4 * (j))) & 15ull)))); \
                            MT_ATOMIC_ADD(p_, gq); MT_ATOMIC_ADD(p_ + hdelta, hq); }
+            if (MT_ROT) {        // every lane has sixteen slots per chunk (absent ones go to its dummy slot)
+                MT_ATOM(0, w, 0); MT_ATOM(0, w, 1); MT_ATOM(0, w, 2); MT_ATOM(0, w, 3); MT_ATOM(0, w, 4); MT_ATOM(0, w, 5); MT_ATOM(0, w, 6); MT_ATOM(0, w, 7);
+                MT_ATOM(0, w, 8); MT_ATOM(0, w, 9); MT_ATOM(0, w, 10); MT_ATOM(0, w, 11); MT_ATOM(0, w, 12); MT_ATOM(0, w, 13); MT_ATOM(0, w, 14); MT_ATOM(0, w, 15);
+                if (ACC2) {
+                    MT_ATOM(NACC - 1, w1, 0); MT_ATOM(NACC - 1, w1, 1); MT_ATOM(NACC - 1, w1, 2); MT_ATOM(NACC - 1, w1, 3); MT_ATOM(NACC - 1, w1, 4); MT_ATOM(NACC - 1, w1, 5);
+                    MT_ATOM(NACC - 1, w1, 6); MT_ATOM(NACC - 1, w1, 7); MT_ATOM(NACC - 1, w1, 8); MT_ATOM(NACC - 1, w1, 9); MT_ATOM(NACC - 1, w1, 10); MT_ATOM(NACC - 1, w1, 11);
+                    MT_ATOM(NACC - 1, w1, 12); MT_ATOM(NACC - 1, w1, 13); MT_ATOM(NACC - 1, w1, 14); MT_ATOM(NACC - 1, w1, 15);
+                }
+            } else
             if (nfeat >= 15) {   // the common shapes (full chunk, or 15 features): no per-feature branches
                 MT_ATOM(0, w, 0); MT_ATOM(0, w, 1); MT_ATOM(0, w, 2); MT_ATOM(0, w, 3); MT_ATOM(0, w, 4); MT_ATOM(0, w, 5); MT_ATOM(0, w, 6); MT_ATOM(0, w, 7);
                 MT_ATOM(0, w, 8); MT_ATOM(0, w, 9); MT_ATOM(0, w, 10); MT_ATOM(0, w, 11); MT_ATOM(0, w, 12); MT_ATOM(0, w, 13); MT_ATOM(0, w, 14);
@@ -535,7 +604,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
 #pragma unroll
                 for (int j = 0; j < 14; ++j) if (j < nfeat) MT_ATOM(0, w, j);
             }
-            if (ACC2) {
+            if (!MT_ROT && ACC2) {
                 if (nfeat1 >= 15) {
                     MT_ATOM(NACC - 1, w1, 0); MT_ATOM(NACC - 1, w1, 1); MT_ATOM(NACC - 1, w1, 2); MT_ATOM(NACC - 1, w1, 3); MT_ATOM(NACC - 1, w1, 4); MT_ATOM(NACC - 1, w1, 5);
                     MT_ATOM(NACC - 1, w1, 6); MT_ATOM(NACC - 1, w1, 7); MT_ATOM(NACC - 1, w1, 8); MT_ATOM(NACC - 1, w1, 9); MT_ATOM(NACC - 1, w1, 10); MT_ATOM(NACC - 1, w1, 11);
@@ -1269,6 +1338,7 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
 // training row ends in its final speculative node, whose score delta the replay has tabulated.
 // grid (gx, K), block 256, 4 rows per thread.
 // ------------------------------------------------------------------------------------------------
+template <bool COUNT_ONLY /* only the exact row counts of the deepest children: the fused k_level_final_grad_* pass does the rest */>
 __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ rec, const uint8_t* __restrict__ node_all,
                                                      const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, const TreeOut out,
                                                      const double* __restrict__ node_delta, double* __restrict__ score, int32_t* __restrict__ count,
@@ -1281,6 +1351,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     if (out.L[(long long)it * c.K + k] <= 1) return;   // no split: no score change, nothing to count
     const LvPlan* pp = &plan[k];
     const bool route = !pp->done;                      // plan(max_depth) expanded at least one node
+    if (COUNT_ONLY && !route) return;                  // nothing is routed at the last level: nothing to count
     const int n_exp = route ? pp->n_exp : 0, child_first = pp->child_first;
     const int tid = threadIdx.x, lane = tid & 63;
     nd[tid] = node_delta[(long long)k * 256 + tid];
@@ -1294,6 +1365,42 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     // 4 rows per thread; node ids and scores are loaded together (independent loads), then routed and written back
     const bool aligned16 = (((unsigned long long)sk) & 15ull) == 0ull;   // uniform
     for (long long i = ((long long)blockIdx.x * 256 + tid) * 4; i < N; i += (long long)gridDim.x * 1024) {
+        if (COUNT_ONLY) {   // node ids only (1 B per row); rows outside the expanded parents of the last level cost nothing else
+            if (i + 3 < N) {
+                const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
+                if (n4 == 0xFFFFFFFFu) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = (int)((n4 >> (8 * j)) & 0xFFu);
+                    if (n == LV_INACTIVE) continue;
+                    const uint32_t w0 = route0[n];
+                    if (w0 & (1u << 24)) {
+                        const long long row = i + j;
+                        const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
+                        const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
+                        const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
+                        const uint32_t w1 = route1[n];
+                        const int ch = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
+                        if (!inbag || inbag[row]) atomicAdd(&cnt[(ch - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                    }
+                }
+                continue;
+            }
+            for (long long row = i; row < N && row < i + 4; ++row) {
+                const int n = node[row];
+                if (n == LV_INACTIVE) continue;
+                const uint32_t w0 = route0[n];
+                if (w0 & (1u << 24)) {
+                    const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
+                    const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
+                    const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
+                    const uint32_t w1 = route1[n];
+                    const int ch = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
+                    if (!inbag || inbag[row]) atomicAdd(&cnt[(ch - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                }
+            }
+            continue;
+        }
         if (i + 3 < N && aligned16) {
             const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
             double2 s01 = *reinterpret_cast<const double2*>(sk + i), s23 = *reinterpret_cast<const double2*>(sk + i + 2);
@@ -1339,6 +1446,201 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
         int tot = 0;
         for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
         if (tot) atomicAdd(&count[(long long)k * 256 + child_first + ci], tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The last pass of iteration i FUSED with the gradients of iteration i + 1 ("k_level_final and k_grad_mc both read the
+// K x N scores").  k_level_final reads node id + score and writes the score (17 B per (row, class tree)); the gradient kernel of the
+// next iteration reads the score again and writes (g, h) and the reset node id (17 B).  Fused, a score is read once, updated, written
+// once and turned into the next (g, h) while it is in a register / in the workgroup's LDS tile: 26 B instead of 34 B, one launch
+// instead of two.  Same arithmetic in the same order as k_level_final + k_grad_mc / k_grad_mc_rows / k_grad<OBJ> (the new score is
+// the double that k_level_final would have stored and the gradient kernel loaded), so every model stays bit-identical.
+//
+//   k_level_fin_table         one 32-byte entry per (class tree, node id): what a row sitting in that node needs -- the last routing step
+//                             (feature, threshold, NaN bin, default direction) and the score delta on either side.
+//   k_level_final<true>       the exact row counts of the deepest children (Tree::leaf_count_) stay a pass of their own: it reads the
+//                             node ids only (1 B per (row, class tree)) and returns at once for a class tree that routes nothing at the
+//                             last level.  (First cut: leaf counters in the LDS of persistent workgroups of the fused kernel -- those
+//                             held 3 x 43 KB of every CU's LDS for the whole launch, the level passes of the other targets in flight
+//                             could not start next to them, and the bench step went from 84.6 to 89.1 ms.)
+//   k_level_final_grad_mc     softmax, 16 <= K <= 112: k_grad_mc's layout (64 rows x 4 class-slice waves, K x 64 score tile in LDS)
+//   k_level_final_grad_rows   thread per row: binary / L2 (one class tree) and softmax with K < 16
+// Not used with bagging (the bag of iteration i + 1 is drawn between the two halves) nor for the last iteration.
+// ------------------------------------------------------------------------------------------------
+struct FinEntry {
+    uint32_t w0;          // feature | (theta+1) << 8 | nan bin << 16 | expanded << 24 | default-left << 25   (0: the node is not routed)
+    uint32_t skip;        // the class tree has no split: its scores do not change at all
+    double dl, dr;        // score delta of a row that ends on the left / right side (not routed: both = the node's own delta)
+    double pad2;
+};
+static_assert(sizeof(FinEntry) == 32, "one 16-byte gather per (row, class tree) + 8 more bytes for the rows that are routed to the right");
+
+__global__ __launch_bounds__(256) void k_level_fin_table(const LvPlan* __restrict__ plan, const TreeOut out, const double* __restrict__ node_delta,
+                                                         FinEntry* __restrict__ fin /* [K][256] */, const int32_t* __restrict__ itp, LevelConst c) {
+    const int k = blockIdx.x, n = threadIdx.x;
+    const int L = out.L[(long long)(*itp) * c.K + k];
+    const LvPlan* pp = &plan[k];
+    FinEntry e; e.w0 = 0u; e.skip = 0u; e.dl = 0.0; e.dr = 0.0; e.pad2 = 0.0;
+    if (L <= 1) e.skip = 1u;
+    else {
+        const uint32_t w0 = pp->done ? 0u : pp->route0[n];      // plan(max_depth) expanded nothing: no routing step
+        const uint32_t w1 = pp->route1[n];
+        const double* nd = node_delta + (long long)k * 256;
+        if (w0 & (1u << 24)) { e.w0 = w0; e.dl = nd[w1 & 0xFFu]; e.dr = nd[(w1 >> 8) & 0xFFu]; }
+        else { e.dl = nd[n]; e.dr = e.dl; }
+    }
+    fin[(long long)k * 256 + n] = e;
+}
+
+// The classes of a step are worked in chunks of FIN_CH: all node ids and scores of a chunk are requested first, then all table entries,
+// then the (rare) record bytes -- three memory round trips per chunk instead of two per class (a first cut with one class after the
+// other was SLOWER than the two kernels it replaces).  An entry's first 16 bytes -- routing word, skip flag, left delta -- are gathered
+// for every (row, class tree); the right delta only by the rows whose node IS routed and that go right.
+constexpr int FIN_CH = 8;
+struct FinHead { uint32_t w0, skip; double dl; };
+__device__ __forceinline__ FinHead fin_head(const FinEntry* __restrict__ fin, long long idx) {
+    const uint4 q = reinterpret_cast<const uint4*>(fin)[idx * 2];
+    FinHead h; h.w0 = q.x; h.skip = q.y; h.dl = __hiloint2double((int)q.w, (int)q.z);
+    return h;
+}
+__device__ __forceinline__ double fin_route(const FinHead& e, const FinEntry* __restrict__ fin, long long idx, const uint8_t* __restrict__ rec8, long long N, long long row) {
+    double d = e.dl;
+    if (e.w0 & (1u << 24)) {
+        const int f = (int)(e.w0 & 0xFFu), theta1 = (int)((e.w0 >> 8) & 0xFFu), nanbin = (int)((e.w0 >> 16) & 0xFFu);
+        const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
+        const bool left = (bin == nanbin) ? ((e.w0 >> 25) & 1u) != 0u : (bin < theta1);
+        if (!left) d = fin[idx].dr;
+    }
+    return d;
+}
+
+// softmax, 16 <= K <= 112.  grid: one workgroup per 64 rows; dynamic LDS = (K * 64 + 320) * 8.
+__global__ __launch_bounds__(256) void k_level_final_grad_mc(const uint4* __restrict__ rec, uint8_t* __restrict__ node_all, const FinEntry* __restrict__ fin,
+                                                             double* __restrict__ score, const int32_t* __restrict__ ycol, const double* __restrict__ class_w,
+                                                             const double* __restrict__ sample_w, float2* __restrict__ gh, LevelConst lc, TrainConst c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* tile = reinterpret_cast<double*>(smem);          // [K][64]
+    double* pmax = tile + (size_t)c.K * 64;                  // [4][64]
+    double* psum = pmax + 256;                               // [64]
+    const long long N = c.N, NS = lc.NS;
+    // (wv through readfirstlane: the class k of a step is then a scalar for the compiler, and so is every per-class base address)
+    const int K = c.K, r = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
+    const long long i = (long long)blockIdx.x * 64 + r;
+    const bool valid = i < N;
+    const long long ic = valid ? i : N - 1;
+    const int y = ycol[ic];
+    double m = -INFINITY;
+    for (int k0 = wv; k0 < K; k0 += 4 * FIN_CH) {
+        int nn[FIN_CH]; double vv[FIN_CH]; FinHead ee[FIN_CH];
+#pragma unroll
+        for (int u = 0; u < FIN_CH; ++u) {
+            const int k = k0 + 4 * u, kc = k < K ? k : k0;
+            nn[u] = (int)(node_all + (long long)kc * NS)[(unsigned)ic];        // scalar base + 32-bit row offset (the host keeps N below 2^28 here)
+            vv[u] = (score + (long long)kc * N)[(unsigned)ic];
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_CH; ++u) {
+            const int k = k0 + 4 * u, kc = k < K ? k : k0;
+            if (!(valid && k < K)) nn[u] = LV_INACTIVE;
+            ee[u] = fin_head(fin + (long long)kc * 256, (long long)(unsigned)(nn[u] != LV_INACTIVE ? nn[u] : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_CH; ++u) {
+            const int k = k0 + 4 * u;
+            if (k < K) {     // (uniform)
+                double v = vv[u];
+                if (nn[u] != LV_INACTIVE) {
+                    const double d = fin_route(ee[u], fin, (long long)k * 256 + nn[u], rec8, N, i);
+                    if (!ee[u].skip) { v += d; score[(long long)k * N + i] = v; }
+                    if (nn[u] != 0) node_all[(long long)k * NS + i] = 0;          // every training row restarts in the root
+                }
+                tile[k * 64 + r] = v; if (v > m) m = v;
+            }
+        }
+    }
+    pmax[wv * 64 + r] = m;
+    __syncthreads();
+    double wmax = pmax[r];
+    { const double b1 = pmax[64 + r], b2 = pmax[128 + r], b3 = pmax[192 + r]; if (b1 > wmax) wmax = b1; if (b2 > wmax) wmax = b2; if (b3 > wmax) wmax = b3; }
+    for (int k = wv; k < K; k += 4) tile[k * 64 + r] = rg_exp(tile[k * 64 + r] - wmax);
+    __syncthreads();
+    if (wv == 0) { double wsum = 0.0; for (int k = 0; k < K; ++k) wsum += tile[k * 64 + r]; psum[r] = wsum; }
+    __syncthreads();
+    if (!valid || y < 0) return;    // not a training row: its gh stays 0 for ever
+    double wi = class_w ? class_w[y] : 1.0;
+    if (sample_w) wi = wi * sample_w[i];
+    wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
+    const double wsum = psum[r];
+    for (int k = wv; k < K; k += 4) {
+        const double pk = tile[k * 64 + r] / wsum;
+        store_gh(gh, (long long)k * c.NG + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
+    }
+}
+
+// thread per row: binary (OBJ 0) / L2 (OBJ 2) with one class tree, softmax (OBJ 1) with K < 16 (the row's K scores parked in its own LDS
+// column, as k_grad_mc_rows).  grid: one workgroup per R rows; dynamic LDS = OBJ == 1 ? K * R * 8 : 0.
+template <int OBJ, int R>
+__global__ __launch_bounds__(R) void k_level_final_grad_rows(const uint4* __restrict__ rec, uint8_t* __restrict__ node_all, const FinEntry* __restrict__ fin,
+                                                             double* __restrict__ score, const int32_t* __restrict__ ycol, const double* __restrict__ y_value,
+                                                             const double* __restrict__ class_w, const double* __restrict__ sample_w, float2* __restrict__ gh,
+                                                             LevelConst lc, TrainConst c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = (OBJ == 1) ? c.K : 1;
+    double* tile = reinterpret_cast<double*>(smem) + threadIdx.x;                                         // element k at tile[k * R]  (OBJ 1)
+    const long long N = c.N, NS = lc.NS;
+    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
+    const long long i = (long long)blockIdx.x * R + threadIdx.x;
+    if (i >= N) return;
+    const int y = ycol[i];
+    double wmax = -INFINITY, s0 = 0.0;
+    for (int k0 = 0; k0 < K; k0 += FIN_CH) {
+        int nn[FIN_CH]; double vv[FIN_CH]; FinHead ee[FIN_CH];
+#pragma unroll
+        for (int u = 0; u < FIN_CH; ++u) {
+            const int kc = k0 + u < K ? k0 + u : k0;
+            nn[u] = (int)node_all[(long long)kc * NS + i];
+            vv[u] = score[(long long)kc * N + i];
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_CH; ++u) {
+            const int kc = k0 + u < K ? k0 + u : k0;
+            if (k0 + u >= K) nn[u] = LV_INACTIVE;
+            ee[u] = fin_head(fin, (long long)kc * 256 + (nn[u] != LV_INACTIVE ? nn[u] : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_CH; ++u) {
+            const int k = k0 + u;
+            if (k < K) {
+                double v = vv[u];
+                if (nn[u] != LV_INACTIVE) {
+                    const double d = fin_route(ee[u], fin, (long long)k * 256 + nn[u], rec8, N, i);
+                    if (!ee[u].skip) { v += d; score[(long long)k * N + i] = v; }
+                    if (nn[u] != 0) node_all[(long long)k * NS + i] = 0;
+                }
+                if (OBJ == 1) { tile[k * R] = v; if (v > wmax) wmax = v; } else s0 = v;
+            }
+        }
+    }
+    if (y < 0) return;            // not a training row: its gh stays 0 for ever
+    double wi = class_w ? class_w[y] : 1.0;
+    if (sample_w) wi = wi * sample_w[i];
+    wi = (double)(float)wi;       // LightGBM Metadata keeps weights as float32
+    if (OBJ == 0) {               // binary_objective.hpp GetGradients (sigmoid = 1, label_weight = 1)
+        const double label = (y > 0) ? 1.0 : -1.0;
+        const double response = -label / (1.0 + rg_exp(label * s0));
+        const double abs_r = fabs(response);
+        store_gh(gh, i, response * wi, abs_r * (1.0 - abs_r) * wi);
+    } else if (OBJ == 2) {        // RegressionL2loss::GetGradients
+        store_gh(gh, i, (s0 - y_value[y]) * wi, wi);
+    } else {
+        double wsum = 0.0;
+        for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
+        for (int kk = 0; kk < K; ++kk) {
+            const double pk = tile[kk * R] / wsum;
+            store_gh(gh, (long long)kk * c.NG + i, ((y == kk) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
+        }
     }
 }
 

@@ -306,3 +306,30 @@ def test_sparse_sweep_of_the_level_pass_changes_nothing(rows, cols, tgt, monkeyp
             blobs.append(N.train(X, cards[feats], y, K, class_weight=balanced_weights(y, K), objective=0 if K == 2 else 1, num_class=max(K, 2),
                                  n_estimators=14, learning_rate=0.2, **kw).save())
         assert blobs[0] == blobs[1], kw
+
+
+@pytest.mark.parametrize("rows,cols,tgt", [(600, 4, 2), (30000, 11, 10), (30000, 11, 5), (50000, 6, 0)])
+def test_last_pass_fused_with_the_next_gradients_changes_nothing(rows, cols, tgt, monkeypatch):
+    """k_level_final_grad_* (RGBM_FUSE_GRAD, default on): the last routing step + score update of iteration i and the gradients of
+    iteration i + 1 in one pass.  Same arithmetic in the same order as k_level_final + the gradient kernel, so the model bytes (leaf
+    counts included: the fused pass only counts rows that end in leaves of the finished tree) must not depend on it -- softmax with
+    K = 64 (the 64-rows x 4-waves layout) and K = 4 / 12 (thread per row), binary, L2 regression, with NULL target cells in the table
+    (rows that never take part), deep trees whose last level is routed, and one-iteration / two-iteration jobs (first and last
+    iteration are the unfused forms)."""
+    from repair import _native as N
+    from tests.synth import make_table, balanced_weights
+    dirty, clean, cards = make_table(rows, cols, seed=31, null_ratio=0.03)
+    feats = [c for c in range(cols) if c != tgt]
+    K = int(cards[tgt])
+    tab = N.Table(dirty, cards)
+    yv = np.arange(K, dtype=np.float64) * 0.75 - 1.0
+    cases = [dict(objective=0 if K == 2 else 1, num_class=max(K, 2), class_weight=balanced_weights(dirty[tgt], K), n_estimators=9, learning_rate=0.2),
+             dict(objective=0 if K == 2 else 1, num_class=max(K, 2), class_weight=None, n_estimators=2, num_leaves=90, min_data_in_leaf=2),
+             dict(objective=0 if K == 2 else 1, num_class=max(K, 2), class_weight=None, n_estimators=1),
+             dict(objective=2, y_value=yv, class_weight=None, n_estimators=7, learning_rate=0.3, num_leaves=50, min_data_in_leaf=5)]
+    for kw in cases:
+        blobs = []
+        for v in ("0", "1"):
+            monkeypatch.setenv("RGBM_FUSE_GRAD", v)
+            blobs.append(tab.train(tgt, feats, **kw).save())
+        assert blobs[0] == blobs[1], {k: v for k, v in kw.items() if k not in ("class_weight", "y_value")}
