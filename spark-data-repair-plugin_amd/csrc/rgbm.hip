@@ -415,7 +415,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // instead of one pass that accumulates both), RGBM_MT_SPEC=0|1 (wave-specialised level pass), RGBM_MT_SPARSE=0 (no sparse sweep: class trees
 // with few live rows are walked tile by tile like the others).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -430,6 +430,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_SPEC")) w.mt_spec = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RGBM_MT_SPARSE")) w.mt_sparse = atoi(e) != 0;
     if (const char* e = getenv("RGBM_FUSE_GRAD")) w.fuse_grad = atoi(e) != 0;
+    if (const char* e = getenv("RGBM_MT_LOCK")) w.mt_lock = atoi(e);
     w.timing = getenv("RGBM_TIMING") != nullptr;
     return w;
 }
@@ -757,6 +758,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<uint8_t> d_node; DevBuf<LvPlan> d_plan; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
     DevBuf<FinEntry> d_fin;   // fused last pass + next gradients (k_level_final_grad_*)
+    DevBuf<uint32_t> d_prog; uint32_t mt_epoch = 0;   // lock-step progress words of the wave-specialised level pass: [row blocks][tree groups]
     bool fuse_grad = false; size_t fuse_lds = 0; int fuse_grid = 1;
     int n_hnodes = 1;
     bool use_reduce = false;   // root pass: sum the per-workgroup partials in a separate kernel (many workgroups per class tree, joint bins, or row-sharded)
@@ -856,6 +858,11 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             mt_gx[level] = (int)gx;
             for (auto& L : mt_plan[level]) L.gx = (int)gx;
             part_items = std::max(part_items, (size_t)K * (size_t)gx * (size_t)worst);
+        }
+        {
+            size_t prog_words = 0;
+            for (int level = 1; level < p.max_depth; ++level) for (const auto& L : mt_plan[level]) prog_words = std::max(prog_words, (size_t)L.G * (size_t)L.gx);
+            d_prog.alloc(std::max<size_t>(prog_words, 1)); d_prog.zero(s);
         }
         d_node.alloc((size_t)K * lc.NS);
         d_plan.alloc(K); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
@@ -1033,13 +1040,15 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         for (const MtLaunch& L : mt_plan[level]) {
             LevelConst l1 = ll;
             l1.mt_T = L.T; l1.mt_G = L.G; l1.mt_ch = L.ch; l1.mt_slot0 = L.slot0; l1.mt_nslots = L.nslots; l1.mt_route = L.route; l1.mt_sparse = sw.mt_sparse ? 1 : 0;
+            // lock-step of the class-tree groups of a row block (wave-specialised pass): window in tile rounds, one round = 8 wave tiles of records
+            l1.mt_window = sw.mt_lock < 0 ? 0 : sw.mt_lock;     // off by default: measured -63 % HBM fetch and +23 % time (profiles/r5e_*): the pass is not bound by that traffic l1.mt_epoch = (mt_epoch++ % 4095u) + 1u;      // (never 0: the words start zeroed)
             const dim3 grid((unsigned)L.G * (unsigned)L.gx);
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
 #define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, SPEC) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, SPEC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, l1); \
+                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, l1); \
                                            else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, SPEC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, l1); } while (0)
+                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, l1); } while (0)
 #define RGBM_LAUNCH_MT(NCHR, THR, ACC, SPEC) do { if (use_bagging) RGBM_LAUNCH_MT2(NCHR, true, d_inbag.p, THR, ACC, SPEC); else RGBM_LAUNCH_MT2(NCHR, false, nullptr, THR, ACC, SPEC); } while (0)
                 if (L.acc2) { if (sw.mt_spec != 0) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true); else RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, false); }
                 else if (nchr == 1 && sw.mt_spec == 1) RGBM_LAUNCH_MT(1, LV_THREADS, false, true);

@@ -62,6 +62,7 @@ constexpr int MT_THREADS_ACC2 = 768;
 #ifndef MT_CONSUMERS_N
 #define MT_CONSUMERS_N 4
 #endif
+constexpr int MT_LOCK_EVERY = 4;              // lock-step: tile rounds between two looks at the row block's progress words
 constexpr int MT_CONSUMERS = MT_CONSUMERS_N;              // wave-specialised pass: consumer waves of a workgroup (one per SIMD)         // workgroup of a two-chunk pass: 12 waves with 168 VGPRs each (two records per row stay in registers), a third less ring
 
 struct SNode {   // speculative node of one class tree
@@ -91,7 +92,9 @@ struct LevelConst {
     int32_t xcd_blocks;          // root pass: 1-D grid of K * gx blocks, contiguous row blocks, all class trees of a row block on one XCD
     // k_level_mt launch: class trees per workgroup, tree groups, chunk whose features are accumulated, built-slot window, routing?
     int32_t mt_T, mt_G, mt_ch, mt_slot0, mt_nslots, mt_route;
-    int32_t mt_sparse, mt_pad;   // 1: class trees with few live rows are swept through their node ids (k_level_mt, plain single-chunk pass)
+    int32_t mt_sparse, mt_window;   // mt_sparse 1: class trees with few live rows are swept through their node ids (k_level_mt, plain single-chunk pass);
+                                    // mt_window > 0: the class-tree groups of a row block walk it in step (wave-specialised pass, see "lock-step")
+    uint32_t mt_epoch, mt_pad;      // lock-step: tag of this launch in the progress words
     long long N, NS, NG;         // rows; row stride of the node-id arrays and of the (g, h) arrays (both N rounded up to a whole wave tile of 256 rows)
     double sg, sh;               // 2^e_g, 2^e_h: float32 (g, h) -> fixed point (fx_from_f32)
 };
@@ -328,7 +331,8 @@ template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers),
 __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
                                                          const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                          int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
-                                                         int32_t* __restrict__ err_flag, LevelConst c) {
+                                                         int32_t* __restrict__ err_flag, uint32_t* __restrict__ prog /* [row blocks][tree groups] lock-step progress words (SPEC), or null */,
+                                                         LevelConst c) {
     static_assert(!ACC2 || NCHR == 2, "a two-chunk pass keeps both records in registers");
     constexpr int WAVES = THREADS / 64;
     constexpr int NCONS = SPEC ? MT_CONSUMERS : 0, NPROD = WAVES - NCONS;     // waves that walk the rows / waves that only run batches
@@ -797,7 +801,38 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             load_tree(wt_c, kk_c, n4_a, ga0, ga1);
             load_tree(wt_b, kk_b, n4_b, gb0, gb1);
             lookup(n4_a, tree_entry(kk_c), row_mask(wt_c), e_a, in_a);
+            // ---- lock-step of the class-tree groups of a row block (round 5).  Every group's workgroup reads the block's bin records; they
+            // run on one XCD at the same time (launch order), but nothing keeps them at the same place: on the 100M x 32 shape the groups
+            // drifted further apart than the XCD's 4 MB L2 holds and a level pass moved 25.5 GB for 8.3 GB of (node id, g, h) stream and
+            // 3.2 GB of records (profiles/traffic.json, round 4).  Now wave 0 of a workgroup publishes the tile round it is in (a word per
+            // (row block, group), tagged with the launch's epoch), and every producer wave looks at the block's words every MT_LOCK_EVERY
+            // rounds: it sleeps while the slowest group that HAS STARTED in this launch and has not finished is more than mt_window rounds
+            // behind.  The slowest started group never waits, so the wait ends; a group that is not resident yet is not waited for.
+            const bool lock = c.mt_window > 0 && prog != nullptr && c.mt_G > 1;
+            uint32_t* prog_rb = prog + (size_t)rb * (size_t)c.mt_G;
+            const uint32_t ep_tag = c.mt_epoch << 20;
             for (long long q = 0; q < Q; ++q) {
+                if (lock && kk_c == 0) {
+                    const uint32_t round = (uint32_t)((wt_c - my_first) / NPROD);
+                    if ((round & (MT_LOCK_EVERY - 1)) == 0u) {
+                        if (wave == 0 && lane == 0) __hip_atomic_store(prog_rb + grp, ep_tag | (round < 0xFFFFEu ? round + 1u : 0xFFFFEu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int spin = 0; spin < 4096; ++spin) {        // (bounded: a lost update can cost time, never the pass)
+                            uint32_t slow = 0xFFFFFFFFu;
+                            for (int g0 = 0; g0 < c.mt_G; g0 += 64) {
+                                uint32_t v = 0xFFFFFFFFu;
+                                if (g0 + lane < c.mt_G) {
+                                    const uint32_t w = __hip_atomic_load(prog_rb + g0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if ((w >> 20) == c.mt_epoch && (w & 0xFFFFFu) != 0xFFFFFu) v = w & 0xFFFFFu;     // started in this launch, not finished
+                                }
+#pragma unroll
+                                for (int o = 32; o >= 1; o >>= 1) { const uint32_t v2 = (uint32_t)__shfl_xor((int)v, o); v = v2 < v ? v2 : v; }
+                                slow = v < slow ? v : slow;
+                            }
+                            if (slow == 0xFFFFFFFFu || round + 1u <= slow + (uint32_t)c.mt_window) break;
+                            __builtin_amdgcn_s_sleep(32);
+                        }
+                    }
+                }
                 load_rec(wt_b, rn, r1n, bag_n);                                        // stage R
                 load_tree(wt_a, kk_a, n4_c, gc0, gc1);                                 // stage A
                 lookup(n4_b, tree_entry(kk_b), row_mask(wt_b), e_b, in_b);             // stage B
@@ -923,7 +958,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             }
         }
     }
-    if (SPEC) { if (wave < NPROD) { asm volatile("" ::: "memory"); if (lane == 0) { RS_STORE(wave, p_tail); asm volatile("" ::: "memory"); RS_STORE(32 + wave, 1u); } } }
+    if (SPEC) { if (wave < NPROD) { asm volatile("" ::: "memory"); if (lane == 0) { RS_STORE(wave, p_tail); asm volatile("" ::: "memory"); RS_STORE(32 + wave, 1u); } }
+                if (c.mt_window > 0 && prog != nullptr && wave == 0 && lane == 0)      // lock-step: this group is done with the block (nobody waits for it any more)
+                    __hip_atomic_store(prog + (size_t)rb * (size_t)c.mt_G + grp, (c.mt_epoch << 20) | 0xFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #undef RS_LOAD
 #undef RS_STORE
     else while (r_cnt > 0) run_batch(r_cnt < 64 ? r_cnt : 64);
