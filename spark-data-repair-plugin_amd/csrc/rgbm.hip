@@ -1041,7 +1041,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             LevelConst l1 = ll;
             l1.mt_T = L.T; l1.mt_G = L.G; l1.mt_ch = L.ch; l1.mt_slot0 = L.slot0; l1.mt_nslots = L.nslots; l1.mt_route = L.route; l1.mt_sparse = sw.mt_sparse ? 1 : 0;
             // lock-step of the class-tree groups of a row block (wave-specialised pass): window in tile rounds, one round = 8 wave tiles of records
-            l1.mt_window = sw.mt_lock < 0 ? 0 : sw.mt_lock;     // off by default: measured -63 % HBM fetch and +23 % time (profiles/r5e_*): the pass is not bound by that traffic l1.mt_epoch = (mt_epoch++ % 4095u) + 1u;      // (never 0: the words start zeroed)
+            // off by default: measured -63 % HBM fetch and +23 % time on 100M x 32 (profiles/r5e_*): the pass is not bound by that traffic
+            l1.mt_window = sw.mt_lock < 0 ? 0 : sw.mt_lock;
+            l1.mt_epoch = (mt_epoch++ % 4095u) + 1u;      // (never 0: the words start zeroed)
             const dim3 grid((unsigned)L.G * (unsigned)L.gx);
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
