@@ -600,7 +600,11 @@ void fit_setup(const rgbm_table& tab, const double* y_value_in, const double* cl
     // fixed-point grid of the histogram sums (numerics v2.1, rgbm_numerics.h): |g_i| <= (bound_g / w_max) * w_i and h_i <= (bound_h / w_max) * w_i
     // hold for every row i, so with e = min(50 - ceil_log2(bound), 62 - ceil_log2(bound * sum_w / w_max)) every converted value is at most
     // 2^50 in magnitude (the range of the rint trick) and an int64 sum over all training rows (of all ranks) stays below 2^62
-    int e_g = rg::fx_exponent(bound_g, sumw / w_max), e_h = rg::fx_exponent(bound_h, sumw / w_max);
+    double wr = sumw / w_max;
+    // test hook (tools/numerics_scale.py; the oracle reads the same variable): RGBM_FX_ROWS = R sizes the grid as if the table held R training rows with
+    // this table's weight distribution -- the grid a 10M / 100M-row table of this kind gets, on a table that trains in seconds
+    if (const char* ev = std::getenv("RGBM_FX_ROWS")) { const double R = std::atof(ev); if (R > (double)n_train && n_train > 0) wr *= R / (double)n_train; }
+    int e_g = rg::fx_exponent(bound_g, wr), e_h = rg::fx_exponent(bound_h, wr);
     // test hook (tests/test_numerics_bound.py; the oracle reads the same variable): RGBM_FX_E = E caps the grid at E bits for a value equal to
     // the bound -- what a table of 2^(62 - E) equally weighted rows gets (E = 38: 10M rows, E = 35: 100M rows) -- on a table of any size
     if (const char* ev = std::getenv("RGBM_FX_E")) {
