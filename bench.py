@@ -49,7 +49,7 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(cols, seed, targets, steps_full, budget_s=25.0, full_rows=0, full_iters=5):
+def cpu_baseline(cols, seed, targets, steps_full, budget_s=25.0, full_rows=0, full_iters=20, cells_full=0):
     """CPU legs on a bounded sample of the same workload, timed on this box's host cores.
 
     "port": oracle/rgbm_oracle.c, the plain-C restatement of the LightGBM 3.3.1 path (the real Spark + LightGBM stack cannot be
@@ -119,26 +119,46 @@ def cpu_baseline(cols, seed, targets, steps_full, budget_s=25.0, full_rows=0, fu
                                  "scaled by iterations x%.1f and by their %.0f %% share of the class trees" % (done, t_fit, t_pred, iters, steps_full, scale, 100 * share))
     except Exception as e:  # noqa: BLE001 - the secondary leg never fails the bench
         out["hgb"] = dict(value=None, error=str(e))
-    # ---- one target at FULL size (hygiene): the binary target c0 of the whole table, a few boosting iterations, every core
-    # the feature-parallel histograms can use -- unscaled, next to the GPU's time for the same target and iteration count
+    # ---- two targets at FULL size, unscaled rows: the binary target and a K = 8 one on the whole table, binning + `full_iters`
+    # boosting iterations each, every core the feature-parallel histograms can use; from their per-iteration times an estimate of the whole job
+    # whose only scaling is over class trees and iterations (cost per (row, class tree, iteration) is what both fits measure)
     try:
         if full_rows and full_rows * cols <= 400_000_000:
             fd, _, fcards = make_table(full_rows, cols, seed=seed)
-            t = targets[0]
-            r = fd[t] >= 0
-            K = int(fcards[t])
-            cw = balanced_class_weight(np.bincount(fd[t][r], minlength=K))
-            Xf = np.ascontiguousarray(fd[feats_of[t]][:, r]); yf = fd[t][r]
+            want = [targets[0]] + [t for t in targets if int(fcards[t]) >= 8][:1]
+            fits, thr = [], min(nproc, 64)
+            O.lib().orc_set_threads(thr)
+            for t in want:
+                r = fd[t] >= 0
+                K = int(fcards[t])
+                cw = balanced_class_weight(np.bincount(fd[t][r], minlength=K))
+                Xf = np.ascontiguousarray(fd[feats_of[t]][:, r]); yf = fd[t][r]
+                kw = dict(class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), **BASE_PARAMS)
+                t0 = time.perf_counter()
+                O.train(Xf, fcards[feats_of[t]], yf, K, n_estimators=1, **kw)                 # binning + one iteration: the set-up share
+                t_one = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                O.train(Xf, fcards[feats_of[t]], yf, K, n_estimators=full_iters, **kw)
+                dt = time.perf_counter() - t0
+                per_it = max(dt - t_one, 1e-9) / max(full_iters - 1, 1)
+                fits.append(dict(target="c%d (K=%d)" % (t, K), class_trees=1 if K == 2 else K, rows=int(r.sum()), iterations=full_iters, train_sec=dt,
+                                 setup_and_first_iteration_sec=t_one, sec_per_iteration=per_it))
+                del Xf, yf
             del fd
-            O.lib().orc_set_threads(min(nproc, 64))
-            t0 = time.perf_counter()
-            O.train(Xf, fcards[feats_of[t]], yf, K, class_weight=cw, objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=full_iters, **BASE_PARAMS)
-            dt = time.perf_counter() - t0
             O.lib().orc_set_threads(1)
-            out["full_size_target"] = dict(target="c%d (K=%d)" % (t, K), rows=int(r.sum()), iterations=full_iters, train_sec=dt, threads=min(nproc, 64),
-                                           note="binning + %d boosting iterations of ONE target model on the whole table, not scaled" % full_iters)
+            out["full_size_target"] = dict(fits[0], threads=thr, note="binning + %d boosting iterations of ONE target model on the whole table, not scaled" % full_iters)
+            out["full_size_targets"] = fits
+            if len(fits) > 1:
+                trees_job = sum(1 if int(cards[t]) <= 2 else int(cards[t]) for t in targets)
+                per_tree_it = fits[-1]["sec_per_iteration"] / fits[-1]["class_trees"]          # the multiclass fit: a class tree's iteration on all rows
+                est = trees_job * per_tree_it * steps_full + sum(f["setup_and_first_iteration_sec"] for f in fits) / len(fits) * len(targets)
+                out["full_size_estimate"] = dict(value=cells_full / est if cells_full else None, unit="repaired cells/sec", job_sec=est, threads=thr,
+                                                 how="whole-table fits of %s, one after another on %d threads; job = %d class trees x %d iterations x %.3f s per class-tree iteration "
+                                                     "+ set-up per target; rows NOT scaled -- the figure the GPU/CPU ratio should be read against (the 250 000-row sample above "
+                                                     "amortises the split search worse and keeps the histograms in cache)" % (", ".join(f["target"] for f in fits), thr, trees_job, steps_full, per_tree_it))
     except Exception as e:  # noqa: BLE001
         out["full_size_target"] = dict(error=str(e))
+    out["read_the_gpu_cpu_ratio_against"] = "full_size_estimate (whole-table fits, rows not scaled)" if "full_size_estimate" in out else "value (250 000-row sample, scaled)"
     return out
 
 
@@ -180,6 +200,8 @@ def main():
     ap.add_argument("--no-full-job", action="store_true", help="do not run the 300-iteration job when --steps differs from 300")
     ap.add_argument("--mode", choices=["auto", "targets"], default="auto", help="multi-GPU split: auto = hybrid row/target sharding")
     ap.add_argument("--force-row-sharding", action="store_true", help="testing: run the collective (RCCL) path with a world of one")
+    ap.add_argument("--row-shard-all", action="store_true", help="testing, with --force-row-sharding: EVERY target takes the collective path (what a rank of the "
+                                                                  "shard-only multi-GPU job does; with --rows 12500000 --config 100m32 this is one rank's share of the 8-GPU job)")
     ap.add_argument("--roofline-steps", type=int, default=20, help="boosting iterations of the sequential pass that measures the kernel roofline")
     ap.add_argument("--concurrency", type=int, default=None, help="target models trained at once per rank (default: RGBM_TARGET_CONCURRENCY or 6)")
     ap.add_argument("--train-rows", type=int, default=0,
@@ -212,7 +234,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("RGBM_COMM_TIMEOUT_S", "180")   # a peer that died inside a collective fails this rank after 3 min, not 10
-        dist.init_process_group("gloo" if share_gpu else "nccl", rank=rank, world_size=world)
+        import datetime
+        # every wait of the job is bounded: torch's collectives by this timeout, librepairgbm's by RGBM_COMM_TIMEOUT_S (its watchdog aborts the
+        # communicator and the call raises) -- a rank that is gone ends the job with an error line, not with a hang
+        dist.init_process_group("gloo" if share_gpu else "nccl", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("BENCH_DIST_TIMEOUT_S", "900"))))
 
     from repair import dist as rdist
     from repair.engine import HipEngine, run_job, model_params, balanced_class_weight
@@ -227,99 +253,118 @@ def main():
     # generator draws the chunks that overlap the range), every target is trained row-sharded over all ranks (integer all-reduce of
     # histograms: same models as on one GPU), the rank repairs the dirty rows of its shard and the repaired cells are all-gathered.
     # No rank ever holds the 12.8 GB table.  (Decided collectively: it needs the RCCL communicator on every rank.)
-    shard_only, row_base = False, 0
+    shard_only = False
     if world > 1 and a.mode == "auto" and rows * cols > 400_000_000 and not (0 < a.train_rows < rows):
         shard_only = bool(rdist.init_row_comm(local_rank))
-    # ---- inputs (outside the timed region: detector + encoder outputs, resident in HBM)
-    t_gen = time.perf_counter()
-    if shard_only:
-        row_base, c0 = rdist.shard_rows(rows, world, rank)
-        dirty, null_truth, cards = make_table_parallel(rows, cols, seed=cfg["seed"], threads=max(1, min(32, os.cpu_count() or 1) // max(1, min(world, 8))),
-                                                       row_range=(row_base, row_base + c0))
-    elif rows * cols > 400_000_000:
-        dirty, null_truth, cards = make_table_parallel(rows, cols, seed=cfg["seed"], threads=min(32, os.cpu_count() or 1) // max(1, min(world, 4)) or 1)
-    else:
-        dirty, clean, cards = make_table(rows, cols, seed=cfg["seed"])
-        null_truth = {t: (np.flatnonzero(dirty[t] < 0), clean[t][dirty[t] < 0]) for t in targets}
-        del clean
-    t_gen = time.perf_counter() - t_gen
-    dirty_mask = (dirty[targets] < 0).any(axis=0)
-    dirty_pos = np.flatnonzero(dirty_mask) + row_base                    # positions in the whole table
-    dirty_rows = np.ascontiguousarray(dirty[:, dirty_mask])
-    n_cells = int((dirty_rows[targets] < 0).sum())
-    n_dirty_rows = int(dirty_rows.shape[1])
-    if shard_only:
-        n_cells, n_dirty_rows = int(rdist.sum_over_ranks(n_cells)), int(rdist.sum_over_ranks(n_dirty_rows))
+    # ---- inputs (outside the timed region: detector + encoder outputs, resident in HBM) + the warm-up fits
     eng = HipEngine(device_id=local_rank)
-    train_src = dirty
-    if 0 < a.train_rows < rows:
-        sel = np.sort(np.random.Generator(np.random.PCG64(7)).choice(rows, a.train_rows, replace=False))
-        train_src = np.ascontiguousarray(dirty[:, sel])
-    label_counts = {t: np.bincount(train_src[t][train_src[t] >= 0], minlength=int(cards[t])) for t in targets}
-    if shard_only:
-        label_counts = {t: rdist.sum_arrays(label_counts[t].astype(np.int64)) for t in targets}      # GLOBAL counts (class weights, costs)
-    eng.upload(np.ascontiguousarray(train_src[:, :4096]), cards)   # creates the library's pinned staging ring (one-time hipHostMalloc, ~0.1 s) outside the upload figure
-    torch.cuda.synchronize()
-    t_up = time.perf_counter()
-    train_tab = eng.upload(train_src, cards)
-    dirty_tab = eng.upload(dirty_rows, cards)
-    torch.cuda.synchronize()
-    t_up = time.perf_counter() - t_up
-    upload_bytes = train_src.nbytes + dirty_rows.nbytes
-    row_tab = None
-    if shard_only:
-        row_tab = train_tab
-    elif world > 1 and a.mode == "auto" and rdist.init_row_comm(local_rank):
-        b0, c0 = rdist.shard_rows(train_src.shape[1], world, rank)
-        row_tab = eng.upload(np.ascontiguousarray(train_src[:, b0:b0 + c0]), cards)
-    elif world == 1 and a.force_row_sharding:
-        from repair import _native
-        _native.comm_init(_native.comm_unique_id(), 0, 1, local_rank)
-        row_tab = train_tab
-    null_cells = dirty_rows < 0
-    del dirty, train_src
 
-    row_sharding_note = None
-    # ---- warm-up: W boosting iterations of one model (kernel load, allocator, clocks)
-    if a.warmup > 0:
-        t = targets[min(4, len(targets) - 1)]
-        feats = [c for c in range(cols) if c != t]
-        p = dict(BASE_PARAMS, n_estimators=a.warmup)
-        m = eng.train(train_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
-        warm = eng.upload(dirty_rows[:, :min(4096, dirty_rows.shape[1])], cards)
-        eng.repair_chain(warm, [m], [t], [feats], 0, warm.n)
-        m_bytes = m.save()
-        del warm, m
-        if row_tab is not None:
-            # collective warm-up (RCCL kernels, channels) that doubles as a self-check: the row-sharded model must be the
-            # bytes of the single-device model trained a moment ago.  Any failure or mismatch on any rank -> every rank drops
-            # the communicator and the job runs target-sharded (the reference's own parallel mode).
-            ok = 1
-            try:
-                ms = eng.train_row_sharded(row_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
-                if shard_only:   # no rank holds the whole table: the ranks must at least agree on the model, byte for byte
-                    digests = rdist.exchange_blobs({rank: hashlib.md5(ms.save()).digest()})
-                    ok = int(len(set(digests.values())) == 1)
-                else:
-                    ok = int(ms.save() == m_bytes)
-            except Exception as e:  # noqa: BLE001
-                print("[bench] row-sharded warm-up failed on rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
-                ok = 0
-            if world > 1:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-                ok = int(flag.item())
-            if not ok and shard_only:
-                raise SystemExit("bench.py: the ranks of the row-sharded warm-up fit disagree on the model (or the fit failed); a shard-only job cannot fall back")
-            if not ok:
-                from repair import _native
-                _native.comm_finalize()
-                row_tab = None
-                row_sharding_note = "disabled: the row-sharded warm-up model differed from the single-device one (or failed)"
+    def load_and_warm(shard_only):
+        """Generates / uploads this rank's tables and runs the warm-up fits.  Returns None when a shard-only job's row-sharded warm-up failed
+        (the caller then loads whole tables on every rank and runs target-sharded: slower to set up, but the job completes)."""
+        row_base = 0
+        t_gen = time.perf_counter()
+        if shard_only:
+            row_base, c0 = rdist.shard_rows(rows, world, rank)
+            dirty, null_truth, cards = make_table_parallel(rows, cols, seed=cfg["seed"], threads=max(1, min(32, os.cpu_count() or 1) // max(1, min(world, 8))),
+                                                           row_range=(row_base, row_base + c0))
+        elif rows * cols > 400_000_000:
+            dirty, null_truth, cards = make_table_parallel(rows, cols, seed=cfg["seed"], threads=min(32, os.cpu_count() or 1) // max(1, min(world, 4)) or 1)
+        else:
+            dirty, clean, cards = make_table(rows, cols, seed=cfg["seed"])
+            null_truth = {t: (np.flatnonzero(dirty[t] < 0), clean[t][dirty[t] < 0]) for t in targets}
+            del clean
+        t_gen = time.perf_counter() - t_gen
+        dirty_mask = (dirty[targets] < 0).any(axis=0)
+        dirty_pos = np.flatnonzero(dirty_mask) + row_base                    # positions in the whole table
+        dirty_rows = np.ascontiguousarray(dirty[:, dirty_mask])
+        n_cells = int((dirty_rows[targets] < 0).sum())
+        n_dirty_rows = int(dirty_rows.shape[1])
+        if shard_only:
+            n_cells, n_dirty_rows = int(rdist.sum_over_ranks(n_cells)), int(rdist.sum_over_ranks(n_dirty_rows))
+        train_src = dirty
+        if 0 < a.train_rows < rows:
+            sel = np.sort(np.random.Generator(np.random.PCG64(7)).choice(rows, a.train_rows, replace=False))
+            train_src = np.ascontiguousarray(dirty[:, sel])
+        label_counts = {t: np.bincount(train_src[t][train_src[t] >= 0], minlength=int(cards[t])) for t in targets}
+        if shard_only:
+            label_counts = {t: rdist.sum_arrays(label_counts[t].astype(np.int64)) for t in targets}      # GLOBAL counts (class weights, costs)
+        eng.upload(np.ascontiguousarray(train_src[:, :4096]), cards)   # creates the library's pinned staging ring (one-time hipHostMalloc, ~0.1 s) outside the upload figure
+        torch.cuda.synchronize()
+        t_up = time.perf_counter()
+        train_tab = eng.upload(train_src, cards)
+        dirty_tab = eng.upload(dirty_rows, cards)
+        torch.cuda.synchronize()
+        t_up = time.perf_counter() - t_up
+        upload_bytes = train_src.nbytes + dirty_rows.nbytes
+        row_tab = None
+        if shard_only:
+            row_tab = train_tab
+        elif world > 1 and a.mode == "auto" and rdist.init_row_comm(local_rank):
+            b0, c0 = rdist.shard_rows(train_src.shape[1], world, rank)
+            row_tab = eng.upload(np.ascontiguousarray(train_src[:, b0:b0 + c0]), cards)
+        elif world == 1 and a.force_row_sharding:
+            from repair import _native
+            _native.comm_init(_native.comm_unique_id(), 0, 1, local_rank)
+            row_tab = train_tab
+        null_cells = dirty_rows < 0
+        del dirty, train_src
+
+        note = None
+        # ---- warm-up: W boosting iterations of one model (kernel load, allocator, clocks)
+        if a.warmup > 0:
+            t = targets[min(4, len(targets) - 1)]
+            feats = [c for c in range(cols) if c != t]
+            p = dict(BASE_PARAMS, n_estimators=a.warmup)
+            m = eng.train(train_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
+            warm = eng.upload(dirty_rows[:, :min(4096, dirty_rows.shape[1])], cards)
+            eng.repair_chain(warm, [m], [t], [feats], 0, warm.n)
+            m_bytes = m.save()
+            del warm, m
+            if row_tab is not None:
+                # collective warm-up (RCCL kernels, channels) that doubles as a self-check: the row-sharded model must be the
+                # bytes of the single-device model trained a moment ago.  Any failure or mismatch on any rank -> every rank drops
+                # the communicator and the job runs target-sharded (the reference's own parallel mode).
+                ok = 1
+                try:
+                    ms = eng.train_row_sharded(row_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
+                    if shard_only:   # no rank holds the whole table: the ranks must at least agree on the model, byte for byte
+                        digests = rdist.exchange_blobs({rank: hashlib.md5(ms.save()).digest()})
+                        ok = int(len(set(digests.values())) == 1)
+                    else:
+                        ok = int(ms.save() == m_bytes)
+                except Exception as e:  # noqa: BLE001
+                    print("[bench] row-sharded warm-up failed on rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+                    ok = 0
+                if world > 1:
+                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                    ok = int(flag.item())
+                if not ok:
+                    from repair import _native
+                    if _native.comm_info()["kind"] != 0:
+                        _native.comm_finalize()
+                    rdist.ROW_COMM.update(fell_back=True, why="the row-sharded warm-up fit failed or the ranks disagreed on its model")
+                    if shard_only:      # a rank holds nothing but its shard: target sharding needs the whole table -> build it, on every rank
+                        return None
+                    row_tab = None
+                    note = "disabled: the row-sharded warm-up model differed from the single-device one (or failed)"
+        return dict(row_base=row_base, cards=cards, null_truth=null_truth, t_gen=t_gen, dirty_pos=dirty_pos, dirty_rows=dirty_rows, n_cells=n_cells,
+                    n_dirty_rows=n_dirty_rows, label_counts=label_counts, train_tab=train_tab, dirty_tab=dirty_tab, t_up=t_up, upload_bytes=upload_bytes,
+                    row_tab=row_tab, note=note)
+
+    inp = load_and_warm(shard_only)
+    if inp is None:
+        print("[bench] rank %d: shard-only job falls back to target sharding over torch's group (every rank loads the whole table)" % rank, file=sys.stderr, flush=True)
+        shard_only = False
+        inp = load_and_warm(False)
+    row_base, cards, null_truth, t_gen, dirty_pos, dirty_rows = inp["row_base"], inp["cards"], inp["null_truth"], inp["t_gen"], inp["dirty_pos"], inp["dirty_rows"]
+    n_cells, n_dirty_rows, label_counts, train_tab, dirty_tab = inp["n_cells"], inp["n_dirty_rows"], inp["label_counts"], inp["train_tab"], inp["dirty_tab"]
+    t_up, upload_bytes, row_tab, row_sharding_note = inp["t_up"], inp["upload_bytes"], inp["row_tab"], inp["note"]
 
     def plan_of(row_sharding):
         costs = [(t, (1 if int(cards[t]) <= 2 else int(cards[t])) * float(np.sum(label_counts[t])) * 1e-6) for t in targets]
-        pl = rdist.plan(costs, world, row_sharding, force=a.force_row_sharding, all_targets=shard_only)
+        pl = rdist.plan(costs, world, row_sharding, force=a.force_row_sharding, all_targets=shard_only or (a.row_shard_all and a.force_row_sharding))
         return {k: ([round(x, 1) for x in v] if k == "target_sharded_units_per_rank" else (round(v, 2) if isinstance(v, float) else v)) for k, v in pl.items()}
 
     def timed_job(n_estimators, want_stats=False, concurrency=None):
@@ -330,7 +375,8 @@ def main():
         rdist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = run_job(eng, train_tab, fresh, cards, targets, label_counts, params, want_stats=want_stats, row_table=row_tab,
-                      force_row_sharding=a.force_row_sharding, train_concurrency=concurrency, dirty_is_shard=shard_only, row_shard_all=shard_only)
+                      force_row_sharding=a.force_row_sharding, train_concurrency=concurrency, dirty_is_shard=shard_only,
+                      row_shard_all=shard_only or (a.row_shard_all and a.force_row_sharding))
         torch.cuda.synchronize(); rdist.barrier()
         return res, rdist.max_over_ranks(time.perf_counter() - t0)
 
@@ -360,6 +406,13 @@ def main():
     level_stream_bytes = rdist.sum_over_ranks(sum((s_["hist_launches"] - roof_steps) * 9.0 * float(getattr(row_tab if shard_only else train_tab, "n", 0)) *
                                                   (1 if int(cards[s_["target"]]) <= 2 else int(cards[s_["target"]])) for s_ in res_roof["stats"]))
     train_s = rdist.max_over_ranks(res["times"]["train"]); infer_s = rdist.max_over_ranks(res["times"]["infer"])
+    # what the FINISHED trees of the roofline pass needed below their roots (rows of the smaller child of every split whose children can be
+    # split again): the level grower accumulates a superset (it cannot know at level 3 which nodes best-first growth will take), and
+    # `roofline.achieved` counts what it accumulated -- `frac_needed` prices the same launches at the bytes LightGBM's own growth order needs
+    from repair import _native as _N
+    needed_level_rows = 0
+    if rank == 0 and not shard_only:
+        needed_level_rows = sum(_N.needed_built_rows(res_roof["models"][s_["target"]], BASE_PARAMS["max_depth"]) for s_ in res_roof["stats"])
 
     fixed_shards = 0.0
     if shard_only:   # every rank checks the cells of its own dirty rows against the clean values it generated
@@ -393,10 +446,17 @@ def main():
                  "achieved": nbytes / max(ms, 1e-9) * 1e-6, "frac": nbytes / max(ms, 1e-9) * 1e-6 / HBM_PEAK_GBS}
             if name == "level":   # what a level pass streams by construction: 1 B node id + 8 B (g, h) of every (row, class tree) of its target
                 c["stream_bytes_per_launch"] = level_stream_bytes / nl
+                c["bound"] = "instruction issue: routing VALU + LDS atomics of a SIMD take turns (DESIGN 5); its HBM stream alone would take stream_bytes / ~5 TB/s"
+                if needed_level_rows:
+                    c["needed_alg_bytes_per_launch"] = needed_level_rows * (cols - 1 + 8) / nl
+                    c["frac_needed"] = needed_level_rows * (cols - 1 + 8) / max(ms, 1e-9) * 1e-6 / HBM_PEAK_GBS
+            else:
+                c["bound"] = "lds-atomic: 14 ds_add_u64 per row (7 joint-bin groups x (g, h)) at ~12.8 cycles per wave instruction; algorithmic bytes follow SURVEY 8(d) (F + 8 per row), the pass's HBM traffic is about half of them"
             if traffic and name in traffic["classes"]:
                 tc = traffic["classes"][name]
                 c["traffic"] = {"fetch_bytes_per_launch": tc["fetch_bytes_per_launch"], "write_bytes_per_launch": tc["write_bytes_per_launch"],
-                                "ratio_to_algorithmic": tc["bytes_per_launch"] / max(nbytes / nl, 1e-9)}
+                                "ratio_to_algorithmic": tc["bytes_per_launch"] / max(nbytes / nl, 1e-9),
+                                "hbm_GBps": tc["bytes_per_launch"] / max(ms / nl, 1e-9) * 1e-6}
             classes[name] = c
         out = {
             "metric": "repaired cells/sec", "value": n_cells / elapsed, "unit": "cells/s",
@@ -425,6 +485,8 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": "rg::k_level_root + rg::k_level_mt (histogram build of the level grower; a level pass also routes the rows of its level: DataPartition::Split is not a separate kernel)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # the same launches priced at what the finished trees needed (root passes in full + the smaller child of every final split)
+                         "frac_needed": ((root_bytes + needed_level_rows * (cols - 1 + 8)) / max(hist_ms_all, 1e-9) * 1e-6 / HBM_PEAK_GBS) if needed_level_rows else None,
                          "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                          "classes": classes,
                          "measured_on": "sequential pass (one target model at a time) of %d boosting iterations of the same job, %.2f s; HIP events per launch" % (roof_steps, elapsed_roof),
@@ -434,8 +496,13 @@ def main():
         }
         if row_sharding_note:
             out["config"]["row_sharding"] = row_sharding_note
+        if world > 1:   # what the first multi-rank runs need to show: did RCCL really span the world, how long did it take, did the job fall back
+            rc = dict(rdist.ROW_COMM)
+            out["config"]["rccl"] = {"asked": rc["asked"], "ranks_seen_by_ncclCommCount": rc["ranks"], "comm_init_sec": round(rc["init_sec"], 3), "fell_back": rc["fell_back"],
+                                     "why": rc["why"], "timeout_s": float(os.environ.get("RGBM_COMM_TIMEOUT_S", "600")),
+                                     "fusion": res.get("fusion") or None}
         if not a.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (the other ranks would sit in the barrier below)
-            out["cpu_baseline"] = cpu_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS, full_rows=rows if not (0 < a.train_rows < rows) else 0)
+            out["cpu_baseline"] = cpu_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS, full_rows=rows if not (0 < a.train_rows < rows) else 0, cells_full=n_cells)
             fst = out["cpu_baseline"].get("full_size_target")
             if fst and "train_sec" in fst:      # the GPU's wall time for the same target and iteration count (sequential roofline pass, setup included pro rata)
                 g = [s_ for s_ in res_roof["stats"] if s_.get("target") == targets[0]]

@@ -255,11 +255,25 @@ int rgbm_table_shape(const rgbm_table* t, int64_t* n_out, int32_t* c_out, int32_
 int rgbm_comm_unique_id(void* id_out /* [RGBM_COMM_ID_BYTES], call on one rank, hand to all */);
 int rgbm_comm_init(const void* id, int32_t rank, int32_t nranks, int32_t device_id);
 int rgbm_comm_finalize(void);
-int rgbm_comm_info(int32_t* info /* [3] = {0 none | 1 RCCL | 2 thread group, rank, nranks} */);
+int rgbm_comm_info(int32_t* info /* [3] = {0 none | 1 RCCL | 2 thread group | 3 member of a fusion group, rank, nranks} */);
+int rgbm_comm_count(int32_t* n_out /* ranks the communicator really spans (ncclCommCount); 1 without one */);
 /* Test transport: the ranks are host threads of one process sharing one device. */
 int rgbm_local_group_create(int32_t nranks, int32_t device_id, void** group_out);
 void rgbm_local_group_free(void* group);
 int rgbm_comm_init_local(void* group, int32_t rank);
+
+/* Fusion group: the row-sharded training calls a rank makes AT THE SAME TIME (one host thread + one stream each; the reference trains its
+ * targets in parallel, python/repair/model.py:817-926).  The calling thread's communicator moves into the group; every member thread joins
+ * with its index (the same indices on every rank), trains its targets with RGBM_FLAG_ROW_SHARDED as usual and leaves.  Inside, the i-th
+ * collective of every member still taking part is carried by ONE all-reduce per element type of the rank's communicator over the members'
+ * buffers laid side by side (member order): a rank issues 8 collectives per boosting iteration of ALL its row-sharded targets instead of 8
+ * per target, and the targets overlap on the device.  Models are unchanged (integer sums).  A member that fails breaks the group: the other
+ * members' calls fail at their next collective.  rgbm_fusion_free hands the communicator back to the calling thread. */
+int rgbm_fusion_create(int32_t n_members, void** fusion_out);
+int rgbm_fusion_join(void* fusion, int32_t member /* 0 .. n_members-1, on the member's own thread */);
+int rgbm_fusion_leave(int32_t failed /* 0: done; 1: this member failed -- the group is broken */);
+int rgbm_fusion_info(void* fusion, int64_t* info /* [4] = {collectives issued, member parts carried, members still in, broken} */);
+int rgbm_fusion_free(void* fusion);
 
 /* ---- model handle: pickling (python/repair/model.py:910,921,1069) -------------------------- */
 int rgbm_model_save(const rgbm_model* m, void* buf, size_t* len); /* buf==NULL: length query */

@@ -195,16 +195,119 @@ struct LocalGroup {
     }
 };
 
+struct Fusion;
 struct Comm {
-    int kind = 0;   // 0 none, 1 RCCL, 2 local thread group
+    int kind = 0;   // 0 none, 1 RCCL, 2 local thread group, 3 member of a fusion group (the rank's communicator lives in the group)
     int rank = 0, nranks = 1;
     ncclComm_t nccl = nullptr;
     LocalGroup* lg = nullptr;
     void* tmp = nullptr; size_t tmp_bytes = 0;
+    Fusion* fusion = nullptr; int member = 0;      // kind 3
 };
 thread_local Comm g_comm;
 
 enum { AR_I64 = 0, AR_U32 = 1, AR_I32 = 2 };
+
+// ---------------------------------------------------------------------------------------------
+// Fusion group (round 5): the row-sharded training calls of ONE rank that run at the same time -- one host thread and one HIP stream
+// each -- and exchange in LOCK STEP.  Every row-sharded training call makes the same sequence of collectives (code counts once, then per
+// boosting iteration one all-reduce per level and one of the deepest counts: the sequence is fixed by the parameters, not by the
+// data), so the i-th collective of every member is carried by ONE all-reduce of the rank's communicator over the members' buffers laid
+// side by side: a member records an event behind its producers and waits at a host barrier; the last one to arrive copies all parts
+// into a staging buffer on the group's stream, enqueues the collective and the copies back and records a `done` event; every member's
+// stream then waits for that event.  Nothing synchronises with the device: the host threads only meet at enqueue time.
+// What it buys: the row-sharded targets of a rank trained one after another on the thread that owns the
+// communicator -- the in-rank concurrency (22 % at N = 1) was gone exactly where every target is row-sharded, and a job paid 8
+// collectives per target-iteration.  Now they overlap like the target-sharded ones and a rank issues 8 collectives per iteration of
+// ALL its row-sharded targets.  The members' order inside the fused buffer is their index, so it is the same on every rank.
+// A member that fails breaks the group: the others raise at their next collective (and the RCCL communicator is aborted, as before).
+// ---------------------------------------------------------------------------------------------
+struct Fusion {
+    static constexpr int MAX_MEMBERS = 64;
+    Comm comm;                  // the rank's communicator (moved in by rgbm_fusion_create, moved back by rgbm_fusion_free)
+    int device = 0;
+    int n = 0;                  // members still taking part
+    std::mutex mu; std::condition_variable cv;
+    int arrived = 0; long long gen = 0; bool broken = false; std::string why;
+    struct Part { void* buf = nullptr; size_t count = 0; int type = 0; hipStream_t s = nullptr; hipEvent_t ready = nullptr; bool in = false; } part[MAX_MEMBERS];
+    void* stage = nullptr; size_t stage_bytes = 0;
+    hipStream_t cs = nullptr; hipEvent_t done = nullptr;
+    long long collectives = 0, fused_parts = 0;    // statistics
+};
+
+void all_reduce_on(Comm& c, void* buf, size_t count, int type, hipStream_t s);
+
+// the collective of one step for every member that is parked in it (called with f->mu held, by the last member to arrive -- or by a member
+// that leaves while all the remaining ones are parked).  Members may be at different points of their sequences (one is counting codes for
+// its next target while another is in the middle of an iteration): the parts are grouped by element type, one all-reduce per type present,
+// in a fixed type order -- the same on every rank, because which member takes part in the k-th step only depends on the sequences.
+void fusion_run_step_locked(Fusion* f) {
+    try {
+        for (int type = 0; type < 3; ++type) {
+            const size_t esz = type == AR_I64 ? 8 : 4;
+            size_t total = 0; int nparts = 0;
+            for (int j = 0; j < Fusion::MAX_MEMBERS; ++j) if (f->part[j].in && f->part[j].type == type) { total += f->part[j].count; ++nparts; }
+            if (nparts == 0) continue;
+            if (total * esz > f->stage_bytes) {
+                HIPCHK(hipStreamSynchronize(f->cs));
+                if (f->stage) (void)hipFree(f->stage);
+                f->stage_bytes = std::max<size_t>(total * esz * 2, 1 << 20);
+                HIPCHK(hipMalloc(&f->stage, f->stage_bytes));
+            }
+            size_t off = 0;
+            for (int j = 0; j < Fusion::MAX_MEMBERS; ++j) {
+                Fusion::Part& q = f->part[j];
+                if (!q.in || q.type != type) continue;
+                HIPCHK(hipStreamWaitEvent(f->cs, q.ready, 0));
+                if (q.count) HIPCHK(hipMemcpyAsync(static_cast<char*>(f->stage) + off * esz, q.buf, q.count * esz, hipMemcpyDeviceToDevice, f->cs));
+                off += q.count;
+            }
+            all_reduce_on(f->comm, f->stage, total, type, f->cs);
+            off = 0;
+            for (int j = 0; j < Fusion::MAX_MEMBERS; ++j) {
+                Fusion::Part& q = f->part[j];
+                if (!q.in || q.type != type) continue;
+                if (q.count) HIPCHK(hipMemcpyAsync(q.buf, static_cast<char*>(f->stage) + off * esz, q.count * esz, hipMemcpyDeviceToDevice, f->cs));
+                off += q.count; f->fused_parts += 1;
+            }
+            f->collectives += 1;
+        }
+        for (int j = 0; j < Fusion::MAX_MEMBERS; ++j) f->part[j].in = false;
+        HIPCHK(hipEventRecord(f->done, f->cs));
+    } catch (const std::exception& e) { f->broken = true; f->why = e.what(); }
+    f->arrived = 0; ++f->gen; f->cv.notify_all();
+}
+
+// one fused collective; called by every member with its own buffer
+void fused_all_reduce(Fusion* f, int me, void* buf, size_t count, int type, hipStream_t s) {
+    Fusion::Part& mine = f->part[me];
+    if (!mine.ready) HIPCHK(hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(mine.ready, s));
+    std::unique_lock<std::mutex> lk(f->mu);
+    if (f->broken) throw std::runtime_error("fusion group: a concurrent row-sharded training call of this rank failed (" + f->why + ")");
+    mine.buf = buf; mine.count = count; mine.type = type; mine.s = s; mine.in = true;
+    const long long gen = f->gen;
+    if (++f->arrived >= f->n) fusion_run_step_locked(f);
+    else f->cv.wait(lk, [&] { return f->gen != gen || f->broken; });
+    if (f->broken) throw std::runtime_error("fusion group: a concurrent row-sharded training call of this rank failed (" + f->why + ")");
+    HIPCHK(hipStreamWaitEvent(s, f->done, 0));
+}
+
+// a member is done (its training call returned or failed): the others go on among themselves
+void fusion_leave(bool failed, const char* why) {
+    Comm& c = g_comm;
+    if (c.kind != 3 || !c.fusion) return;
+    Fusion* f = c.fusion;
+    {
+        std::lock_guard<std::mutex> lk(f->mu);
+        f->part[c.member].in = false;
+        if (failed && !f->broken) { f->broken = true; f->why = why ? why : "unknown error"; if (f->comm.kind == 1 && f->comm.nccl) { (void)ncclCommAbort(f->comm.nccl); f->comm.nccl = nullptr; f->comm.kind = 0; } }
+        f->n -= 1;
+        if (f->broken) f->cv.notify_all();
+        else if (f->n > 0 && f->arrived >= f->n) fusion_run_step_locked(f);     // the remaining members are all parked in their next step: it is theirs alone
+    }
+    g_comm = Comm();
+}
 
 // Fail-safe for the RCCL transport.  A rank that dies (or throws) in the middle of a training call never enqueues its next
 // all-reduce, and its peers would sit in theirs for ever.  So (a) a rank that fails ABORTS its communicator before the error
@@ -215,11 +318,13 @@ enum { AR_I64 = 0, AR_U32 = 1, AR_I32 = 2 };
 void comm_abort() {
     Comm& c = g_comm;
     if (c.kind == 1 && c.nccl) { (void)ncclCommAbort(c.nccl); c.nccl = nullptr; c.kind = 0; c.nranks = 1; c.rank = 0; }
+    if (c.kind == 3 && c.fusion) fusion_leave(true, "a member's stream failed or timed out inside a collective");
 }
 
 void stream_sync_watchdog(hipStream_t s) {
     Comm& c = g_comm;
-    if (c.kind != 1) { HIPCHK(hipStreamSynchronize(s)); return; }
+    const bool fused_rccl = c.kind == 3 && c.fusion && c.fusion->comm.kind == 1;
+    if (c.kind != 1 && !fused_rccl) { HIPCHK(hipStreamSynchronize(s)); return; }
     static const double limit = [] { const char* e = getenv("RGBM_COMM_TIMEOUT_S"); double v = e ? atof(e) : 600.0; return v > 0.0 ? v : 600.0; }();
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -227,7 +332,9 @@ void stream_sync_watchdog(hipStream_t s) {
         if (q == hipSuccess) return;
         if (q != hipErrorNotReady) { (void)hipGetLastError(); comm_abort(); throw std::runtime_error(std::string("training stream failed during a collective: ") + hipGetErrorString(q)); }
         ncclResult_t ae = ncclSuccess;
-        if (c.nccl && ncclCommGetAsyncError(c.nccl, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
+        ncclComm_t nc = fused_rccl ? c.fusion->comm.nccl : c.nccl;
+        if (fused_rccl && c.fusion->broken) { const std::string w = c.fusion->why; comm_abort(); throw std::runtime_error("fusion group broken: " + w); }
+        if (nc && ncclCommGetAsyncError(nc, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
             const std::string what = ncclGetErrorString(ae);
             comm_abort();
             throw std::runtime_error("RCCL reported an asynchronous error (a peer rank failed?): " + what);
@@ -254,6 +361,10 @@ __global__ void k_sum_ranks(PtrList src, int n, T* __restrict__ out, size_t coun
 // in-place sum all-reduce of `count` elements on stream s
 void all_reduce(void* buf, size_t count, int type, hipStream_t s) {
     Comm& c = g_comm;
+    if (c.kind == 3) { fused_all_reduce(c.fusion, c.member, buf, count, type, s); return; }     // (also with count == 0: every member takes part in every step)
+    all_reduce_on(c, buf, count, type, s);
+}
+void all_reduce_on(Comm& c, void* buf, size_t count, int type, hipStream_t s) {
     if (c.kind == 0 || count == 0) return;
     const size_t esz = type == AR_I64 ? 8 : 4;
     if (c.kind == 1) {
@@ -2054,7 +2165,7 @@ RGBM_EXPORT int rgbm_table_train(const rgbm_table* t, int32_t target_col, const 
             *out = train_core(*t, target_col, feat_cols, f, y_value, class_weight, nullptr, nullptr, *p, stats);
         } catch (...) {
             // a rank that fails inside a row-sharded call must not leave its peers waiting in their next all-reduce
-            if ((p->reserved & RGBM_FLAG_ROW_SHARDED) && g_comm.kind == 1) comm_abort();
+            if ((p->reserved & RGBM_FLAG_ROW_SHARDED) && (g_comm.kind == 1 || g_comm.kind == 3)) comm_abort();
             throw;
         }
         return RGBM_OK;
@@ -2361,6 +2472,63 @@ RGBM_EXPORT int rgbm_comm_init_local(void* group, int32_t rank) {
     });
 }
 
+// ---- fusion group: concurrent row-sharded training calls of one rank, one collective per step for all of them (see struct Fusion)
+RGBM_EXPORT int rgbm_fusion_create(int32_t n_members, void** out) {
+    if (!out || n_members < 1 || n_members > Fusion::MAX_MEMBERS) return fail(RGBM_ERR_ARG, "rgbm_fusion_create: bad argument (1..64 members)");
+    return guarded([&]() {
+        if (g_comm.kind != 1 && g_comm.kind != 2) throw std::invalid_argument("rgbm_fusion_create: the calling thread has no communicator (rgbm_comm_init)");
+        std::unique_ptr<Fusion> f(new Fusion());
+        HIPCHK(hipGetDevice(&f->device));
+        HIPCHK(hipStreamCreateWithFlags(&f->cs, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&f->done, hipEventDisableTiming));
+        f->n = n_members;
+        f->comm = g_comm; g_comm = Comm();         // the communicator lives in the group until rgbm_fusion_free hands it back
+        *out = f.release();
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_fusion_join(void* fusion, int32_t member) {
+    Fusion* f = static_cast<Fusion*>(fusion);
+    if (!f || member < 0 || member >= Fusion::MAX_MEMBERS) return fail(RGBM_ERR_ARG, "rgbm_fusion_join: bad argument");
+    return guarded([&]() {
+        if (g_comm.kind != 0) throw std::invalid_argument("rgbm_fusion_join: this thread already has a communicator");
+        use_device(f->device);
+        g_comm.kind = 3; g_comm.rank = f->comm.rank; g_comm.nranks = f->comm.nranks; g_comm.fusion = f; g_comm.member = member;
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_fusion_leave(int32_t failed) {
+    fusion_leave(failed != 0, "a member reported a failure");
+    return RGBM_OK;
+}
+
+RGBM_EXPORT int rgbm_fusion_info(void* fusion, int64_t* info /* [4] = {collectives issued, member parts carried, members still in, broken} */) {
+    Fusion* f = static_cast<Fusion*>(fusion);
+    if (!f || !info) return fail(RGBM_ERR_ARG, "rgbm_fusion_info: bad argument");
+    std::lock_guard<std::mutex> lk(f->mu);
+    info[0] = f->collectives; info[1] = f->fused_parts; info[2] = f->n; info[3] = f->broken ? 1 : 0;
+    return RGBM_OK;
+}
+
+RGBM_EXPORT int rgbm_fusion_free(void* fusion) {
+    Fusion* f = static_cast<Fusion*>(fusion);
+    if (!f) return RGBM_OK;
+    return guarded([&]() {
+        (void)hipSetDevice(f->device);
+        if (f->cs) { (void)hipStreamSynchronize(f->cs); (void)hipStreamDestroy(f->cs); }
+        if (f->done) (void)hipEventDestroy(f->done);
+        for (auto& q : f->part) if (q.ready) (void)hipEventDestroy(q.ready);
+        if (f->stage) (void)hipFree(f->stage);
+        // the communicator goes back to the calling thread (unless that thread has one already, or the group broke and aborted it)
+        if (g_comm.kind == 0 && (f->comm.kind == 1 || f->comm.kind == 2)) g_comm = f->comm;
+        else { if (f->comm.kind == 1 && f->comm.nccl) (void)ncclCommDestroy(f->comm.nccl); if (f->comm.tmp) (void)hipFree(f->comm.tmp); }
+        delete f;
+        return RGBM_OK;
+    });
+}
+
 RGBM_EXPORT int rgbm_comm_finalize(void) {
     if (g_comm.kind == 1 && g_comm.nccl) (void)ncclCommDestroy(g_comm.nccl);
     if (g_comm.tmp) (void)hipFree(g_comm.tmp);
@@ -2370,8 +2538,26 @@ RGBM_EXPORT int rgbm_comm_finalize(void) {
 
 RGBM_EXPORT int rgbm_comm_info(int32_t* info) {
     if (!info) return fail(RGBM_ERR_ARG, "rgbm_comm_info: bad argument");
-    info[0] = g_comm.kind; info[1] = g_comm.rank; info[2] = g_comm.nranks;
+    info[0] = g_comm.kind; info[1] = g_comm.rank; info[2] = g_comm.nranks;     // (kind 3: member of a fusion group)
     return RGBM_OK;
+}
+
+// ranks the calling thread's RCCL communicator really spans (ncclCommCount), 1 for no communicator: what a multi-GPU job prints so that a
+// silent fall-back to fewer ranks is visible in its result line
+RGBM_EXPORT int rgbm_comm_count(int32_t* n_out) {
+    if (!n_out) return fail(RGBM_ERR_ARG, "rgbm_comm_count: bad argument");
+    return guarded([&]() {
+        *n_out = 1;
+        const Comm& c = (g_comm.kind == 3 && g_comm.fusion) ? g_comm.fusion->comm : g_comm;
+        if (c.kind == 2) *n_out = c.nranks;
+        if (c.kind == 1 && c.nccl) {
+            int n = 0;
+            ncclResult_t r = ncclCommCount(c.nccl, &n);
+            if (r != ncclSuccess) throw std::runtime_error(std::string("ncclCommCount failed: ") + ncclGetErrorString(r));
+            *n_out = n;
+        }
+        return RGBM_OK;
+    });
 }
 
 RGBM_EXPORT void rgbm_model_free(rgbm_model* m) { delete m; }

@@ -79,7 +79,7 @@ def lib():
         for name in ("rgbm_device_count", "rgbm_version", "rgbm_release_cache", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
                      "rgbm_table_create", "rgbm_table_train", "rgbm_table_train_batch", "rgbm_table_repair_chain", "rgbm_table_read_column",
                      "rgbm_model_save", "rgbm_model_load", "rgbm_model_info", "rgbm_model_importance",
-                     "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
+                     "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info", "rgbm_comm_count",
                      "rgbm_local_group_create", "rgbm_comm_init_local",
                      "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
                      "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict",
@@ -97,8 +97,9 @@ EXPORTED_SYMBOLS = [
     "rgbm_device_count", "rgbm_last_error", "rgbm_version", "rgbm_release_cache", "rgbm_train", "rgbm_predict", "rgbm_repair_chain",
     "rgbm_table_create", "rgbm_table_free", "rgbm_table_train", "rgbm_table_train_batch", "rgbm_table_repair_chain", "rgbm_table_read_column",
     "rgbm_model_save", "rgbm_model_load", "rgbm_model_free", "rgbm_model_info", "rgbm_model_importance",
-    "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info",
+    "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info", "rgbm_comm_count",
     "rgbm_local_group_create", "rgbm_local_group_free", "rgbm_comm_init_local",
+    "rgbm_fusion_create", "rgbm_fusion_join", "rgbm_fusion_leave", "rgbm_fusion_info", "rgbm_fusion_free",
     "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
     "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict", "rgbm_table_shape",
     "rgbm_table_repair_pmf", "rgbm_table_read_cells", "rgbm_table_write_cells", "rgbm_host_alloc", "rgbm_host_free",
@@ -129,6 +130,103 @@ def comm_info():
     a = np.zeros(3, np.int32)
     _check(lib().rgbm_comm_info(_p(a, C.c_int32)), "rgbm_comm_info")
     return dict(kind=int(a[0]), rank=int(a[1]), nranks=int(a[2]))
+
+
+def model_trees(blob):
+    """The trees of a serialised model (rgbm_model_save), in (iteration, class tree) order: dicts of the arrays the blob stores -- feat, theta,
+    dleft, left, right (child >= 0: internal node, < 0: ~leaf), gain, leaf_value, leaf_count.  Returns (K, n_iter, trees)."""
+    import struct
+    hdr = struct.unpack_from("7i", blob, 0)
+    ver, K, n_iter, F = hdr[1], hdr[4], hdr[5], hdr[6]
+    p = 28
+    for _ in range(F):
+        _, V, _ = struct.unpack_from("3i", blob, p); p += 12 + 4 * V
+        if ver == 2:
+            nw, = struct.unpack_from("i", blob, p); p += 4 + 4 * nw
+    trees = []
+    for _ in range(K * n_iter):
+        L, = struct.unpack_from("i", blob, p); p += 4
+        n = L - 1
+        t = {}
+        for name in ("feat", "theta", "dleft", "left", "right"):
+            t[name] = np.frombuffer(blob, np.int32, n, p); p += 4 * n
+        t["gain"] = np.frombuffer(blob, np.float64, n, p); p += 8 * n
+        t["leaf_value"] = np.frombuffer(blob, np.float64, L, p); p += 8 * L
+        t["leaf_count"] = np.frombuffer(blob, np.int32, L, p); p += 4 * L
+        trees.append(t)
+    return K, n_iter, trees
+
+
+def needed_built_rows(blob, max_depth):
+    """Rows whose (g, h) the FINISHED trees of a model needed in a histogram below the root: for every split whose children can still be
+    split (depth + 1 < max_depth) the rows of its smaller child (LightGBM constructs the smaller leaf and derives the sibling by
+    subtraction) -- what a grower that knew the final trees in advance would accumulate.  The level grower expands a superset."""
+    _, _, trees = model_trees(blob)
+    total = 0
+    for tr in trees:
+        n = len(tr["feat"])
+        if n == 0:
+            continue
+        left, right, lc = tr["left"], tr["right"], tr["leaf_count"]
+        cnt = np.zeros(n, np.int64)
+        for j in range(n - 1, -1, -1):          # children have larger indices than their parent (Tree::Split numbering)
+            a, b = int(left[j]), int(right[j])
+            cnt[j] = (cnt[a] if a >= 0 else int(lc[~a])) + (cnt[b] if b >= 0 else int(lc[~b]))
+        depth = np.zeros(n, np.int32)
+        for j in range(n):
+            a, b = int(left[j]), int(right[j])
+            if a >= 0:
+                depth[a] = depth[j] + 1
+            if b >= 0:
+                depth[b] = depth[j] + 1
+            if depth[j] + 1 < max_depth:
+                ca = cnt[a] if a >= 0 else int(lc[~a]); cb = cnt[b] if b >= 0 else int(lc[~b])
+                total += int(min(ca, cb))
+    return total
+
+
+def comm_count():
+    """Ranks the calling thread's communicator really spans (ncclCommCount); 1 without a communicator."""
+    n = C.c_int32(0)
+    _check(lib().rgbm_comm_count(C.byref(n)), "rgbm_comm_count")
+    return int(n.value)
+
+
+class FusionGroup:
+    """The row-sharded training calls this rank makes AT THE SAME TIME (include/rgbm.h "Fusion group"): created on the thread that holds
+    the rank's communicator, which moves into the group until ``close()``.  Every member thread runs ``with group.member(j): ...`` around its
+    ``Table.train(..., row_sharded=True)`` calls (the same j on every rank); the i-th collective of all members is one all-reduce."""
+
+    def __init__(self, n_members):
+        self.h = C.c_void_p()
+        _check(lib().rgbm_fusion_create(C.c_int32(n_members), C.byref(self.h)), "rgbm_fusion_create")
+        self.n_members = n_members
+
+    class _Member:
+        def __init__(self, group, j):
+            self.group, self.j = group, j
+
+        def __enter__(self):
+            _check(lib().rgbm_fusion_join(self.group.h, C.c_int32(self.j)), "rgbm_fusion_join")
+            return self
+
+        def __exit__(self, et, ev, tb):
+            lib().rgbm_fusion_leave(C.c_int32(0 if et is None else 1))
+            return False
+
+    def member(self, j):
+        return FusionGroup._Member(self, j)
+
+    def info(self):
+        a = np.zeros(4, np.int64)
+        _check(lib().rgbm_fusion_info(self.h, _p(a, C.c_int64)), "rgbm_fusion_info")
+        return dict(collectives=int(a[0]), parts=int(a[1]), members_in=int(a[2]), broken=bool(a[3]))
+
+    def close(self):
+        """Hands the communicator back to the calling thread (call it on the thread that created the group, after every member left)."""
+        if self.h:
+            _check(lib().rgbm_fusion_free(self.h), "rgbm_fusion_free")
+            self.h = C.c_void_p()
 
 
 class LocalGroup:

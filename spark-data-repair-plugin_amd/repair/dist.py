@@ -79,7 +79,7 @@ def split_targets(costs, world_size, row_sharding, force=False, all_targets=Fals
     return big, small
 
 
-def plan(costs, world_size, row_sharding, force=False, all_targets=False):
+def plan(costs, world_size, row_sharding, force=False, all_targets=False, fused_targets=6):
     """The schedule `engine.run_job` will follow, in cost units (class trees x training rows), so that it can be checked without
     hardware: which targets are row-sharded, the load every rank gets from the target-sharded ones, the critical path and the
     speed-up it allows before collective / tail costs -- and, when the costs are given in class trees x 10^6 rows, the same with the
@@ -92,40 +92,64 @@ def plan(costs, world_size, row_sharding, force=False, all_targets=False):
     loads = [float(sum(cost_of[t] for t in a)) for a in assign]
     shared = float(sum(c for _, c in big)) / max(world_size, 1)
     path = shared + (max(loads) if loads else 0.0)
-    # with the launch floor: the row-sharded targets train one after another on every rank, the target-sharded ones next to them
+    # with the launch floor.  The row-sharded targets of a rank train in a FUSION GROUP (engine.run_job): up to `fused` of them in flight at
+    # once, their chains of small kernels overlapping, and the i-th collective of all of them is ONE all-reduce -- the launch floor and the
+    # collectives are charged once per round of `fused` targets (the largest target's floor), not once per target
     ws = max(world_size, 1)
     floor_of = lambda c: max(float(c), LAUNCH_FLOOR_UNITS)   # noqa: E731
-    shared_f = float(sum(max(float(c) / ws, LAUNCH_FLOOR_UNITS) + (COLLECTIVE_UNITS if ws > 1 else 0.0) for _, c in big))
-    loads_f = [float(sum(floor_of(cost_of[t]) for t in a)) for a in assign]
+    fused = max(1, int(fused_targets))
+    shared_f = 0.0
+    for i in range(0, len(big), fused):
+        grp = [float(c) / ws for _, c in big[i:i + fused]]
+        shared_f += max(sum(grp), LAUNCH_FLOOR_UNITS) + (COLLECTIVE_UNITS if ws > 1 else 0.0)
+    def in_rounds(cs):      # `fused` targets in flight at once on a rank (six by default, engine._train_concurrency): the floor once per round
+        cs = sorted((float(c) for c in cs), reverse=True)
+        return float(sum(max(sum(cs[i:i + fused]), LAUNCH_FLOOR_UNITS) for i in range(0, len(cs), fused)))
+    loads_f = [in_rounds(cost_of[t] for t in a) for a in assign]
     path_f = shared_f + (max(loads_f) if loads_f else 0.0)
-    single_f = float(sum(floor_of(c) for _, c in costs))
+    single_f = in_rounds(c for _, c in costs)
+    del floor_of
     return dict(world_size=world_size, total_units=total, row_sharded=[t for t, _ in big], row_sharded_units_per_rank=shared,
                 target_sharded=assign, target_sharded_units_per_rank=loads, critical_path_units=path,
                 ideal_speedup=(total / path) if path > 0 else 1.0,
-                critical_path_units_with_floor=path_f, speedup_with_floor=(single_f / path_f) if path_f > 0 else 1.0)
+                critical_path_units_with_floor=path_f, speedup_with_floor=(single_f / path_f) if path_f > 0 else 1.0,
+                fused_row_sharded_targets=fused, collectives_per_iteration=(8 * ((len(big) + fused - 1) // fused)) if ws > 1 else 0)
+
+
+ROW_COMM = {"asked": False, "ranks": 1, "init_sec": 0.0, "fell_back": False, "why": ""}     # what bench.py prints as config.rccl
 
 
 def init_row_comm(device_id):
     """Create the librepairgbm RCCL communicator of this process (one rank per GPU).  Returns True when every rank
-    succeeded; on any failure every rank tears down and the job falls back to plain target sharding."""
+    succeeded AND the communicator spans the whole world (ncclCommCount); on any failure every rank tears down and the job
+    falls back to plain target sharding.  ROW_COMM records what happened (ranks seen, seconds, fell back and why)."""
+    import time
     d = _dist()
     if d is None or d.get_world_size() == 1 or d.get_backend() != "nccl":
         return False
     import torch
     from repair import _native
     rank, ws = d.get_rank(), d.get_world_size()
+    ROW_COMM.update(asked=True, ranks=1, fell_back=False, why="")
+    t0 = time.perf_counter()
     box = [_native.comm_unique_id() if rank == 0 else None]
     d.broadcast_object_list(box, src=0)
-    ok = 1
+    ok, why = 1, ""
     try:
         _native.comm_init(box[0], rank, ws, device_id)
-    except Exception:  # noqa: BLE001 - any failure means "no row sharding", never a crash
-        ok = 0
+        seen = _native.comm_count()
+        ROW_COMM["ranks"] = seen
+        if seen != ws:
+            ok, why = 0, "the communicator spans %d ranks, the job has %d" % (seen, ws)
+    except Exception as e:  # noqa: BLE001 - any failure means "no row sharding", never a crash
+        ok, why = 0, "%s: %s" % (type(e).__name__, e)
     t = torch.tensor([ok], dtype=torch.int32, device=_tensor_device())
     d.all_reduce(t, op=d.ReduceOp.MIN)
+    ROW_COMM["init_sec"] = time.perf_counter() - t0
     if int(t.item()) == 1:
         return True
-    if ok:
+    ROW_COMM.update(fell_back=True, why=why or "another rank could not create its communicator")
+    if _native.comm_info()["kind"] != 0:
         _native.comm_finalize()
     return False
 

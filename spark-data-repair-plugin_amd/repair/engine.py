@@ -59,6 +59,13 @@ class HipEngine:
         """Collective: every rank calls this for the same target with its own row shard (needs dist.init_row_comm)."""
         return shard_table.train(target, feats, y_value=y_value, class_weight=class_weight, want_stats=want_stats, row_sharded=True, **params)
 
+    def fusion_group(self, n_members):
+        """Several row-sharded targets of this rank in flight at once, ONE collective per step for all of them (_native.FusionGroup).  Needs the
+        rank's communicator on the calling thread; None when there is none (then the targets train one after another, as before)."""
+        if _native.comm_info()["kind"] not in (1, 2) or n_members < 2:
+            return None
+        return _native.FusionGroup(n_members)
+
     def load_model(self, blob):
         return _native.Model.load(blob)
 
@@ -180,7 +187,7 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     big, small = dist.split_targets(costs, ws, row_table is not None, force=force_row_sharding, all_targets=row_shard_all)
     mine = dist.assign_targets(small, ws)[rank]
     t0 = time.perf_counter()
-    blobs, stats, shared = {}, [], {}
+    blobs, stats, shared, fusion_stats = {}, [], {}, {}
     trained = {}     # target -> the model object this rank trained itself (load(save(m)) is m: no need to parse its own blob again)
 
     def one(t, table, fn):
@@ -240,8 +247,34 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
         pool = ThreadPoolExecutor(max_workers=max(1, conc - (1 if big else 0)))
         futs = {t: pool.submit(one, t, train_tables.get(t, train_table), engine.train) for t in order}
     try:
-        for t, _ in big:                  # collective: same order on every rank, identical model everywhere
-            shared[t] = one(t, row_table, engine.train_row_sharded)
+        # Row-sharded targets (collective: every rank trains the same targets, identical model everywhere).  With a fusion group the rank
+        # keeps several of them in flight -- member j of the group trains big[j], big[j + M], ... on a thread and a stream of its own, the
+        # same assignment on every rank -- and the i-th collective of all members is ONE all-reduce (include/rgbm.h "Fusion group").
+        # Without one (oracle engine of the CPU tests, a single target, RGBM_FUSION=0) they train one after another on this thread.
+        import os
+        # (members in flight: measured on one rank's share of the 100M x 32 job -- a 12.5M-row shard, eight targets -- 91.8 ms per step one
+        # after another, 79.9 with six in flight, 75.6 with all eight, 72.5 without any collective: profiles/r5g_*; a shard's targets are small,
+        # so up to eight as long as the memory budget of `conc` whole-table targets allows it)
+        n_members = min(len(big), max(1, conc, min(8, int(os.environ.get("RGBM_FUSION_MEMBERS", "8"))))) if os.environ.get("RGBM_FUSION", "1") != "0" else 1
+        if conc <= 1:
+            n_members = 1
+        group = engine.fusion_group(n_members) if (n_members > 1 and hasattr(engine, "fusion_group")) else None
+        if group is not None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            def member(j):
+                with group.member(j):
+                    return [(t, one(t, row_table, engine.train_row_sharded)) for t, _ in big[j::n_members]]
+            try:
+                with ThreadPoolExecutor(max_workers=n_members) as ex:
+                    for part in ex.map(member, range(n_members)):
+                        shared.update(part)
+                fusion_stats.update(group.info(), members=n_members)
+            finally:
+                group.close()
+        else:
+            for t, _ in big:
+                shared[t] = one(t, row_table, engine.train_row_sharded)
         for t in mine_single:
             blobs[t] = futs[t].result() if pool is not None else one(t, train_tables.get(t, train_table), engine.train)
     except BaseException:
@@ -290,5 +323,5 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
         probs = dist.gather_rows(prob, D) if prob is not None else None
         values = dist.gather_rows(val, D) if val is not None else None
     t_gather = time.perf_counter() - t0
-    return dict(labels=labels, probs=probs, values=values, models=all_blobs, stats=stats, my_targets=mine, row_sharded_targets=[t for t, _ in big],
+    return dict(labels=labels, probs=probs, values=values, models=all_blobs, stats=stats, my_targets=mine, row_sharded_targets=[t for t, _ in big], fusion=fusion_stats,
                 dirty_row0=row0, times=dict(train=t_train, exchange=t_xchg, infer=t_infer, gather=t_gather))

@@ -205,7 +205,8 @@ def test_plan_charges_launch_floor_and_collectives():
     north = [(0, 100.0), (1, 300.0), (2, 400.0), (3, 600.0), (4, 800.0), (5, 1200.0), (6, 1600.0), (7, 2400.0)]     # class trees x 10^6 rows, 100M x 32
     pl = dist.plan(north, 8, True, all_targets=True)
     assert pl["row_sharded"] == list(range(8)) and abs(pl["ideal_speedup"] - 8.0) < 1e-9
-    assert 7.0 < pl["speedup_with_floor"] < 8.0            # 7.5: the floor costs the cheap targets, the collectives all of them
-    tiny = [(t, 30.0) for t in range(8)]                    # eight targets below the launch floor: eight ranks cannot make row sharding pay
-    assert dist.plan(tiny, 8, True, all_targets=True)["speedup_with_floor"] < 1.0
-    assert dist.plan(tiny, 8, False)["speedup_with_floor"] >= 7.9    # ... target sharding does
+    assert 7.0 < pl["speedup_with_floor"] < 8.0            # 7.9: the collectives cost a little -- ONE per level for the six targets in flight (fusion group)
+    assert pl["collectives_per_iteration"] == 16            # 8 targets = two rounds of six in flight x 8 steps, not 8 x 8
+    tiny = [(t, 30.0) for t in range(8)]                    # eight targets below the launch floor: row sharding gains little (the floor once per round of six) ...
+    rs, ts = dist.plan(tiny, 8, True, all_targets=True)["speedup_with_floor"], dist.plan(tiny, 8, False)["speedup_with_floor"]
+    assert rs < 3.5 and ts > 2.0 * rs                       # ... target sharding (one whole target per rank) is the better schedule for them
