@@ -55,7 +55,9 @@ constexpr int MT_WT_ROWS = 256;              // rows of one wave tile: 4 consecu
 #ifndef MT_RING_N
 #define MT_RING_N 128
 #endif
-constexpr int MT_RING = MT_RING_N;                 // entries of a wave's built-row ring: <= 63 waiting + <= 64 appended per row step
+constexpr int MT_RING_PLAIN = MT_RING_N;           // entries of a wave's built-row ring: <= 63 waiting + <= 64 appended per row step (64: the waiting ones leave first)
+constexpr int MT_RING_SPEC = MT_RING_N < 128 ? 128 : MT_RING_N;    // wave-specialised pass: the consumer takes full batches only, so a ring holds two of them
+__host__ __device__ constexpr int mt_ring(bool spec) { return spec ? MT_RING_SPEC : MT_RING_PLAIN; }
 constexpr int MT_CNT_REP = 8;
 
 constexpr int MT_THREADS_ACC2 = 768;
@@ -165,7 +167,7 @@ constexpr int LV_ROOT_FIXED = 256;
 constexpr long long MT_SPARSE_DIV = MT_SPARSE_DIV_N;
 __host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2, bool spec = false) {
     return ((!acc2 && !spec) ? (long long)MT_MAX_T * 8 /* live-node masks of the sparse sweep */ : 0) + (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
-           (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * MT_RING * ((acc2 ? 32 : 16) + 8 + 2) + 256;     // (consumer waves have no ring)
+           (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * mt_ring(spec) * ((acc2 ? 32 : 16) + 8 + 2) + 256;     // (consumer waves have no ring)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     constexpr int NCONS = SPEC ? MT_CONSUMERS : 0, NPROD = WAVES - NCONS;     // waves that walk the rows / waves that only run batches
     constexpr int NACC = ACC2 ? 2 : 1;                     // chunks accumulated by this launch
     constexpr int NRINGS = SPEC ? NPROD : WAVES;
+    constexpr int MT_RING = mt_ring(SPEC);
     // SPARSE: class trees whose expanded parents hold a few per cent of the rows (the deep levels of many-class targets: 1.3 % at level 6
     // of the K = 64 target, profiles/r04z_*) are not walked tile by tile; see "sparse sweep" below
     constexpr bool SPARSE = (NCHR == 1) && !ACC2 && !SPEC;
@@ -759,6 +762,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                         if (p_tail + n_new - p_head_seen > (uint32_t)MT_RING) __builtin_amdgcn_s_sleep(2);
                     }
                 }
+                // a ring smaller than 128 entries (MT_RING_N=64: 26 KB more LDS for histograms) may not hold this row step's entries next to the
+                // waiting ones: those leave first, as a partial batch (never taken with 128 entries: <= 63 wait, <= 64 arrive)
+                if (!SPEC && MT_RING < 128 && r_cnt + (int)__popcll(m) > MT_RING) run_batch(r_cnt);
                 if (built) {
                     const int pos = SPEC ? (int)((p_tail + (uint32_t)__popcll(m & lane_lt)) & (uint32_t)(MT_RING - 1))
                                          : (r_head + r_cnt + (int)__popcll(m & lane_lt)) & (MT_RING - 1);
