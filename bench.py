@@ -259,7 +259,7 @@ def main():
     # ---- inputs (outside the timed region: detector + encoder outputs, resident in HBM) + the warm-up fits
     eng = HipEngine(device_id=local_rank)
 
-    def load_and_warm(shard_only):
+    def load_and_warm(shard_only, allow_row_comm=True):
         """Generates / uploads this rank's tables and runs the warm-up fits.  Returns None when a shard-only job's row-sharded warm-up failed
         (the caller then loads whole tables on every rank and runs target-sharded: slower to set up, but the job completes)."""
         row_base = 0
@@ -300,7 +300,7 @@ def main():
         row_tab = None
         if shard_only:
             row_tab = train_tab
-        elif world > 1 and a.mode == "auto" and rdist.init_row_comm(local_rank):
+        elif world > 1 and a.mode == "auto" and allow_row_comm and rdist.init_row_comm(local_rank):
             b0, c0 = rdist.shard_rows(train_src.shape[1], world, rank)
             row_tab = eng.upload(np.ascontiguousarray(train_src[:, b0:b0 + c0]), cards)
         elif world == 1 and a.force_row_sharding:
@@ -325,17 +325,18 @@ def main():
                 # collective warm-up (RCCL kernels, channels) that doubles as a self-check: the row-sharded model must be the
                 # bytes of the single-device model trained a moment ago.  Any failure or mismatch on any rank -> every rank drops
                 # the communicator and the job runs target-sharded (the reference's own parallel mode).
-                ok = 1
+                ok, dig = 1, b"failed"
                 try:
                     ms = eng.train_row_sharded(row_tab, t, feats, balanced_class_weight(label_counts[t]), model_params(int(cards[t]), p))
-                    if shard_only:   # no rank holds the whole table: the ranks must at least agree on the model, byte for byte
-                        digests = rdist.exchange_blobs({rank: hashlib.md5(ms.save()).digest()})
-                        ok = int(len(set(digests.values())) == 1)
-                    else:
+                    dig = hashlib.md5(ms.save()).digest()
+                    if not shard_only:
                         ok = int(ms.save() == m_bytes)
                 except Exception as e:  # noqa: BLE001
                     print("[bench] row-sharded warm-up failed on rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
                     ok = 0
+                if shard_only and world > 1:   # no rank holds the whole table: the ranks must at least agree on the model, byte for byte
+                    digests = rdist.exchange_blobs({rank: dig})      # (every rank takes part, also one whose fit failed: no rank waits for a missing peer)
+                    ok = int(ok and len(set(digests.values())) == 1)
                 if world > 1:
                     flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
                     torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
@@ -357,7 +358,7 @@ def main():
     if inp is None:
         print("[bench] rank %d: shard-only job falls back to target sharding over torch's group (every rank loads the whole table)" % rank, file=sys.stderr, flush=True)
         shard_only = False
-        inp = load_and_warm(False)
+        inp = load_and_warm(False, allow_row_comm=False)
     row_base, cards, null_truth, t_gen, dirty_pos, dirty_rows = inp["row_base"], inp["cards"], inp["null_truth"], inp["t_gen"], inp["dirty_pos"], inp["dirty_rows"]
     n_cells, n_dirty_rows, label_counts, train_tab, dirty_tab = inp["n_cells"], inp["n_dirty_rows"], inp["label_counts"], inp["train_tab"], inp["dirty_tab"]
     t_up, upload_bytes, row_tab, row_sharding_note = inp["t_up"], inp["upload_bytes"], inp["row_tab"], inp["note"]
@@ -411,7 +412,7 @@ def main():
     # `roofline.achieved` counts what it accumulated -- `frac_needed` prices the same launches at the bytes LightGBM's own growth order needs
     from repair import _native as _N
     needed_level_rows = 0
-    if rank == 0 and not shard_only:
+    if rank == 0 and world == 1:      # (one rank: its statistics cover every launch the figure is priced over)
         needed_level_rows = sum(_N.needed_built_rows(res_roof["models"][s_["target"]], BASE_PARAMS["max_depth"]) for s_ in res_roof["stats"])
 
     fixed_shards = 0.0

@@ -44,6 +44,8 @@ final)
   python tools/make_traffic_json.py $O/pmc32_FETCH_SIZE $O/pmc32_WRITE_SIZE ${tag}_100m32 --rows 100000000 --cols 32 --targets $T8 > $O/traffic32_json.log 2>&1; tail -4 $O/traffic32_json.log
   cp profiles/traffic.json $O/traffic.json; cp profiles/${tag}*_hbm_traffic_pmc.txt $O/ 2>/dev/null
   timeout 1200 python bench.py --config 100m32 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_100m32.log 2>&1; J $O/bench_100m32.log $O/bench_100m32_steps20_and_complete_job.json; show $O/bench_100m32_steps20_and_complete_job.json
+  BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-full-job --no-cpu-baseline --roofline-steps 1 > $O/bench_2ranks.log 2>&1; J $O/bench_2ranks.log $O/bench_2ranks_on_one_gpu_gloo_steps5.json; show $O/bench_2ranks_on_one_gpu_gloo_steps5.json
+  timeout 600 python bench.py --train-rows 10000 --no-cpu-baseline > $O/bench_train_rows_10000.log 2>&1; J $O/bench_train_rows_10000.log $O/bench_train_rows_10000.json; show $O/bench_train_rows_10000.json
   find $O -name "*.csv" -size +2M -delete; find $O -name "*.db" -delete; rm -rf $O/pmc_* $O/pmc32_* $O/trace_seq ;;
 *) echo "unknown task $task"; exit 2 ;;
 esac
