@@ -6,6 +6,7 @@ two hold the HIP trainer to the oracle at the real shapes: the K = 64 and the bi
 target of a configs[3] shard, two boosting iterations each, serialised model bytes identical.  The oracle runs its histograms
 feature-parallel (OpenMP; bit-identical for any thread count), which keeps each case to a minute or two of host time.
 
+Round 5: the golden file holds ALL 16 targets of the job (60 iterations each) and a second file the 12.5M x 32 shard (30 iterations).
 Round 4 adds the pin PAST iteration 2: tests/golden/bench_job_digests.json holds the oracle's per-iteration
 tree digests of the K = 64 and the binary target of the 10M x 16 job for 60 boosting iterations (20 minutes of host time, generated
 once by tests/golden/make_bench_job_golden.py); the HIP trainer trains those targets WITH FIVE OTHER TARGETS IN FLIGHT -- the
