@@ -149,3 +149,40 @@ def test_chain_fills_only_nulls_and_feeds_later_models():
     if both.any():
         p_chain = models[1].predict(np.ascontiguousarray(tbl[feats][:, both]))
         assert np.array_equal(p_chain.argmax(1), lab[1][both])
+
+
+def test_model_trees_and_needed_built_rows_of_a_serialised_model():
+    """repair._native.model_trees / needed_built_rows (bench.py's `roofline.frac_needed`): the blob parser against the test suite's own
+    (tests/numerics_bound.parse_trees), and the rows the finished trees needed below their roots against a direct walk of one tree."""
+    import numpy as np
+    from oracle import oracle as O
+    from repair import _native as N
+    from tests.numerics_bound import parse_trees
+    from tests.synth import make_table, balanced_weights
+    d, _, cards = make_table(6000, 8, seed=3)
+    t = 5
+    feats = [c for c in range(8) if c != t]
+    r = d[t] >= 0
+    K = int(cards[t])
+    blob = O.train(np.ascontiguousarray(d[feats][:, r]), cards[feats], d[t][r], K, class_weight=balanced_weights(d[t], K), objective=1, num_class=K,
+                   n_estimators=3, max_depth=4, num_leaves=12, min_data_in_leaf=5).save()
+    Ka, na, ta = N.model_trees(blob)
+    Kb, nb, tb = parse_trees(blob)
+    assert (Ka, na, len(ta)) == (Kb, nb, len(tb)) == (K, 3, 3 * K)
+    for a, b in zip(ta, tb):
+        for name in ("feat", "theta", "dleft", "left", "right", "gain", "leaf_value", "leaf_count"):
+            assert np.array_equal(a[name], b[name])
+
+    def walk(tr, max_depth):
+        def size(ref):
+            return int(tr["leaf_count"][~ref]) if ref < 0 else size(int(tr["left"][ref])) + size(int(tr["right"][ref]))
+
+        def rec(ref, depth):
+            if ref < 0:
+                return 0
+            a, b = int(tr["left"][ref]), int(tr["right"][ref])
+            here = min(size(a), size(b)) if depth + 1 < max_depth else 0
+            return here + rec(a, depth + 1) + rec(b, depth + 1)
+        return rec(0, 0) if len(tr["feat"]) else 0
+    assert N.needed_built_rows(blob, 4) == sum(walk(tr, 4) for tr in ta)
+    assert 0 < N.needed_built_rows(blob, 4) < N.needed_built_rows(blob, 8) + 1
