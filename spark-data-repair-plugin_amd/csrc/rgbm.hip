@@ -526,7 +526,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // instead of one pass that accumulates both), RGBM_MT_SPEC=0|1 (wave-specialised level pass), RGBM_MT_SPARSE=0 (no sparse sweep: class trees
 // with few live rows are walked tile by tile like the others).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than two copies of the level's histograms (default), 0 = never, 1 = every plain one-chunk pass */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 6 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (6 = three copies) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -542,6 +542,9 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_SPARSE")) w.mt_sparse = atoi(e) != 0;
     if (const char* e = getenv("RGBM_FUSE_GRAD")) w.fuse_grad = atoi(e) != 0;
     if (const char* e = getenv("RGBM_MT_LOCK")) w.mt_lock = atoi(e);
+    if (const char* e = getenv("RGBM_MT_ROT")) w.mt_rot = atoi(e);
+    if (const char* e = getenv("RGBM_MT_ROT_COPIES2")) w.mt_rot_copies2 = atoi(e);
+    if (const char* e = getenv("RGBM_MT_ROT_T")) w.mt_rot_T = atoi(e) != 0;
     w.timing = getenv("RGBM_TIMING") != nullptr;
     return w;
 }
@@ -883,7 +886,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<FeatMeta> d_vfmeta; DevBuf<ChunkMeta> d_vcmeta; DevBuf<uint4> d_rec_j; DevBuf<HistBin> d_part_j, d_red_j;
     DevBuf<JointFeat> d_jf; DevBuf<int16_t> d_binfeat;
     // one k_level_mt launch of a level: (chunk, window of built slots); the first one of a level routes
-    struct MtLaunch { int ch, slot0, nslots, route, T, G, gx, acc2; };
+    struct MtLaunch { int ch, slot0, nslots, route, T, G, gx, acc2, rot; };
     std::vector<std::vector<MtLaunch>> mt_plan(LV_MAX_DEPTH + 1);
     std::vector<int> mt_gx(LV_MAX_DEPTH + 1, 8);           // row blocks per class tree of a level's launches (one value per level: the partials share it)
     if (level_mode) {
@@ -952,10 +955,21 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 const long long t_nodes = std::max<long long>(win, cap / rep_target);
                 int T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(t_nodes / win, MT_MAX_T), std::min<long long>(K, MT_MAX_RT / (2 * worst))));
                 if (sw.mt_T >= 1) T = std::max(1, std::min(T, sw.mt_T));
+                // Feature rotation of the histogram updates (rgbm_level.h, MT_ROT) for the launches whose LDS holds fewer than three copies of their
+                // worst-case histograms -- the deepest dense levels, where rows of one cluster pile up on one address per feature: measured -11 % at
+                // level 5 of the K = 64 target and +35-60 % where there IS room for replicas (profiles/r5c_*), hence per launch.  Plain one-chunk pass only.
+                const bool plain1 = (!acc2 && nchunk == 1 && !spec && mt_thr == LV_THREADS) || (acc2 && spec);      // the two instantiations that exist with rotation
+                const bool rot = plain1 && (sw.mt_rot == 1 || (sw.mt_rot < 0 && cap * 2 < (long long)sw.mt_rot_copies2 * T * win)) &&
+                                 (long long)T * win * (node_bytes + mt_rot_dummy(true) * 16) <= lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec);
+                // a rotated launch needs ONE copy: as many class trees per workgroup as the LDS holds (RGBM_MT_ROT_T=0: keep the T sized for replication)
+                if (rot && sw.mt_rot_T && sw.mt_T < 1) {
+                    const long long cap_rot = (lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec)) / (node_bytes + mt_rot_dummy(true) * 16);
+                    T = (int)std::max<long long>(T, std::min<long long>(std::min<long long>(cap_rot / win, MT_MAX_T), std::min<long long>(K, MT_MAX_RT / (2 * worst))));
+                }
                 const int G = (K + T - 1) / T;
                 if (ch == 0) G_first = G;
                 for (int s0 = 0; s0 < worst; s0 += win)
-                    mt_plan[level].push_back(MtLaunch{ch, s0, win, (ch == 0 && s0 == 0) ? 1 : 0, T, G, 0, acc2 ? 1 : 0});
+                    mt_plan[level].push_back(MtLaunch{ch, s0, win, (ch == 0 && s0 == 0) ? 1 : 0, T, G, 0, acc2 ? 1 : 0, rot ? 1 : 0});
             }
             const long long gmin = std::max<long long>(1, (N + (1ll << 22) - 1) >> 22);
             // row blocks per class tree: a multiple of 8 (one XCD each); G * gx workgroups should fill whole rounds of 256 CUs (G = 24: 8 row
@@ -1050,12 +1064,16 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             std::lock_guard<std::mutex> lk(attr_mu);
             if (!attr_done[tab.device & 63]) {
                 HIPCHK(hipFuncSetAttribute((const void*)k_level_root, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
-#define RGBM_MT_ATTR1(NCHR, BAG, ROUTE, THR, ACC, SPEC) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, ROUTE, THR, ACC, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
+#define RGBM_MT_ATTR1(NCHR, BAG, ROUTE, THR, ACC, ...) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, ROUTE, THR, ACC, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
 #define RGBM_MT_ATTR(NCHR, THR, ACC, SPEC) RGBM_MT_ATTR1(NCHR, false, true, THR, ACC, SPEC); RGBM_MT_ATTR1(NCHR, false, false, THR, ACC, SPEC); \
                                            RGBM_MT_ATTR1(NCHR, true, true, THR, ACC, SPEC); RGBM_MT_ATTR1(NCHR, true, false, THR, ACC, SPEC)
                 RGBM_MT_ATTR(0, LV_THREADS, false, false); RGBM_MT_ATTR(1, LV_THREADS, false, false); RGBM_MT_ATTR(2, LV_THREADS, false, false);
                 RGBM_MT_ATTR(2, MT_THREADS_ACC2, true, false); RGBM_MT_ATTR(1, 768, false, false);
                 RGBM_MT_ATTR(1, LV_THREADS, false, true); RGBM_MT_ATTR(2, MT_THREADS_ACC2, true, true);
+                RGBM_MT_ATTR1(1, false, true, LV_THREADS, false, false, true); RGBM_MT_ATTR1(1, false, false, LV_THREADS, false, false, true);
+                RGBM_MT_ATTR1(1, true, true, LV_THREADS, false, false, true); RGBM_MT_ATTR1(1, true, false, LV_THREADS, false, false, true);
+                RGBM_MT_ATTR1(2, false, true, MT_THREADS_ACC2, true, true, true); RGBM_MT_ATTR1(2, false, false, MT_THREADS_ACC2, true, true, true);
+                RGBM_MT_ATTR1(2, true, true, MT_THREADS_ACC2, true, true, true); RGBM_MT_ATTR1(2, true, false, MT_THREADS_ACC2, true, true, true);
 #undef RGBM_MT_ATTR
 #undef RGBM_MT_ATTR1
                 attr_done[tab.device & 63] = 1;
@@ -1162,14 +1180,15 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const dim3 grid((unsigned)L.G * (unsigned)L.gx);
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
-#define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, SPEC) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, SPEC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+#define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, ...) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, __VA_ARGS__>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
                                                                           d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, l1); \
-                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, SPEC>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, __VA_ARGS__>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
                                                                    d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, l1); } while (0)
-#define RGBM_LAUNCH_MT(NCHR, THR, ACC, SPEC) do { if (use_bagging) RGBM_LAUNCH_MT2(NCHR, true, d_inbag.p, THR, ACC, SPEC); else RGBM_LAUNCH_MT2(NCHR, false, nullptr, THR, ACC, SPEC); } while (0)
-                if (L.acc2) { if (sw.mt_spec != 0) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true); else RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, false); }
+#define RGBM_LAUNCH_MT(NCHR, THR, ACC, ...) do { if (use_bagging) RGBM_LAUNCH_MT2(NCHR, true, d_inbag.p, THR, ACC, __VA_ARGS__); else RGBM_LAUNCH_MT2(NCHR, false, nullptr, THR, ACC, __VA_ARGS__); } while (0)
+                if (L.acc2) { if (sw.mt_spec != 0 && L.rot) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true, true); else if (sw.mt_spec != 0) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true); else RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, false); }
                 else if (nchr == 1 && sw.mt_spec == 1) RGBM_LAUNCH_MT(1, LV_THREADS, false, true);
                 else if (nchr == 1 && sw.mt_threads == 768) RGBM_LAUNCH_MT(1, 768, false, false);
+                else if (nchr == 1 && L.rot) RGBM_LAUNCH_MT(1, LV_THREADS, false, false, true);
                 else if (nchr == 1) RGBM_LAUNCH_MT(1, LV_THREADS, false, false);
                 else if (nchr == 2) RGBM_LAUNCH_MT(2, LV_THREADS, false, false);
                 else RGBM_LAUNCH_MT(0, LV_THREADS, false, false);

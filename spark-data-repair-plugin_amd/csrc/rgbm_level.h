@@ -137,21 +137,26 @@ __host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int q) {
 // at most four replicas (indexed by l / 16) resolve completely.  The record of an entry is rotated by (l mod 16) bytes once (12 VALU), after
 // which step j reads byte j exactly as before; feature slots a lane does not have (beyond nfeat, or byte 15 = the slot id) are masked to
 // bin 0 of a per-replica dummy slot.  Replication under rotation is one uniform shift <= 2 for every feature.
-// Measured (profiles/r5c_*): it helps where the LDS holds ONE copy (level 5 of K = 64: 3.88 -> 3.46 ms) and costs 35-60 % at levels 1-4,
-// where the replicated layout is better than conflict-free: rows of a cluster hold the same bin, replica = lane index puts the lanes of an
-// instruction on CONSECUTIVE 8-byte slots -- no bank conflict at all -- while the rotated lanes land on pseudo-random banks.  Off by default;
-// kept as a compile-time experiment (tools/build_variants.sh rot1 "-DMT_ROT=1").
+// Measured (profiles/r5c_*, r5o_*): as the ONLY form it loses 35-60 % at levels 1-4 of the K = 64 target -- where the LDS has room, the replicated layout is
+// better than conflict-free: rows of a cluster hold the same bin, replica = lane index puts the lanes of an instruction on CONSECUTIVE 8-byte slots (no
+// bank conflict at all), while the rotated lanes land on pseudo-random banks -- and it wins where the LDS holds one or two copies: level 5 of K = 64
+// 3.93 -> 3.43 ms, of K = 32 2.41 -> 1.41, of K = 16 1.44 -> 0.82, and most levels of the two-chunk pass (a node's two histograms are 10 KB).  So rotation is a
+// TEMPLATE PARAMETER (ROTP) and the host picks it per launch: fewer than three copies of the launch's worst-case histograms fit -> rotate, and give the
+// workgroup as many class trees as one copy allows (rgbm.hip, RGBM_MT_ROT / RGBM_MT_ROT_COPIES2 / RGBM_MT_ROT_T).  Bench step 83.9 -> 80.5 ms (same box),
+// one rank's 12.5M x 32 shard 72.1 -> 64.1 ms.  -DMT_ROT=1 still rotates everything (the experiment).
 #ifndef MT_ROT
 #define MT_ROT 0
 #endif
-constexpr int MT_ROT_DUMMY = MT_ROT ? 4 : 0;         // dummy slots per node (one per replica index): where masked-off lanes add
-__host__ __device__ inline int mt_shift(int nbins, int q) { return MT_ROT ? (q < 0 ? 0 : (q > 2 ? 2 : q)) : lv_shift(nbins, q); }
-__host__ __device__ inline int mt_slots(const FeatMeta* fm, int nfeat, int q) {
+constexpr bool MT_ROT_ALL = MT_ROT != 0;             // -DMT_ROT=1: every level pass rotates (the experiment); default: only the launches the host picks (template parameter ROTP)
+__host__ __device__ constexpr int mt_rot_dummy(bool rot) { return rot ? 4 : 0; }         // dummy slots per node (one per replica index): where masked-off lanes add
+__host__ __device__ inline int mt_shift(int nbins, int q, bool rot = MT_ROT_ALL) { return rot ? (q < 0 ? 0 : (q > 2 ? 2 : q)) : lv_shift(nbins, q); }
+__host__ __device__ inline int mt_slots(const FeatMeta* fm, int nfeat, int q, bool rot = MT_ROT_ALL) {
     int t = 0;
-    for (int j = 0; j < nfeat; ++j) t += fm[j].nbins << mt_shift(fm[j].nbins, q);
+    for (int j = 0; j < nfeat; ++j) t += fm[j].nbins << mt_shift(fm[j].nbins, q, rot);
     return t;
 }
-constexpr int MT_MAX_Q = MT_ROT ? 2 : LV_MAX_Q;
+__host__ __device__ constexpr int mt_max_q(bool rot) { return rot ? 2 : LV_MAX_Q; }
+constexpr int MT_ROT_DUMMY = mt_rot_dummy(MT_ROT_ALL);
 
 // bytes the root pass needs besides the histogram: nothing but alignment slack
 constexpr int LV_ROOT_FIXED = 256;
@@ -329,7 +334,8 @@ struct MtTree { int32_t base, nlev, rt_off, slot0, nb, live, child_first, k; }; 
 template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers), 0 = any number of chunks, the split byte is gathered */, bool BAG,
           bool ROUTE /* the first launch of a level: moves the rows to their children; later launches find the built rows by the final ids */,
           int THREADS /* 1024, or MT_THREADS_ACC2 */, bool ACC2 /* NCHR == 2 only: the histograms of BOTH chunks are accumulated by this launch */,
-          bool SPEC /* wave-specialised: the last MT_CONSUMERS waves only run the batches (LDS atomics) out of the other waves' rings */>
+          bool SPEC /* wave-specialised: the last MT_CONSUMERS waves only run the batches (LDS atomics) out of the other waves' rings */,
+          bool ROTP = false /* feature rotation of the histogram updates (see MT_ROT): the host picks it for the launches whose LDS holds fewer than two copies */>
 __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
                                                          const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                          int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
@@ -341,6 +347,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     constexpr int NACC = ACC2 ? 2 : 1;                     // chunks accumulated by this launch
     constexpr int NRINGS = SPEC ? NPROD : WAVES;
     constexpr int MT_RING = mt_ring(SPEC);
+    constexpr bool ROT = ROTP || MT_ROT_ALL;
     // SPARSE: class trees whose expanded parents hold a few per cent of the rows (the deep levels of many-class targets: 1.3 % at level 6
     // of the K = 64 target, profiles/r04z_*) are not walked tile by tile; see "sparse sweep" below
     constexpr bool SPARSE = (NCHR == 1) && !ACC2 && !SPEC;
@@ -430,10 +437,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         if (SPARSE) xmask[lane] = 0ull;
         if (lane == 0) {
             // replication: the largest uniform shift whose histograms fit
-            int s = MT_MAX_Q;
+            int s = mt_max_q(ROT);
             const int tot = ok ? total : 0;
-            while (s > 0 && (long long)tot * (mt_slots(fm, nfeat, s) + (ACC2 ? mt_slots(fm1, nfeat1, s) : 0) + MT_ROT_DUMMY) * 16 > avail) --s;
-            const int spn0 = mt_slots(fm, nfeat, s) + (ACC2 ? mt_slots(fm1, nfeat1, s) : 0) + MT_ROT_DUMMY;
+            while (s > 0 && (long long)tot * (mt_slots(fm, nfeat, s, ROT) + (ACC2 ? mt_slots(fm1, nfeat1, s, ROT) : 0) + mt_rot_dummy(ROT)) * 16 > avail) --s;
+            const int spn0 = mt_slots(fm, nfeat, s, ROT) + (ACC2 ? mt_slots(fm1, nfeat1, s, ROT) : 0) + mt_rot_dummy(ROT);
             if ((long long)tot * spn0 * 16 > avail) atomicOr(err_flag, 2);          // (the host's window sizing guarantees the plain layout fits)
             scal[0] = tot; scal[1] = s; scal[2] = spn0; scal[3] = ((ok && livem != 0ull) ? 1 : 0) | (ok ? nkd_ : nk) << 8;
         }
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 int shj = 0, fb = 0;
-                if (j < na) { shj = mt_shift(fa[j].nbins, s); fb = o; o += fa[j].nbins << shj; }
+                if (j < na) { shj = mt_shift(fa[j].nbins, s, ROT); fb = o; o += fa[j].nbins << shj; }
                 pk |= (unsigned long long)(shj + 3) << (4 * j); cj[a][j] = (fb + (lane & ((1 << shj) - 1))) * 8;
                 if (tid == 0) {
                     const int q = a * 16 + j;
@@ -518,10 +525,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     // first slot (+ the lane's replica l / 16), or of the lane's dummy slot when the chunk has no such feature; rmask[a] zeroes the bytes of
     // the rotated record that are not features, so that a masked lane adds to bin 0 of its dummy slot.
     uint32_t rmask[NACC][4];
-    const int rot_sh = mt_shift(1, s) + 3;            // uniform under rotation
-    if (MT_ROT) {
+    const int rot_sh = mt_shift(1, s, ROT) + 3;            // uniform under rotation
+    if (ROT) {
         const int r16 = lane & 15, c4 = lane >> 4;
-        const int spn_valid = spn - MT_ROT_DUMMY;
+        const int spn_valid = spn - mt_rot_dummy(ROT);
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
             const int na = a == 0 ? nfeat : nfeat1;
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g) + li * spn8;
             uint32_t w[4] = {r.x, r.y, r.z, r.w};
             uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w};
-            if (MT_ROT) {   // rotate the 16-byte record right by (lane mod 16) bytes: byte j of the result = byte (j + lane) mod 16 of the record
+            if (ROT) {   // rotate the 16-byte record right by (lane mod 16) bytes: byte j of the result = byte (j + lane) mod 16 of the record
                 auto rot16 = [&](uint32_t (&x)[4], const uint32_t (&mk)[4]) __attribute__((always_inline)) {
                     const bool d1 = (lane & 4) != 0, d2 = (lane & 8) != 0;
                     const uint32_t a0 = d1 ? x[1] : x[0], a1 = d1 ? x[2] : x[1], a2 = d1 ? x[3] : x[2], a3 = d1 ? x[0] : x[3];
@@ -592,9 +599,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
 #else
 #define MT_ATOMIC_ADD(p, v) atomicAdd(p, v)
 #endif
-#define MT_ATOM(A, W, j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[A][j] + (int)(((W[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << (MT_ROT ? rot_sh : (int)((shp[A] >> (4 * (j))) & 15ull)))); \
+#define MT_ATOM(A, W, j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[A][j] + (int)(((W[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << (ROT ? rot_sh : (int)((shp[A] >> (4 * (j))) & 15ull)))); \
                            MT_ATOMIC_ADD(p_, gq); MT_ATOMIC_ADD(p_ + hdelta, hq); }
-            if (MT_ROT) {        // every lane has sixteen slots per chunk (absent ones go to its dummy slot)
+            if (ROT) {        // every lane has sixteen slots per chunk (absent ones go to its dummy slot)
                 MT_ATOM(0, w, 0); MT_ATOM(0, w, 1); MT_ATOM(0, w, 2); MT_ATOM(0, w, 3); MT_ATOM(0, w, 4); MT_ATOM(0, w, 5); MT_ATOM(0, w, 6); MT_ATOM(0, w, 7);
                 MT_ATOM(0, w, 8); MT_ATOM(0, w, 9); MT_ATOM(0, w, 10); MT_ATOM(0, w, 11); MT_ATOM(0, w, 12); MT_ATOM(0, w, 13); MT_ATOM(0, w, 14); MT_ATOM(0, w, 15);
                 if (ACC2) {
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
 #pragma unroll
                 for (int j = 0; j < 14; ++j) if (j < nfeat) MT_ATOM(0, w, j);
             }
-            if (!MT_ROT && ACC2) {
+            if (!ROT && ACC2) {
                 if (nfeat1 >= 15) {
                     MT_ATOM(NACC - 1, w1, 0); MT_ATOM(NACC - 1, w1, 1); MT_ATOM(NACC - 1, w1, 2); MT_ATOM(NACC - 1, w1, 3); MT_ATOM(NACC - 1, w1, 4); MT_ATOM(NACC - 1, w1, 5);
                     MT_ATOM(NACC - 1, w1, 6); MT_ATOM(NACC - 1, w1, 7); MT_ATOM(NACC - 1, w1, 8); MT_ATOM(NACC - 1, w1, 9); MT_ATOM(NACC - 1, w1, 10); MT_ATOM(NACC - 1, w1, 11);

@@ -333,3 +333,28 @@ def test_last_pass_fused_with_the_next_gradients_changes_nothing(rows, cols, tgt
             monkeypatch.setenv("RGBM_FUSE_GRAD", v)
             blobs.append(tab.train(tgt, feats, **kw).save())
         assert blobs[0] == blobs[1], {k: v for k, v in kw.items() if k not in ("class_weight", "y_value")}
+
+
+@pytest.mark.parametrize("rows,cols,tgt", [(40000, 11, 10), (30000, 11, 8), (25000, 24, 7)])
+def test_feature_rotation_of_the_level_pass_changes_nothing(rows, cols, tgt, monkeypatch):
+    """The histogram updates of a level pass in rotated form (lane l works on feature (j + l) mod 16: rgbm_level.h, MT_ROT) -- chosen per launch
+    where the LDS holds fewer than three copies of the level's histograms (RGBM_MT_ROT=-1, the default), never (0) or for every pass that has the
+    instantiation (1) -- are the same exact integer sums in another order of atomics: the model bytes must not depend on it.  Many-class targets on
+    one 16-byte record (deep levels rotate by default) and a two-chunk table (the wave-specialised pass: both records rotated), also with bagging
+    and with a small LDS pool (several built-slot windows per level)."""
+    from repair import _native as N
+    from tests.synth import make_table, balanced_weights
+    dirty, clean, cards = make_table(rows, cols, seed=37)
+    feats = [c for c in range(cols) if c != tgt]
+    K = int(cards[tgt])
+    tab = N.Table(dirty, cards)
+    for kw, env in ((dict(), {}), (dict(bagging_fraction=0.7, bagging_freq=1), {}), (dict(num_leaves=60, min_data_in_leaf=3), {"RGBM_LV_LDS": "99000"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        blobs = []
+        for v in ("0", "-1", "1"):
+            monkeypatch.setenv("RGBM_MT_ROT", v)
+            blobs.append(tab.train(tgt, feats, class_weight=balanced_weights(dirty[tgt], K), objective=1, num_class=K, n_estimators=8, learning_rate=0.2, **kw).save())
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert blobs[0] == blobs[1] == blobs[2], (kw, env)
