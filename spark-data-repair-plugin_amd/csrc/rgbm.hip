@@ -526,7 +526,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // instead of one pass that accumulates both), RGBM_MT_SPEC=0|1 (wave-specialised level pass), RGBM_MT_SPARSE=0 (no sparse sweep: class trees
 // with few live rows are walked tile by tile like the others).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than two copies of the level's histograms (default), 0 = never, 1 = every plain one-chunk pass */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 6 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (6 = three copies) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than two copies of the level's histograms (default), 0 = never, 1 = every plain one-chunk pass */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 6 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (6 = three copies) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -545,6 +545,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_ROT")) w.mt_rot = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT_COPIES2")) w.mt_rot_copies2 = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT_T")) w.mt_rot_T = atoi(e) != 0;
+    if (const char* e = getenv("RGBM_JOINT_WIDE")) w.joint_wide = atoi(e) != 0;
     w.timing = getenv("RGBM_TIMING") != nullptr;
     return w;
 }
@@ -881,7 +882,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     int n_hnodes = 1;
     bool use_reduce = false;   // root pass: sum the per-workgroup partials in a separate kernel (many workgroups per class tree, joint bins, or row-sharded)
     // joint bins for the root pass (rgbm_level.h, k_pack_joint): a second record whose bytes hold GROUPS of low-cardinality features
-    bool joint_root = false; int vtotbins = 0;
+    bool joint_root = false, joint_wide = false; int vtotbins = 0;
     LevelConst lcj; memset(&lcj, 0, sizeof(lcj));
     DevBuf<FeatMeta> d_vfmeta; DevBuf<ChunkMeta> d_vcmeta; DevBuf<uint4> d_rec_j; DevBuf<HistBin> d_part_j, d_red_j;
     DevBuf<JointFeat> d_jf; DevBuf<int16_t> d_binfeat;
@@ -1018,15 +1019,27 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             std::vector<int> order(F); for (int f = 0; f < F; ++f) order[f] = f;
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fmeta[a].nbins > fmeta[b].nbins; });
             std::vector<std::vector<int>> groups; std::vector<int> prod;
-            for (int f : order) {
-                int best = -1;
-                for (size_t g = 0; g < groups.size(); ++g)
-                    if (prod[g] * fmeta[f].nbins <= 256 && (best < 0 || prod[g] > prod[best])) best = (int)g;
-                if (best < 0) { groups.emplace_back(); prod.push_back(1); best = (int)groups.size() - 1; }
-                groups[best].push_back(f); prod[best] *= fmeta[f].nbins;
+            auto pack = [&](int cap, std::vector<std::vector<int>>& gs, std::vector<int>& pr) {      // best-fit-decreasing into groups whose bin counts multiply to <= cap
+                gs.clear(); pr.clear();
+                for (int f : order) {
+                    int best = -1;
+                    for (size_t g = 0; g < gs.size(); ++g)
+                        if ((long long)pr[g] * fmeta[f].nbins <= cap && (best < 0 || pr[g] > pr[best])) best = (int)g;
+                    if (best < 0) { gs.emplace_back(); pr.push_back(1); best = (int)gs.size() - 1; }
+                    gs[best].push_back(f); pr[best] *= fmeta[f].nbins;
+                }
+            };
+            pack(256, groups, prod);
+            // WIDE joint codes (round 5): 16-bit fields, groups of up to 1024 joint bins, at most eight per 16-byte record -- fewer groups = fewer atomics per row
+            // (the synthetic table: 5 groups instead of 7, 10 atomics instead of 14) as long as two copies of the joint histograms fit the LDS
+            {
+                std::vector<std::vector<int>> gw; std::vector<int> pw;
+                pack(JOINT_WIDE_CAP, gw, pw);
+                long long slots2 = 0; for (int v : pw) slots2 += (long long)v * 2;
+                if (sw.joint_wide && gw.size() <= 8 && gw.size() + 2 <= groups.size() && slots2 * 16 + LV_ROOT_FIXED <= lc.lds_bytes) { groups.swap(gw); prod.swap(pw); joint_wide = true; }
             }
             const int VF = (int)groups.size();
-            if (VF > 16 || VF > F - 2) joint_root = false;
+            if (VF > (joint_wide ? 8 : 16) || VF > F - 2) joint_root = false;
             else {
                 std::vector<FeatMeta> vfm(VF); std::vector<JointFeat> jf(F); std::vector<int16_t> binfeat(tc.totbins, 0);
                 ChunkMeta vcm; vcm.first_feat = 0; vcm.nfeat = VF; vcm.fast_slots = 0; vcm.wide_bins = 0;
@@ -1049,7 +1062,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                     d_vfmeta.alloc(VF); d_vfmeta.upload(vfm.data(), VF, s); d_vcmeta.alloc(1); d_vcmeta.upload(&vcm, 1, s);
                     d_jf.alloc(F); d_jf.upload(jf.data(), F, s); d_binfeat.alloc(binfeat.size()); d_binfeat.upload(binfeat.data(), binfeat.size(), s);
                     d_rec_j.alloc((size_t)N);
-                    hipLaunchKernelGGL(k_pack_joint, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_rec.p, (long long)N, F, d_jf.p, d_rec_j.p);
+                    hipLaunchKernelGGL(k_pack_joint, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_rec.p, (long long)N, F, d_jf.p, d_rec_j.p, joint_wide ? 1 : 0);
                     d_part_j.alloc((size_t)K * lc.gx * vtotbins); d_red_j.alloc((size_t)K * vtotbins + (size_t)K * 128 /* k_level_reduce parks the counts behind the bins */);
                     lcj = lc; lcj.nchunk = 1; lcj.F = VF; lcj.totbins = vtotbins; lcj.max_built = 1;
                     use_reduce = true;
@@ -1063,7 +1076,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             static std::mutex attr_mu; static std::vector<char> attr_done(64, 0);
             std::lock_guard<std::mutex> lk(attr_mu);
             if (!attr_done[tab.device & 63]) {
-                HIPCHK(hipFuncSetAttribute((const void*)k_level_root, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+                HIPCHK(hipFuncSetAttribute((const void*)k_level_root<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
+                HIPCHK(hipFuncSetAttribute((const void*)k_level_root<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES));
 #define RGBM_MT_ATTR1(NCHR, BAG, ROUTE, THR, ACC, ...) HIPCHK(hipFuncSetAttribute((const void*)k_level_mt<NCHR, BAG, ROUTE, THR, ACC, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_LDS_BYTES))
 #define RGBM_MT_ATTR(NCHR, THR, ACC, SPEC) RGBM_MT_ATTR1(NCHR, false, true, THR, ACC, SPEC); RGBM_MT_ATTR1(NCHR, false, false, THR, ACC, SPEC); \
                                            RGBM_MT_ATTR1(NCHR, true, true, THR, ACC, SPEC); RGBM_MT_ATTR1(NCHR, true, false, THR, ACC, SPEC)
@@ -1158,11 +1172,14 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     };
     auto launch_root = [&]() {
         timed(true, [&]() {
-            if (joint_root)   // the root pass over the joint record: one pair of atomics per feature GROUP and row
-                hipLaunchKernelGGL(k_level_root, dim3((unsigned)lc.gx * (unsigned)K, 1, 1), dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node.p, d_plan.p, d_part_j.p,
+            if (joint_root && joint_wide)
+                hipLaunchKernelGGL(k_level_root<true>, dim3((unsigned)lc.gx * (unsigned)K, 1, 1), dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node.p, d_plan.p, d_part_j.p,
+                                   d_vfmeta.p, d_vcmeta.p, lcj);
+            else if (joint_root)   // the root pass over the joint record: one pair of atomics per feature GROUP and row
+                hipLaunchKernelGGL(k_level_root<false>, dim3((unsigned)lc.gx * (unsigned)K, 1, 1), dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node.p, d_plan.p, d_part_j.p,
                                    d_vfmeta.p, d_vcmeta.p, lcj);
             else
-                hipLaunchKernelGGL(k_level_root, dim3((unsigned)lc.gx * (unsigned)K, 1, nchunk), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, d_plan.p, d_part.p,
+                hipLaunchKernelGGL(k_level_root<false>, dim3((unsigned)lc.gx * (unsigned)K, 1, nchunk), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, d_plan.p, d_part.p,
                                    d_fmeta.p, d_cmeta.p, lc);
         });
     };

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, SN
 //         of a row block on ONE XCD, which then shares its L2 copy of the block's records) : (gx, K), strided tiles;  grid.z = chunk.
 // Algorithmic bytes per row: F bin bytes + 8 B (g, h).
 // ------------------------------------------------------------------------------------------------
+template <bool WIDE /* the record holds eight 16-bit joint codes (groups of up to JOINT_WIDE_CAP joint bins) instead of sixteen bytes */>
 __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __restrict__ rec, const float2* __restrict__ gh, const uint8_t* __restrict__ node,
                                                               const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                               const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta, LevelConst c) {
@@ -268,10 +269,11 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
             const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, c.sg), hq = (unsigned long long)fx_from_f32(g.y, c.sh);
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g);
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#define LV_ATOM(j) { unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu) << sh3[j])); \
+#define LV_ATOM(j) { const uint32_t code_ = WIDE ? ((w[((j) & 7) >> 1] >> (16 * ((j) & 1))) & 0xFFFFu) : ((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu); \
+                     unsigned long long* p_ = reinterpret_cast<unsigned long long*>(hb + cj[j] + (int)(code_ << sh3[j])); \
                      atomicAdd(p_, gq); atomicAdd(p_ + hdelta, hq); }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) if (j < nfeat) LV_ATOM(j);
+            for (int j = 0; j < (WIDE ? 8 : 16); ++j) if (j < nfeat) LV_ATOM(j);
 #undef LV_ATOM
         }
     };
@@ -1049,7 +1051,8 @@ __global__ __launch_bounds__(256) void k_level_reduce(const HistBin* __restrict_
 struct JointFeat { int32_t voff /* offset of the group's joint histogram */, stride, nbins /* of this feature */, nbv /* joint bins of the group */, hoff, vbyte /* byte of the joint record */, pad0, pad1; };
 
 // joint record of every row from its plain bin record(s); thread per row
-__global__ __launch_bounds__(256) void k_pack_joint(const uint4* __restrict__ rec, long long N, int F, const JointFeat* __restrict__ jf, uint4* __restrict__ rec_joint) {
+constexpr int JOINT_WIDE_CAP = 1024;     // joint bins of a group with 16-bit codes (k_level_root<true>)
+__global__ __launch_bounds__(256) void k_pack_joint(const uint4* __restrict__ rec, long long N, int F, const JointFeat* __restrict__ jf, uint4* __restrict__ rec_joint, int wide) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
@@ -1057,7 +1060,8 @@ __global__ __launch_bounds__(256) void k_pack_joint(const uint4* __restrict__ re
     for (int f = 0; f < F; ++f) {
         const uint32_t bin = rec8[((long long)(f >> 4) * N + i) * 16 + (f & 15)];
         const int vb = jf[f].vbyte;
-        w[vb >> 2] += (bin * (uint32_t)jf[f].stride) << (8 * (vb & 3));    // a group's code stays below 256: no carry into the next byte
+        if (wide) w[vb >> 1] += (bin * (uint32_t)jf[f].stride) << (16 * (vb & 1));   // (a group's code stays below 65536)
+        else w[vb >> 2] += (bin * (uint32_t)jf[f].stride) << (8 * (vb & 3));    // a group's code stays below 256: no carry into the next byte
     }
     rec_joint[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }

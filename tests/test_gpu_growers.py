@@ -358,3 +358,23 @@ def test_feature_rotation_of_the_level_pass_changes_nothing(rows, cols, tgt, mon
         for k_ in env:
             monkeypatch.delenv(k_)
         assert blobs[0] == blobs[1] == blobs[2], (kw, env)
+
+
+def test_wide_joint_codes_in_the_root_pass_change_nothing(monkeypatch):
+    """RGBM_JOINT_WIDE=1: the root pass accumulates joint histograms of up to 1024 joint bins per group (16-bit codes in the joint record, fewer groups);
+    every real feature's histogram is still the exact marginal, so the model bytes are those of the byte-sized groups and of the plain record."""
+    from repair import _native as N
+    from tests.synth import make_table, balanced_weights
+    dirty, clean, cards = make_table(300000, 16, seed=41)       # K * N >= 2^21: the joint root pass is on
+    tgt = 10
+    feats = [c for c in range(16) if c != tgt]
+    K = int(cards[tgt])
+    tab = N.Table(dirty, cards)
+    blobs = []
+    for env in ({"RGBM_JOINT_ROOT": "0"}, {"RGBM_JOINT_WIDE": "0"}, {"RGBM_JOINT_WIDE": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        blobs.append(tab.train(tgt, feats, class_weight=balanced_weights(dirty[tgt], K), objective=1, num_class=K, n_estimators=4, learning_rate=0.2).save())
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert blobs[0] == blobs[1] == blobs[2]
