@@ -213,3 +213,81 @@ def test_rccl_dead_peer_raises_instead_of_hanging(level_pass_kind):
     out = _run_ranks(2, fail_rank=1, timeout_s=8)
     assert out[1][0] == "left"
     assert out[0][0] == "error" and ("collective" in out[0][1] or "RCCL" in out[0][1]), out
+
+
+def _rccl_fused_rank(rank, world, uid, q):
+    """One process per GPU: a fusion group of two members (targets 4 and 0) over the real RCCL communicator."""
+    import os
+    import sys
+    import threading
+    os.environ["RGBM_COMM_TIMEOUT_S"] = "120"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "spark-data-repair-plugin_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from repair import _native as N
+    from tests.synth import make_table, balanced_weights
+    try:
+        dirty, clean, cards = make_table(60000, 8, seed=71, null_ratio=0.02)
+        N.comm_init(uid, rank, world, rank)
+        b0, b1 = rank * 60000 // world, (rank + 1) * 60000 // world
+        tab = N.Table(np.ascontiguousarray(dirty[:, b0:b1]), cards, device_id=rank)
+        fg = N.FusionGroup(2)
+        out, err = {}, []
+
+        def member(j, t):
+            try:
+                with fg.member(j):
+                    feats = [c for c in range(8) if c != t]
+                    K = int(cards[t])
+                    out[t] = tab.train(t, feats, class_weight=balanced_weights(dirty[t], K), row_sharded=True, objective=0 if K == 2 else 1, num_class=max(K, 2),
+                                       n_estimators=6, learning_rate=0.2, device_id=rank).save()
+            except Exception as e:  # noqa: BLE001
+                err.append("%s: %s" % (type(e).__name__, e))
+        ths = [threading.Thread(target=member, args=(j, t)) for j, t in enumerate((4, 0))]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join(timeout=300)
+        info = fg.info()
+        fg.close()
+        N.comm_finalize()
+        single = {}
+        if rank == 0 and not err:
+            full = N.Table(dirty, cards, device_id=0)
+            for t in (4, 0):
+                feats = [c for c in range(8) if c != t]
+                K = int(cards[t])
+                single[t] = full.train(t, feats, class_weight=balanced_weights(dirty[t], K), objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=6,
+                                       learning_rate=0.2, device_id=0).save()
+        q.put((rank, "error" if err else "ok", (err or out, single, info)))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "error", ("%s: %s" % (type(e).__name__, e), {}, {})))
+
+
+def test_rccl_two_processes_fusion_group(level_pass_kind):
+    """The fusion group (two row-sharded targets in flight per rank, one all-reduce per step) over REAL RCCL ranks: both models on both ranks are the
+    single-device models.  Needs two GPUs, like the tests above."""
+    if not _two_gpus():
+        pytest.skip("needs two HIP devices (one process per GPU over RCCL)")
+    import multiprocessing as mp
+    from repair import _native as N
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = N.comm_unique_id()
+    ps = [ctx.Process(target=_rccl_fused_rank, args=(r, 2, uid, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, status, payload = q.get(timeout=600)
+        res[r] = (status, payload)
+    for p in ps:
+        p.join(timeout=60)
+    assert all(s == "ok" for s, _ in res.values()), res
+    single = res[0][1][1]
+    for r in (0, 1):
+        for t in (4, 0):
+            assert res[r][1][0][t] == single[t], "rank %d target c%d" % (r, t)
+    assert res[0][1][2]["parts"] == res[1][1][2]["parts"] > res[0][1][2]["collectives"]
