@@ -960,7 +960,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 // worst-case histograms -- the deepest dense levels, where rows of one cluster pile up on one address per feature: measured -11 % at
                 // level 5 of the K = 64 target and +35-60 % where there IS room for replicas (profiles/r5c_*), hence per launch.  Plain one-chunk pass only.
                 const bool plain1 = (!acc2 && nchunk == 1 && !spec && mt_thr == LV_THREADS) || (acc2 && spec);      // the two instantiations that exist with rotation
-                const bool rot = plain1 && (sw.mt_rot == 1 || (sw.mt_rot < 0 && cap * 2 < (long long)sw.mt_rot_copies2 * T * win)) &&
+                // (a rotated step works on sixteen feature slots per chunk whatever the chunk holds: with few features most lanes of a step idle -- rotate only chunks
+                // that fill at least three quarters of them)
+                const bool rot_full = cmeta[ch].nfeat >= 12 && (!acc2 || cmeta[1].nfeat >= 12);
+                const bool rot = plain1 && (sw.mt_rot == 1 || (sw.mt_rot < 0 && rot_full && cap * 2 < (long long)sw.mt_rot_copies2 * T * win)) &&
                                  (long long)T * win * (node_bytes + mt_rot_dummy(true) * 16) <= lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec);
                 // a rotated launch needs ONE copy: as many class trees per workgroup as the LDS holds (RGBM_MT_ROT_T=0: keep the T sized for replication)
                 if (rot && sw.mt_rot_T && sw.mt_T < 1) {
