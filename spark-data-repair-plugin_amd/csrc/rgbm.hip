@@ -524,7 +524,11 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // tree of the root / level passes), RGBM_MT_TREES (cap on the class trees per level-pass workgroup), RGBM_MT_REP (LDS replication the
 // level passes are sized for, default 8), RGBM_JOINT_ROOT=0, RGBM_MT_ACC2=0 (tables of 17..32 features: one level pass per 16-feature chunk
 // instead of one pass that accumulates both), RGBM_MT_SPEC=0|1 (wave-specialised level pass), RGBM_MT_SPARSE=0 (no sparse sweep: class trees
-// with few live rows are walked tile by tile like the others).
+// with few live rows are walked tile by tile like the others).  Round 5: RGBM_MT_ROT=-1|0|1 (feature rotation of a level pass's histogram updates:
+// per launch where fewer than RGBM_MT_ROT_COPIES2 / 2 copies of its histograms fit the LDS -- the default --, never, every launch that has the
+// instantiation; RGBM_MT_ROT_T=0 keeps the replicated layout's class trees per workgroup), RGBM_MT_LOCK=<rounds> (lock-step of the class-tree groups
+// of a row block, wave-specialised pass), RGBM_FUSE_GRAD=1 (last pass fused with the next gradients), RGBM_JOINT_WIDE=1 (16-bit joint codes in the
+// root pass), RGBM_FX_ROWS / RGBM_FX_E (TEST hooks: the fixed-point grid of a bigger table; the oracle reads them too).
 constexpr int LV_THREADS_DEFAULT = 1024;
 struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than two copies of the level's histograms (default), 0 = never, 1 = every plain one-chunk pass */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 6 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (6 = three copies) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
 RunSwitches read_switches() {
