@@ -42,6 +42,11 @@ BASE_PARAMS = dict(num_leaves=31, max_depth=7, max_bin=255, min_data_in_leaf=20,
                    bagging_freq=0, seed=42, learning_rate=0.01, lambda_l1=0.0, lambda_l2=0.0,
                    min_gain_to_split=0.0, min_sum_hessian_in_leaf=1e-3, bagging_fraction=1.0, feature_fraction=1.0)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+# The LDS-atomic floor of the histogram build ("the ceiling"): a 64-bit LDS atomic instruction of one wave costs ~12.8 cycles of its
+# CU's LDS unit when its lanes do not pile up on addresses (measured on the root pass and by tools/lds_atomic_lanes.hip: profiles/r01_lds_atomic_microbench.txt,
+# r03d_*; the unit's own floor is 10.3), the chip has 256 CUs at 2.4 GHz.  A launch that accumulates P rows with A atomics each cannot finish before
+# P * A / 64 * 12.8 / (256 * 2.4e9) seconds, whatever its HBM traffic is.
+LDS_ATOMIC_CYCLES, N_CUS, CLOCK_HZ = 12.8, 256, 2.4e9
 REF_N_ESTIMATORS = 300         # model.lgb.n_estimators default, python/repair/train.py:53-55
 CONFIGS = {
     "10m16": dict(rows=10_000_000, cols=16, seed=42, n_targets=16, baseline="configs[2]"),
@@ -172,20 +177,51 @@ def _spawn_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
-def _load_traffic(config, world):
+def _load_traffic(config, world, rows, cols, train_rows, forced_collectives):
     """Measured HBM bytes per launch of the two histogram kernel classes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
     calibrated on a kernel of known traffic as MI355X_MICROARCH.md prescribes): the counters cannot be read from inside the process,
     so the numbers come from the committed profile of the same workload over ALL its target models (tools/make_traffic_json.py;
-    profiles/traffic.json says which run) -- the same set of launches the algorithmic bytes next to them describe."""
+    profiles/traffic.json says which run) -- the same set of launches the algorithmic bytes next to them describe.  ONLY for the run
+    the profile was taken on: the whole table of the named config on one rank, every model trained on all rows (a
+    --train-rows / --rows line used to carry the whole-table counters and printed 25-60 TB/s of "HBM traffic")."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         e = t.get(config)
-        if e and "classes" in e and world == 1:
+        same_run = (world == 1 and not forced_collectives and not (0 < train_rows < rows) and
+                    rows == e.get("rows", CONFIGS[config]["rows"]) and cols == e.get("cols", CONFIGS[config]["cols"]))
+        if e and "classes" in e and same_run:
             return e
     except Exception:  # noqa: BLE001
         pass
     return None
+
+
+def true_reference_baseline(cols, seed, targets, steps_full):
+    """The REAL reference arithmetic, when it can be imported: lightgbm (pinned 3.3.1 in bin/requirements.txt:6; python/repair/train.py:92,
+    121-131) with the reference's fixed parameters on the bounded sample cpu_baseline() uses.  Neither this container nor the GPU box has
+    the wheel (no network), so today this reports why it was skipped; tests/test_true_reference_optional.py is the parity side of the hook."""
+    try:
+        import lightgbm as lgb
+    except Exception as e:  # noqa: BLE001
+        return dict(value=None, skipped="lightgbm not importable (%s); the hook runs the day the wheel is at hand" % type(e).__name__)
+    from repair.synth import make_table
+    n, iters = 250_000, 10
+    dirty, _, cards = make_table(n, cols, seed=seed)
+    cells = int((dirty[targets] < 0).sum())
+    t_all = 0.0
+    for t in targets:
+        feats = [c for c in range(cols) if c != t]
+        r = dirty[t] >= 0
+        X = dirty[feats].T.astype(np.float64); X[X < 0] = np.nan
+        K = int(cards[t])
+        m = lgb.LGBMClassifier(boosting_type="gbdt", objective="binary" if K <= 2 else "multiclass", class_weight="balanced", learning_rate=0.01, max_depth=7,
+                               max_bin=255, reg_alpha=0.0, min_split_gain=0.0, n_estimators=iters, random_state=42, n_jobs=-1)
+        t0 = time.perf_counter()
+        m.fit(X[r], dirty[t][r]); m.predict(X[~r])
+        t_all += time.perf_counter() - t0
+    return dict(value=cells / max(t_all * steps_full / float(iters), 1e-9), unit="repaired cells/sec", cores=os.cpu_count() or 1, kind="reference",
+                version=getattr(lgb, "__version__", "?"), sample="%d-row sample, %d of %d iterations, scaled" % (n, iters, steps_full))
 
 
 def main():
@@ -437,7 +473,9 @@ def main():
             idx = np.searchsorted(dirty_pos, pos)
             fixed += int((labels[i][idx] == truth).sum())
         achieved = hist_bytes_all / max(hist_ms_all, 1e-9) * 1e-6
-        traffic = _load_traffic(a.config, world)
+        traffic = _load_traffic(a.config, world, rows, cols, a.train_rows, a.force_row_sharding)
+        st0 = res_roof["stats"][0] if res_roof["stats"] else {}
+        atoms = {"root": int(st0.get("root_atomics_per_row", 0)), "level": int(st0.get("level_atomics_per_row", 0))}
         # the two kernel classes of the histogram build, each with its own algorithmic bytes, launch time and (from the committed PMC
         # profile of the same target set) HBM-side bytes per launch
         classes = {}
@@ -453,11 +491,20 @@ def main():
                     c["frac_needed"] = needed_level_rows * (cols - 1 + 8) / max(ms, 1e-9) * 1e-6 / HBM_PEAK_GBS
             else:
                 c["bound"] = "lds-atomic: 14 ds_add_u64 per row (7 joint-bin groups x (g, h)) at ~12.8 cycles per wave instruction; algorithmic bytes follow SURVEY 8(d) (F + 8 per row), the pass's HBM traffic is about half of them"
+            if atoms[name]:     # the LDS-atomic floor of this class: (accumulated rows x atomics per row / 64 lanes) wave instructions at the conflict-free rate
+                pairs = nbytes / (cols - 1 + 8) / nl
+                c["atomics_per_row"] = atoms[name]
+                c["atomic_floor_us"] = pairs * atoms[name] / 64.0 * LDS_ATOMIC_CYCLES / (N_CUS * CLOCK_HZ) * 1e6
+                c["atomic_floor_share_of_launch"] = c["atomic_floor_us"] / max(c["avg_launch_us"], 1e-9)
             if traffic and name in traffic["classes"]:
                 tc = traffic["classes"][name]
-                c["traffic"] = {"fetch_bytes_per_launch": tc["fetch_bytes_per_launch"], "write_bytes_per_launch": tc["write_bytes_per_launch"],
-                                "ratio_to_algorithmic": tc["bytes_per_launch"] / max(nbytes / nl, 1e-9),
-                                "hbm_GBps": tc["bytes_per_launch"] / max(ms / nl, 1e-9) * 1e-6}
+                gbps = tc["bytes_per_launch"] / max(ms / nl, 1e-9) * 1e-6
+                if gbps <= HBM_PEAK_GBS:      # (a figure above the HBM peak means the profile does not describe THIS run: not evidence, not printed)
+                    c["traffic"] = {"fetch_bytes_per_launch": tc["fetch_bytes_per_launch"], "write_bytes_per_launch": tc["write_bytes_per_launch"],
+                                    "ratio_to_algorithmic": tc["bytes_per_launch"] / max(nbytes / nl, 1e-9), "hbm_GBps": gbps}
+                else:
+                    c["traffic"] = {"dropped": "profiles/traffic.json would put this class at %.0f GB/s, above the HBM peak: the committed counters are not of this run" % gbps}
+                    traffic = None
             classes[name] = c
         out = {
             "metric": "repaired cells/sec", "value": n_cells / elapsed, "unit": "cells/s",
@@ -493,7 +540,13 @@ def main():
                          "measured_on": "sequential pass (one target model at a time) of %d boosting iterations of the same job, %.2f s; HIP events per launch" % (roof_steps, elapsed_roof),
                          "launches": int(launches_all), "avg_launch_us": hist_ms_all * 1e3 / max(launches_all, 1),
                          "alg_bytes_per_launch": hist_bytes_all / max(launches_all, 1),
-                         "root_scan_GBps_rank0": root_bytes / max(root_ms, 1e-9) * 1e-6},
+                         "root_scan_GBps_rank0": root_bytes / max(root_ms, 1e-9) * 1e-6,
+                         # the ceiling of the two-64-bit-atomics-per-feature numerics: the same algorithmic bytes over the LDS-atomic floors of both classes
+                         "atomic_floor": ({"ms_per_roofline_pass": sum(classes[n]["atomic_floor_us"] * classes[n]["launches"] for n in classes) * 1e-3,
+                                           "frac_at_floor": hist_bytes_all / max(sum(classes[n]["atomic_floor_us"] * classes[n]["launches"] for n in classes) * 1e-3, 1e-9) * 1e-6 / HBM_PEAK_GBS,
+                                           "cycles_per_wave_atomic": LDS_ATOMIC_CYCLES, "cus": N_CUS, "clock_hz": CLOCK_HZ,
+                                           "note": "frac cannot exceed frac_at_floor with two 64-bit LDS atomics per feature and built row (DESIGN 5, the ceiling)"}
+                                          if all("atomic_floor_us" in classes[n] for n in classes) else None)},
         }
         if row_sharding_note:
             out["config"]["row_sharding"] = row_sharding_note
@@ -504,6 +557,7 @@ def main():
                                      "fusion": res.get("fusion") or None}
         if not a.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (the other ranks would sit in the barrier below)
             out["cpu_baseline"] = cpu_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS, full_rows=rows if not (0 < a.train_rows < rows) else 0, cells_full=n_cells)
+            out["cpu_baseline"]["true_reference"] = true_reference_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS)
             fst = out["cpu_baseline"].get("full_size_target")
             if fst and "train_sec" in fst:      # the GPU's wall time for the same target and iteration count (sequential roofline pass, setup included pro rata)
                 g = [s_ for s_ in res_roof["stats"] if s_.get("target") == targets[0]]

@@ -82,6 +82,9 @@ typedef struct {
     int64_t trees;           /* trees grown */
     double route_ms;         /* always 0 since numerics version 200: DataPartition::Split of a level is part of the level pass (k_level_mt), */
     int64_t route_launches;  /* whose time is in hist_ms; the fields keep the struct layout of version 102 */
+    /* version 220: what the LDS-atomic floor of the histogram build is priced with (bench.py roofline.classes.*.atomic_floor_us) */
+    int64_t root_atomics_per_row;   /* 64-bit LDS atomics a root pass issues per accumulated row: 2 per joint-bin group (or per feature without joint bins) */
+    int64_t level_atomics_per_row;  /* ... a level pass issues per built row: 2 per feature */
 } rgbm_train_stats;
 
 /* Number of usable HIP devices (0 if none). */

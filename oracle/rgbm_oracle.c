@@ -276,6 +276,28 @@ static inline int64_t fx_from_f32(float v, double scale) {
     return (int64_t)rint(x);
 }
 
+/* Numerics v2.2 (csrc/rgbm_numerics.h): the fixed-point grid is chosen PER CLASS TREE AND BOOSTING ITERATION.  Every in-bag (g, h) has a coarse
+ * magnitude q = ceil(|v| * 2^c) with c = 24 - ceil_log2(bound) (an integer <= 2^24); Q = the exact integer sum of q over the rows of the
+ * iteration's bag bounds the sum of |v|: sum |v| <= Q * 2^-c.  With e = c + 62 - ceil_log2(Q) every row's |rint(v 2^e)| <= |v| 2^e + 1/2 <=
+ * 1.5 q 2^(e-c) (q >= 1 wherever v != 0 and e > c), so the sum of the magnitudes over ANY set of rows stays below 1.5 * 2^62 < 2^63: an int64
+ * sum cannot overflow.  e never drops below the v2.1 exponent of the model (whose own bound holds whatever Q is) and never exceeds
+ * 50 - ceil_log2(bound) (one value stays within the range of the device's rint trick).
+ * RGBM_FX_ROWS = R (with RGBM_TEST_HOOKS=1; the product reads the same pair): the grid a table of R rows with this table's gradient
+ * distribution gets -- Q is multiplied by ceil(R / N) and the v2.1 floor is the one of R rows. */
+static inline int64_t f32_park(float v) { union { float f; uint32_t u; } x; x.f = v; return (int64_t)x.u; }
+static inline float f32_unpark(int64_t b) { union { float f; uint32_t u; } x; x.u = (uint32_t)b; return x.f; }
+static inline int64_t fx_coarse(float v, int c) { double x = ceil(ldexp(fabs((double)v), c)); if (x > 2147483648.0) x = 2147483648.0; return (int64_t)x; }
+static inline int ceil_log2_u64(uint64_t q) { int n = 0; if (q <= 1) return 0; --q; while (q) { ++n; q >>= 1; } return n; }
+typedef struct { int c_g, c_h, e_g_max, e_h_max; int64_t q_mult; } fx_grid;
+static inline int fx_tree_exponent(int64_t q, int64_t q_mult, int c, int e_min, int e_max) {
+    q *= q_mult;
+    int e = (q <= 0) ? e_max : c + 62 - ceil_log2_u64((uint64_t)q);
+    if (e > e_max) e = e_max;
+    if (e < e_min) e = e_min;
+    return e;
+}
+static int fx_test_hooks(void) { const char* ev = getenv("RGBM_TEST_HOOKS"); return ev && atoi(ev) != 0; }
+
 /* Threads of the timing harness (bench.py cpu_baseline): LightGBM's col-wise mode builds the per-feature histograms in
  * parallel; so does this (features are independent output ranges and the sums are integers: bit-identical for any thread
  * count).  Default 1: the tests never change it. */

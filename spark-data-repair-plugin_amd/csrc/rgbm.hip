@@ -33,7 +33,7 @@
 #include "rgbm_level.h"
 #include "rgbm_small.h"
 
-#define RGBM_VERSION 210   // numerics spec v2.1: float32 (g, h) as LightGBM computes them, exact integer histogram sums on a fixed-point grid of up to 2^50 per value (rgbm_numerics.h)
+#define RGBM_VERSION 220   // numerics spec v2.2: float32 (g, h) as LightGBM computes them, exact integer histogram sums on a fixed-point grid chosen per class tree and boosting iteration (rgbm_numerics.h)
 
 namespace {
 
@@ -227,6 +227,8 @@ struct Fusion {
     Comm comm;                  // the rank's communicator (moved in by rgbm_fusion_create, moved back by rgbm_fusion_free)
     int device = 0;
     int n = 0;                  // members still taking part
+    int n_members = 0;          // members the group was created for (rgbm_fusion_join checks the index against it)
+    bool joined[MAX_MEMBERS] = {};
     std::mutex mu; std::condition_variable cv;
     int arrived = 0; long long gen = 0; bool broken = false; std::string why;
     struct Part { void* buf = nullptr; size_t count = 0; int type = 0; hipStream_t s = nullptr; hipEvent_t ready = nullptr; bool in = false; } part[MAX_MEMBERS];
@@ -288,7 +290,16 @@ void fused_all_reduce(Fusion* f, int me, void* buf, size_t count, int type, hipS
     mine.buf = buf; mine.count = count; mine.type = type; mine.s = s; mine.in = true;
     const long long gen = f->gen;
     if (++f->arrived >= f->n) fusion_run_step_locked(f);
-    else f->cv.wait(lk, [&] { return f->gen != gen || f->broken; });
+    else {
+        // bounded: a member of this rank that never arrives and never leaves -- its thread died before its next collective -- must not
+        // park the others (and, through them, the peer ranks) for ever: after RGBM_COMM_TIMEOUT_S the group is broken and everybody raises
+        static const double limit = [] { const char* e = getenv("RGBM_COMM_TIMEOUT_S"); double v = e ? atof(e) : 600.0; return v > 0.0 ? v : 600.0; }();
+        if (!f->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return f->gen != gen || f->broken; })) {
+            f->broken = true; f->why = "a member of this rank did not reach its next collective within " + std::to_string((int)limit) + " s";
+            if (f->comm.kind == 1 && f->comm.nccl) { (void)ncclCommAbort(f->comm.nccl); f->comm.nccl = nullptr; f->comm.kind = 0; }
+            f->cv.notify_all();
+        }
+    }
     if (f->broken) throw std::runtime_error("fusion group: a concurrent row-sharded training call of this rank failed (" + f->why + ")");
     HIPCHK(hipStreamWaitEvent(s, f->done, 0));
 }
@@ -331,10 +342,19 @@ void stream_sync_watchdog(hipStream_t s) {
         const hipError_t q = hipStreamQuery(s);
         if (q == hipSuccess) return;
         if (q != hipErrorNotReady) { (void)hipGetLastError(); comm_abort(); throw std::runtime_error(std::string("training stream failed during a collective: ") + hipGetErrorString(q)); }
-        ncclResult_t ae = ncclSuccess;
-        ncclComm_t nc = fused_rccl ? c.fusion->comm.nccl : c.nccl;
-        if (fused_rccl && c.fusion->broken) { const std::string w = c.fusion->why; comm_abort(); throw std::runtime_error("fusion group broken: " + w); }
-        if (nc && ncclCommGetAsyncError(nc, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
+        ncclResult_t ae = ncclSuccess; bool have_ae = false;
+        if (fused_rccl) {
+            // the group's state belongs to its mutex: another member may be leaving right now -- writing `why`, aborting the communicator
+            // and clearing the handle -- so the flag, the text and the asynchronous-error query are taken under the lock
+            bool broken; std::string w;
+            {
+                std::lock_guard<std::mutex> lk(c.fusion->mu);
+                broken = c.fusion->broken; if (broken) w = c.fusion->why;
+                if (!broken && c.fusion->comm.nccl) have_ae = ncclCommGetAsyncError(c.fusion->comm.nccl, &ae) == ncclSuccess;
+            }
+            if (broken) { comm_abort(); throw std::runtime_error("fusion group broken: " + w); }
+        } else if (c.nccl) have_ae = ncclCommGetAsyncError(c.nccl, &ae) == ncclSuccess;
+        if (have_ae && ae != ncclSuccess && ae != ncclInProgress) {
             const std::string what = ncclGetErrorString(ae);
             comm_abort();
             throw std::runtime_error("RCCL reported an asynchronous error (a peer rank failed?): " + what);
@@ -527,10 +547,11 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // with few live rows are walked tile by tile like the others).  Round 5: RGBM_MT_ROT=-1|0|1 (feature rotation of a level pass's histogram updates:
 // per launch where fewer than RGBM_MT_ROT_COPIES2 / 2 copies of its histograms fit the LDS -- the default --, never, every launch that has the
 // instantiation; RGBM_MT_ROT_T=0 keeps the replicated layout's class trees per workgroup), RGBM_MT_LOCK=<rounds> (lock-step of the class-tree groups
-// of a row block, wave-specialised pass), RGBM_FUSE_GRAD=1 (last pass fused with the next gradients), RGBM_JOINT_WIDE=1 (16-bit joint codes in the
-// root pass), RGBM_FX_ROWS / RGBM_FX_E (TEST hooks: the fixed-point grid of a bigger table; the oracle reads them too).
+// of a row block, wave-specialised pass), RGBM_JOINT_WIDE=1 (16-bit joint codes in the root pass), RGBM_FX_MEASURE=separate (the coarse gradient sums of
+// numerics v2.2 from a pass of their own instead of out of the gradient kernels), RGBM_TEST_HOOKS=1 + RGBM_FX_ROWS=R (TEST hook: the fixed-point grid of a
+// table of R rows; the oracle reads the same pair; a warning goes to stderr when it is active).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than two copies of the level's histograms (default), 0 = never, 1 = every plain one-chunk pass */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 6 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (6 = three copies) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fuse_grad = false /* last pass of an iteration fused with the next iteration's gradients: measured slower than the two kernels (rgbm_level.h), opt-in */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than mt_rot_copies2 / 2 = THREE copies of the launch's worst-case histograms (default), 0 = never, 1 = every pass that has the instantiation */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 6 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (6 = three copies) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fx_separate = false /* RGBM_FX_MEASURE=separate: the coarse sums behind every class tree's fixed-point grid come from a pass of their own over the (g, h) array (k_fx_measure) instead of out of the gradient kernels -- same sums, same models; the tests run both */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -544,7 +565,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_THREADS")) w.mt_threads = atoi(e) == 768 ? 768 : 1024;
     if (const char* e = getenv("RGBM_MT_SPEC")) w.mt_spec = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RGBM_MT_SPARSE")) w.mt_sparse = atoi(e) != 0;
-    if (const char* e = getenv("RGBM_FUSE_GRAD")) w.fuse_grad = atoi(e) != 0;
+    if (const char* e = getenv("RGBM_FX_MEASURE")) w.fx_separate = strcmp(e, "separate") == 0;
     if (const char* e = getenv("RGBM_MT_LOCK")) w.mt_lock = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT")) w.mt_rot = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT_COPIES2")) w.mt_rot_copies2 = atoi(e);
@@ -716,20 +737,24 @@ void fit_setup(const rgbm_table& tab, const double* y_value_in, const double* cl
     if (obj == 2) { bound_g = (ymax - ymin) * w_max; if (!(bound_g > 0.0)) bound_g = 1.0; bound_h = w_max; }
     else if (obj == 0) { bound_g = w_max; bound_h = 0.25 * w_max; }
     else { bound_g = w_max; bound_h = factor * 0.25 * w_max; }
-    // fixed-point grid of the histogram sums (numerics v2.1, rgbm_numerics.h): |g_i| <= (bound_g / w_max) * w_i and h_i <= (bound_h / w_max) * w_i
-    // hold for every row i, so with e = min(50 - ceil_log2(bound), 62 - ceil_log2(bound * sum_w / w_max)) every converted value is at most
-    // 2^50 in magnitude (the range of the rint trick) and an int64 sum over all training rows (of all ranks) stays below 2^62
+    // fixed-point grid of the histogram sums (numerics v2.2, rgbm_numerics.h).  The FLOOR of every class tree's exponent is v2.1's: |g_i| <= (bound_g / w_max) * w_i
+    // and h_i <= (bound_h / w_max) * w_i hold for every row i, so with e = min(50 - ceil_log2(bound), 62 - ceil_log2(bound * sum_w / w_max)) every converted value is
+    // at most 2^50 in magnitude (the range of the rint trick) and an int64 sum over all training rows (of all ranks) stays below 2^62.  The exponent a class tree
+    // actually gets in an iteration comes from the measured coarse sums of its gradients (FxGrid -> k_fx_scale / k_small_tree).
     double wr = sumw / w_max;
-    // test hook (tools/numerics_scale.py; the oracle reads the same variable): RGBM_FX_ROWS = R sizes the grid as if the table held R training rows with
-    // this table's weight distribution -- the grid a 10M / 100M-row table of this kind gets, on a table that trains in seconds
-    if (const char* ev = std::getenv("RGBM_FX_ROWS")) { const double R = std::atof(ev); if (R > (double)n_train && n_train > 0) wr *= R / (double)n_train; }
-    int e_g = rg::fx_exponent(bound_g, wr), e_h = rg::fx_exponent(bound_h, wr);
-    // test hook (tests/test_numerics_bound.py; the oracle reads the same variable): RGBM_FX_E = E caps the grid at E bits for a value equal to
-    // the bound -- what a table of 2^(62 - E) equally weighted rows gets (E = 38: 10M rows, E = 35: 100M rows) -- on a table of any size
-    if (const char* ev = std::getenv("RGBM_FX_E")) {
-        const int E = std::atoi(ev);
-        if (E >= 8 && E <= 50) { e_g = std::min(e_g, E - rg::fx_ceil_log2(bound_g)); e_h = std::min(e_h, E - rg::fx_ceil_log2(bound_h)); }
+    long long q_mult = 1;
+    // TEST hook (tests/test_numerics_bound.py, tools/numerics_scale.py; the oracle reads the same pair): RGBM_TEST_HOOKS=1 + RGBM_FX_ROWS = R sizes the grid as if the
+    // table held R training rows with this table's gradient distribution -- the grid a 10M / 100M-row table of this kind gets, on a table that trains in seconds.
+    // It changes every model: only honoured with the explicit switch, and said on stderr.
+    if (const char* th = std::getenv("RGBM_TEST_HOOKS")) if (std::atoi(th) != 0) if (const char* ev = std::getenv("RGBM_FX_ROWS")) {
+        const double R = std::atof(ev);
+        if (R > (double)n_train && R <= 4294967296.0 && n_train > 0) {
+            wr *= R / (double)n_train; q_mult = ((long long)R + n_train - 1) / n_train;
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true)) fprintf(stderr, "[rgbm] TEST HOOK active: RGBM_FX_ROWS=%s coarsens the fixed-point grid of every model trained by this process\n", ev);
+        }
     }
+    const int e_g = rg::fx_exponent(bound_g, wr), e_h = rg::fx_exponent(bound_h, wr);
 
     TrainConst& tc = h.tc; memset(&tc, 0, sizeof(tc));
     tc.sg = std::ldexp(1.0, e_g); tc.sh = std::ldexp(1.0, e_h); tc.inv_sg = std::ldexp(1.0, -e_g); tc.inv_sh = std::ldexp(1.0, -e_h);
@@ -737,6 +762,10 @@ void fit_setup(const rgbm_table& tab, const double* y_value_in, const double* cl
     tc.learning_rate = p.learning_rate; tc.factor = factor; tc.min_data_in_leaf = p.min_data_in_leaf; tc.max_depth = p.max_depth;
     tc.num_leaves = p.num_leaves; tc.F = F; tc.K = K; tc.totbins = std::max(totbins, 1); tc.nchunk = nchunk; tc.objective = obj;
     tc.N = N; tc.n_train = n_train; tc.NG = N;
+    tc.fx.c_g = 24 - rg::fx_ceil_log2(bound_g); tc.fx.c_h = 24 - rg::fx_ceil_log2(bound_h);
+    tc.fx.e_g_min = e_g; tc.fx.e_h_min = e_h;
+    tc.fx.e_g_max = 50 - rg::fx_ceil_log2(bound_g); tc.fx.e_h_max = 50 - rg::fx_ceil_log2(bound_h);
+    tc.fx.q_mult = q_mult;
 }
 
 // the trees as the trainer leaves them in its flat device arrays (TreeOut), copied to the host: -> the model's tree list
@@ -867,6 +896,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     DevBuf<float2> d_gh((size_t)K * tc.NG); d_gh.zero(s);      // float32 (g, h) of every (row, class tree); non-training rows stay (0, 0)
     DevBuf<double> d_score((size_t)K * N), d_init(K);
     d_init.upload(init.data(), K, s);
+    DevBuf<unsigned long long> d_fxq((size_t)K * 2); d_fxq.zero(s);      // numerics v2.2: coarse gradient sums of the iteration's class trees (k_fx_scale zeroes them again)
+    DevBuf<FxScale> d_fxs(K);                                            // ... and the grid they give every class tree
     hipLaunchKernelGGL(k_init_score, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_score.p, (long long)N, K, d_init.p);
     DevBuf<int32_t> d_idx0, d_idx1, d_sorted, d_any(NE); d_any.zero(s);
     DevBuf<HistBin> d_pool; DevBuf<TreeState> d_state; DevBuf<Leaf> d_leaves; DevBuf<Cand> d_cand; DevBuf<double> d_upd;
@@ -880,9 +911,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     LevelConst lc; memset(&lc, 0, sizeof(lc));
     DevBuf<uint8_t> d_node; DevBuf<LvPlan> d_plan; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
-    DevBuf<FinEntry> d_fin;   // fused last pass + next gradients (k_level_final_grad_*)
     DevBuf<uint32_t> d_prog; uint32_t mt_epoch = 0;   // lock-step progress words of the wave-specialised level pass: [row blocks][tree groups]
-    bool fuse_grad = false; size_t fuse_lds = 0; int fuse_grid = 1;
     int n_hnodes = 1;
     bool use_reduce = false;   // root pass: sum the per-workgroup partials in a separate kernel (many workgroups per class tree, joint bins, or row-sharded)
     // joint bins for the root pass (rgbm_level.h, k_pack_joint): a second record whose bytes hold GROUPS of low-cardinality features
@@ -900,7 +929,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         if (sw.lv_lds >= 65536 && sw.lv_lds <= LV_LDS_BYTES) lc.lds_bytes = sw.lv_lds;      // testing: a smaller LDS pool forces several built-slot windows per level
         lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
         lc.num_leaves = NL; lc.max_depth = p.max_depth; lc.min_data_in_leaf = p.min_data_in_leaf; lc.N = N; lc.NS = (N + 255) & ~255ll; lc.NG = lc.NS;
-        lc.sg = tc.sg; lc.sh = tc.sh;
         lc.sib_local = (dp && g_comm.rank == 0) ? 1 : 0;
         n_hnodes = (1 << p.max_depth) - 1;
         // ---- root pass: one 1024-thread workgroup per CU and (class tree, row block, chunk).  Contiguous row blocks, a multiple of 8 per
@@ -971,7 +999,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                                  (long long)T * win * (node_bytes + mt_rot_dummy(true) * 16) <= lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec);
                 // a rotated launch needs ONE copy: as many class trees per workgroup as the LDS holds (RGBM_MT_ROT_T=0: keep the T sized for replication)
                 if (rot && sw.mt_rot_T && sw.mt_T < 1) {
-                    const long long cap_rot = (lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec)) / (node_bytes + mt_rot_dummy(true) * 16);
+                    const long long cap_rot = std::min<long long>((lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec)) / (node_bytes + mt_rot_dummy(true) * 16), MT_MAX_NODES);
                     T = (int)std::max<long long>(T, std::min<long long>(std::min<long long>(cap_rot / win, MT_MAX_T), std::min<long long>(K, MT_MAX_RT / (2 * worst))));
                 }
                 const int G = (K + T - 1) / T;
@@ -1009,15 +1037,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const int max_built_all = 1 << std::max(0, p.max_depth - 2);
         d_part_red.alloc((size_t)K * max_built_all * tc.totbins + (size_t)K * 128 /* K*256 int64 counts */);
         d_leafnode.alloc((size_t)K * LV_MAX_LEAVES); d_err.alloc(1); d_err.zero(s); d_ndelta.alloc((size_t)K * 256); d_statrows.alloc(1); d_statrows.zero(s);
-        // The last pass of an iteration fused with the gradients of the next one (rgbm_level.h, k_level_final_grad_*): not with bagging (the next
-        // bag is drawn in between), and for the softmax shapes its two layouts cover (K <= 112: k_grad_mc's bound).  RGBM_FUSE_GRAD=0 keeps
-        // k_level_final + the gradient kernel (same models: tests/test_gpu_growers.py runs both).
-        {
-            const bool mc_tile = obj == 1 && K >= 16;
-            fuse_lds = mc_tile ? (size_t)(K * 64 + 320) * 8 : (obj == 1 ? (size_t)K * 256 * 8 : 0);
-            fuse_grad = sw.fuse_grad && !use_bagging && NE > 1 && (obj != 1 || K <= 112) && fuse_lds <= 64 * 1024 && N < (1ll << 28);
-            if (fuse_grad) { d_fin.alloc((size_t)K * 256); fuse_grid = (int)(mc_tile ? (N + 63) / 64 : (N + 255) / 256); }
-        }
         // Joint bins for the root pass (the tables where the root pass runs at the LDS-atomic rate).  Best-fit-decreasing packing of the
         // features into groups whose bin counts multiply to <= 256; worth it when it saves at least two atomics per row and the groups
         // fit one 16-byte record.  RGBM_JOINT_ROOT=0 disables it (same models either way: the sums are exact integers).
@@ -1166,7 +1185,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         hipEvent_t a = nullptr, b = nullptr;
         if (stats) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
         hipLaunchKernelGGL(k_hist, dim3(hist_gx, K, nchunk), dim3(256), lds_hist, s, d_rec.p, d_gh.p, d_idx0.p, d_idx1.p, d_base.p,
-                           d_state.p, d_pool.p, d_fmeta.p, d_cmeta.p, tc);
+                           d_state.p, d_pool.p, d_fmeta.p, d_cmeta.p, d_fxs.p, tc);
         if (stats) { HIPCHK(hipEventRecord(b, s)); hist_ev.emplace_back(a, b); hist_ev_root.push_back(root ? 1 : 0); }
     };
 
@@ -1181,13 +1200,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         timed(true, [&]() {
             if (joint_root && joint_wide)
                 hipLaunchKernelGGL(k_level_root<true>, dim3((unsigned)lc.gx * (unsigned)K, 1, 1), dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node.p, d_plan.p, d_part_j.p,
-                                   d_vfmeta.p, d_vcmeta.p, lcj);
+                                   d_vfmeta.p, d_vcmeta.p, d_fxs.p, lcj);
             else if (joint_root)   // the root pass over the joint record: one pair of atomics per feature GROUP and row
                 hipLaunchKernelGGL(k_level_root<false>, dim3((unsigned)lc.gx * (unsigned)K, 1, 1), dim3(LV_THREADS), lc.lds_bytes, s, d_rec_j.p, d_gh.p, d_node.p, d_plan.p, d_part_j.p,
-                                   d_vfmeta.p, d_vcmeta.p, lcj);
+                                   d_vfmeta.p, d_vcmeta.p, d_fxs.p, lcj);
             else
                 hipLaunchKernelGGL(k_level_root<false>, dim3((unsigned)lc.gx * (unsigned)K, 1, nchunk), dim3(LV_THREADS), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, d_plan.p, d_part.p,
-                                   d_fmeta.p, d_cmeta.p, lc);
+                                   d_fmeta.p, d_cmeta.p, d_fxs.p, lc);
         });
     };
     // the k_level_mt launches of one level; returns the LevelConst that describes the partials they wrote
@@ -1205,9 +1224,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
 #define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, ...) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, __VA_ARGS__>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, l1); \
+                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, l1); \
                                            else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, __VA_ARGS__>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, l1); } while (0)
+                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, l1); } while (0)
 #define RGBM_LAUNCH_MT(NCHR, THR, ACC, ...) do { if (use_bagging) RGBM_LAUNCH_MT2(NCHR, true, d_inbag.p, THR, ACC, __VA_ARGS__); else RGBM_LAUNCH_MT2(NCHR, false, nullptr, THR, ACC, __VA_ARGS__); } while (0)
                 if (L.acc2) { if (sw.mt_spec != 0 && L.rot) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true, true); else if (sw.mt_spec != 0) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true); else RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, false); }
                 else if (nchr == 1 && sw.mt_spec == 1) RGBM_LAUNCH_MT(1, LV_THREADS, false, true);
@@ -1253,7 +1272,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         trace_copy("lpool", level, d_lpool.p, (size_t)K * n_hnodes * tc.totbins * 16);
     };
     // one boosting iteration of the level grower after the gradients: an iteration-invariant launch sequence
-    auto enqueue_level_growth = [&](bool fuse_next /* also emit the NEXT iteration's gradients (k_level_final_grad_*) */) {
+    auto enqueue_level_growth = [&]() {
             hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, n_in_ptr, (long long)n_train, lc);
             int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
             // partials of this rank -> compact buffer (-> integer all-reduce when row-sharded); the split kernel then sees ONE partial
@@ -1276,7 +1295,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             {
                 auto ex = exchange(true, 1, lc);
                 hipLaunchKernelGGL(k_level_split<true>, dim3((F + 3) / 4, 1, K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p, cntg, d_count.p, d_fmeta.p,
-                                   d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
+                                   d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, d_fxs.p, tc, ex.second);
                 trace_level(0);
             }
             for (int level = 1; level < p.max_depth; ++level) {
@@ -1284,28 +1303,13 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 const LevelConst lp = launch_level(level);
                 auto ex = exchange(false, 1 << (level - 1), lp);
                 hipLaunchKernelGGL(k_level_split<false>, dim3((F + 1) / 2, 1 << (level - 1), K), dim3(256), 0, s, ex.first, d_lpool.p, d_plan.p, d_snodes.p,
-                                   cntg, d_count.p, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, tc, ex.second);
+                                   cntg, d_count.p, d_fmeta.p, d_used.p, d_lcand.p, d_statrows.p, d_it.p, n_hnodes, d_fxs.p, tc, ex.second);
                 trace_level(level);
             }
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
             hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_snodes.p, d_lcand.p, d_fmeta.p, p.max_depth, tc, lc);
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
-            if (fuse_next) {
-                const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw_ = sample_weight_host ? d_sw.p : nullptr;
-                // the exact counts of the deepest children first (it reads the node ids the fused pass resets), then table + fused pass
-                hipLaunchKernelGGL(k_level_final<true>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, (const uint8_t*)nullptr,
-                                   d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
-                hipLaunchKernelGGL(k_level_fin_table, dim3(K), dim3(256), 0, s, d_plan.p, to, d_ndelta.p, d_fin.p, d_it.p, lc);
-                if (obj == 1 && K >= 16)
-                    hipLaunchKernelGGL(k_level_final_grad_mc, dim3(fuse_grid), dim3(256), fuse_lds, s, d_rec.p, d_node.p, d_fin.p, d_score.p, d_ycol, cw, sw_, d_gh.p, lc, tc);
-                else if (obj == 1)
-                    hipLaunchKernelGGL((k_level_final_grad_rows<1, 256>), dim3(fuse_grid), dim3(256), fuse_lds, s, d_rec.p, d_node.p, d_fin.p, d_score.p, d_ycol, yv, cw, sw_, d_gh.p, lc, tc);
-                else if (obj == 0)
-                    hipLaunchKernelGGL((k_level_final_grad_rows<0, 256>), dim3(fuse_grid), dim3(256), fuse_lds, s, d_rec.p, d_node.p, d_fin.p, d_score.p, d_ycol, yv, cw, sw_, d_gh.p, lc, tc);
-                else
-                    hipLaunchKernelGGL((k_level_final_grad_rows<2, 256>), dim3(fuse_grid), dim3(256), fuse_lds, s, d_rec.p, d_node.p, d_fin.p, d_score.p, d_ycol, yv, cw, sw_, d_gh.p, lc, tc);
-            } else
-            hipLaunchKernelGGL(k_level_final<false>, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
+            hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
             if (dp) { hipLaunchKernelGGL(k_copy_i32, dim3(K), dim3(256), 0, s, d_count.p, d_count_g.p, (long long)K * 256); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
             hipLaunchKernelGGL(k_level_leafcount, dim3(K), dim3(LV_MAX_LEAVES), 0, s, d_plan.p, cntg, d_leafnode.p, to, d_it.p, tc);
@@ -1313,17 +1317,36 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             trace_sum("score", d_score.p, (size_t)K * N * 8); trace_sum("node", d_node.p, (size_t)K * lc.NS);
     };
 
+    // numerics v2.2: every class tree of an iteration gets its own fixed-point grid from the coarse sums Q_g, Q_h of its (g, h) (rgbm_numerics.h).  The
+    // gradient kernels leave the sums per workgroup / wave (d_qpart [parts][K][2]: plain stores, no atomics), k_fx_reduce adds them up into d_fxq [K][2];
+    // k_grad<1> (softmax with K > 112) and RGBM_FX_MEASURE=separate take them from a pass of their own over the (g, h) array (k_fx_measure).  Row-sharded:
+    // ONE more integer all-reduce per iteration (2 K words).  k_fx_scale turns the sums into the FxScale table every accumulating / searching kernel reads.
+    const bool mc_tile = obj == 1 && K >= 16 && K <= 112, mc_rows = obj == 1 && K < 16;
+    const bool fx_fused = !sw.fx_separate && (obj != 1 || mc_tile || mc_rows);
+    const long long fx_parts = !fx_fused ? 0 : (mc_tile ? (N + 63) / 64 : (mc_rows ? ((N + 255) / 256) * 4 : (long long)grad_gx));
+    DevBuf<unsigned long long> d_qpart; if (fx_fused) d_qpart.alloc((size_t)fx_parts * K * 2);
     auto enqueue_grad = [&]() {
         const double* cw = class_weight ? d_cw.p : nullptr; const double* yv = y_value ? d_yv.p : nullptr; const double* sw_ = sample_weight_host ? d_sw.p : nullptr;
         const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
         uint8_t* node0 = level_mode ? d_node.p : nullptr;
-        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K < 16)
-            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1 && K <= 112)
-            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
-        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
-        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, tc);
+        unsigned long long* qp = fx_fused ? d_qpart.p : nullptr;
+        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, tc);
+        else if (mc_rows)
+            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, tc);
+        else if (mc_tile)
+            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, tc);
+        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, (unsigned long long*)nullptr, tc);
+        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, tc);
+        if (fx_fused) {
+            const long long total = fx_parts * K * 2;
+            const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(256, (total + 8191) / 8192));
+            hipLaunchKernelGGL(k_fx_reduce, dim3(gx), dim3(256), (size_t)K * 2 * 8, s, d_qpart.p, fx_parts, 2 * K, d_fxq.p);
+        } else {
+            const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(128, (N + 4095) / 4096));
+            hipLaunchKernelGGL(k_fx_measure, dim3(gx, K), dim3(256), 0, s, d_gh.p, (long long)N, (long long)tc.NG, tc.fx, d_fxq.p);
+        }
+        if (dp) all_reduce(d_fxq.p, (size_t)K * 2, AR_I64, s);
+        hipLaunchKernelGGL(k_fx_scale, dim3(1), dim3(256), 0, s, d_fxq.p, K, tc.fx, d_fxs.p);
     };
 
     if (timing) HIPCHK(hipStreamSynchronize(s));
@@ -1345,18 +1368,18 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     for (int it = 0; it < NE; ++it) {
         if (use_bagging && it % p.bagging_freq == 0) enqueue_bagging();
         cur_it = it;
-        if (!(level_mode && fuse_grad && it > 0)) enqueue_grad();     // (fused: the previous iteration's last pass wrote these gradients)
+        enqueue_grad();
         trace_sum("gh", d_gh.p, (size_t)K * tc.NG * 8);
         const uint8_t* usedp = d_used.p + (size_t)it * K * F;
         if (level_mode) {
-            enqueue_level_growth(fuse_grad && it + 1 < NE);
+            enqueue_level_growth();
             hipLaunchKernelGGL(k_next_iteration, dim3(1), dim3(1), 0, s, d_it.p);
             continue;
         }
         hipLaunchKernelGGL(k_init_iter, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_pool.p, to, n_in_ptr, it, tc);
         for (int step = 0; step < NL - 1; ++step) {
             launch_hist(step == 0);
-            hipLaunchKernelGGL(k_split_find, dim3((F + 3) / 4, K), dim3(256), 0, s, d_pool.p, d_state.p, d_leaves.p, d_fmeta.p, usedp, d_cand.p, tc);
+            hipLaunchKernelGGL(k_split_find, dim3((F + 3) / 4, K), dim3(256), 0, s, d_pool.p, d_state.p, d_leaves.p, d_fmeta.p, usedp, d_cand.p, d_fxs.p, tc);
             hipLaunchKernelGGL(k_tree_step, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, d_cand.p, d_pool.p, d_fmeta.p, to, it, tc);
             hipLaunchKernelGGL(k_partition, dim3(part_gx, K), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(d_rec.p), d_idx0.p, d_idx1.p, d_base.p, d_state.p, tc);
             hipLaunchKernelGGL(k_finish_split, dim3(K), dim3(64), 0, s, d_state.p, d_leaves.p, to, it, tc);
@@ -1415,6 +1438,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const int64_t rows_acc = dp ? (int64_t)(h_statrows / (unsigned long long)g_comm.nranks) : (int64_t)h_statrows;
             if (dp) root_rows /= g_comm.nranks;
             stats->hist_rows = rows_acc; stats->root_rows = root_rows;
+            stats->root_atomics_per_row = 2 * (int64_t)(joint_root ? lcj.F : F); stats->level_atomics_per_row = 2 * (int64_t)F;
             // algorithmic bytes: F bin bytes + 8 B (g,h) per accumulated row
             stats->hist_bytes = rows_acc * ((int64_t)F + 8);
             (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
@@ -2524,7 +2548,7 @@ RGBM_EXPORT int rgbm_fusion_create(int32_t n_members, void** out) {
         HIPCHK(hipGetDevice(&f->device));
         HIPCHK(hipStreamCreateWithFlags(&f->cs, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&f->done, hipEventDisableTiming));
-        f->n = n_members;
+        f->n = n_members; f->n_members = n_members;
         f->comm = g_comm; g_comm = Comm();         // the communicator lives in the group until rgbm_fusion_free hands it back
         *out = f.release();
         return RGBM_OK;
@@ -2536,6 +2560,12 @@ RGBM_EXPORT int rgbm_fusion_join(void* fusion, int32_t member) {
     if (!f || member < 0 || member >= Fusion::MAX_MEMBERS) return fail(RGBM_ERR_ARG, "rgbm_fusion_join: bad argument");
     return guarded([&]() {
         if (g_comm.kind != 0) throw std::invalid_argument("rgbm_fusion_join: this thread already has a communicator");
+        {
+            std::lock_guard<std::mutex> lk(f->mu);
+            if (member >= f->n_members) throw std::invalid_argument("rgbm_fusion_join: member index beyond the members the group was created for");
+            if (f->joined[member]) throw std::invalid_argument("rgbm_fusion_join: this member index is taken");
+            f->joined[member] = true;
+        }
         use_device(f->device);
         g_comm.kind = 3; g_comm.rank = f->comm.rank; g_comm.nranks = f->comm.nranks; g_comm.fusion = f; g_comm.member = member;
         return RGBM_OK;
@@ -2573,6 +2603,7 @@ RGBM_EXPORT int rgbm_fusion_free(void* fusion) {
 }
 
 RGBM_EXPORT int rgbm_comm_finalize(void) {
+    if (g_comm.kind == 3) { fusion_leave(false, nullptr); return RGBM_OK; }      // a member thread: leave the group (the communicator is the group's)
     if (g_comm.kind == 1 && g_comm.nccl) (void)ncclCommDestroy(g_comm.nccl);
     if (g_comm.tmp) (void)hipFree(g_comm.tmp);
     g_comm = Comm();

@@ -10,6 +10,7 @@
 //   pool    i64x2 [K][NL][totbins]  per-leaf histograms (exact integer sums)
 #pragma once
 #include <stdint.h>
+#include "rgbm_numerics.h"
 
 namespace rg {
 
@@ -55,7 +56,11 @@ struct ChunkMeta {
 };
 
 struct TrainConst {
+    // the grid of the class tree at hand (numerics v2.2: per class tree and iteration).  The big-table trainers read it from the FxScale
+    // table k_fx_scale writes (tree_const); the batched small-table trainer measures it inside k_small_tree; the host leaves the model's
+    // v2.1 floor here
     double inv_sg, inv_sh, sg, sh;
+    FxGrid fx;
     double l1, l2, min_gain_to_split, min_sum_hessian, learning_rate, factor;
     int32_t min_data_in_leaf, max_depth, num_leaves, F, K, totbins, nchunk, objective;
     long long N, n_train;

@@ -26,6 +26,19 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // (g, h) of one (row, class tree): float2 [K][N] -- LightGBM's score_t pair, the double expression rounded once to float32
 __device__ __forceinline__ void store_gh(float2* gh, long long idx, double g, double h) { gh[idx] = make_float2((float)g, (float)h); }
 
+// the constants of class tree k: the model's, with the fixed-point grid this tree has in this iteration (numerics v2.2, k_fx_scale)
+__device__ __forceinline__ TrainConst tree_const(const TrainConst& c, const FxScale* __restrict__ fxs, int k) {
+    TrainConst t = c;
+    const FxScale f = fxs[k];
+    t.sg = f.sg; t.sh = f.sh; t.inv_sg = f.inv_sg; t.inv_sh = f.inv_sh;
+    return t;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 struct TreeOut {   // flat device arrays of every tree of the model, [(it*K+k)] major
     int32_t* L; int32_t* feat; int32_t* theta; int32_t* dleft; int32_t* left; int32_t* right; double* gain;
     double* leaf_value; int32_t* leaf_count;
@@ -110,7 +123,8 @@ __device__ __forceinline__ void grad_rows(long long first, long long stride, con
                                           const double* __restrict__ y_value, const double* __restrict__ class_w,
                                           const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
                                           float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
-                                          long long NS, const TrainConst& c) {
+                                          long long NS, const TrainConst& c,
+                                          unsigned long long* qacc = nullptr /* OBJ != 1: this thread's sums of the coarse magnitudes of its (g, h) (numerics v2.2), or null */) {
     const long long N = c.N;
     for (long long i = first; i < N; i += stride) {
         const int y = ycol[i];
@@ -132,9 +146,13 @@ __device__ __forceinline__ void grad_rows(long long first, long long stride, con
             double label = (y > 0) ? 1.0 : -1.0;
             double response = -label / (1.0 + rg_exp(label * score[i]));
             double abs_r = fabs(response);
-            store_gh(gh, i, response * wi, abs_r * (1.0 - abs_r) * wi);
+            const float g32 = (float)(response * wi), h32 = (float)(abs_r * (1.0 - abs_r) * wi);
+            gh[i] = make_float2(g32, h32);
+            if (qacc) { qacc[0] += fx_coarse(g32, c.fx.c_g); qacc[1] += fx_coarse(h32, c.fx.c_h); }
         } else if (OBJ == 2) {   // RegressionL2loss::GetGradients
-            store_gh(gh, i, (score[i] - y_value[y]) * wi, wi);
+            const float g32 = (float)((score[i] - y_value[y]) * wi), h32 = (float)wi;
+            gh[i] = make_float2(g32, h32);
+            if (qacc) { qacc[0] += fx_coarse(g32, c.fx.c_g); qacc[1] += fx_coarse(h32, c.fx.c_h); }
         } else {
             const int K = c.K;
             double wmax = score[i];
@@ -154,8 +172,79 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
                                               const double* __restrict__ y_value, const double* __restrict__ class_w,
                                               const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
                                               float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
-                                              long long NS, TrainConst c) {
-    grad_rows<OBJ>((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, score, ycol, y_value, class_w, sample_w, row_in_bag, gh, node0, NS, c);
+                                              long long NS, unsigned long long* __restrict__ qpart /* OBJ != 1: [gridDim.x][2] coarse sums of this workgroup's (g, h), or null */,
+                                              TrainConst c) {
+    unsigned long long acc[2] = {0ull, 0ull};
+    const bool measure = OBJ != 1 && qpart != nullptr;
+    grad_rows<OBJ>((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, score, ycol, y_value, class_w, sample_w, row_in_bag, gh, node0, NS, c,
+                   measure ? acc : nullptr);
+    if (measure) {
+        __shared__ unsigned long long ws[4][2];
+        const unsigned long long a0 = wave_sum_u64(acc[0]), a1 = wave_sum_u64(acc[1]);
+        if (lane_id() == 0) { ws[threadIdx.x >> 6][0] = a0; ws[threadIdx.x >> 6][1] = a1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            qpart[(size_t)blockIdx.x * 2] = ws[0][0] + ws[1][0] + ws[2][0] + ws[3][0];
+            qpart[(size_t)blockIdx.x * 2 + 1] = ws[0][1] + ws[1][1] + ws[2][1] + ws[3][1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Numerics v2.2: the fixed-point grid of every class tree of the iteration (rgbm_numerics.h).
+//   the gradient kernels leave, per workgroup (or wave), the coarse sums Q_g, Q_h of the (g, h) they wrote: qpart [parts][K][2]
+//   k_fx_reduce   column sums of qpart -> Q [K][2]          (k_fx_measure: the same sums straight from the (g, h) array, for the gradient
+//                                                            kernels that do not measure -- k_grad<1>, K > 112 -- and as the cross-check)
+//   (row-sharded: one integer all-reduce of Q)
+//   k_fx_scale    Q -> FxScale [K], and Q back to zero for the next iteration
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fx_reduce(const unsigned long long* __restrict__ qpart, long long nparts, int C2 /* 2 K */, unsigned long long* __restrict__ Q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);     // [C2]
+    for (int i = threadIdx.x; i < C2; i += 256) acc[i] = 0ull;
+    __syncthreads();
+    const long long total = nparts * C2;
+    const long long per = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < total ? lo + per : total;
+    int col = (int)((lo + threadIdx.x) % C2);
+    const int step = 256 % C2;
+    for (long long e = lo + threadIdx.x; e < hi; e += 256) {
+        const unsigned long long v = qpart[e];
+        if (v) atomicAdd(&acc[col], v);                                        // (LDS; the lanes of a wave hold 64 consecutive columns)
+        col += step; if (col >= C2) col -= C2;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C2; i += 256) { const unsigned long long v = acc[i]; if (v) atomicAdd(&Q[i], v); }
+}
+
+// grid (gx, K), block 256
+__global__ __launch_bounds__(256) void k_fx_measure(const float2* __restrict__ gh, long long N, long long NG, FxGrid fx, unsigned long long* __restrict__ Q) {
+    const int k = blockIdx.y;
+    const float2* ghk = gh + (long long)k * NG;
+    unsigned long long a0 = 0ull, a1 = 0ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+        const float2 g = ghk[i];
+        a0 += fx_coarse(g.x, fx.c_g); a1 += fx_coarse(g.y, fx.c_h);
+    }
+    __shared__ unsigned long long ws[4][2];
+    a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
+    if (lane_id() == 0) { ws[threadIdx.x >> 6][0] = a0; ws[threadIdx.x >> 6][1] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long s0 = ws[0][0] + ws[1][0] + ws[2][0] + ws[3][0], s1 = ws[0][1] + ws[1][1] + ws[2][1] + ws[3][1];
+        if (s0) atomicAdd(&Q[2 * k], s0);
+        if (s1) atomicAdd(&Q[2 * k + 1], s1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fx_scale(unsigned long long* __restrict__ Q, int K, FxGrid fx, FxScale* __restrict__ fxs) {
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int e_g = fx_tree_exponent(Q[2 * k], fx.q_mult, fx.c_g, fx.e_g_min, fx.e_g_max);
+        const int e_h = fx_tree_exponent(Q[2 * k + 1], fx.q_mult, fx.c_h, fx.e_h_min, fx.e_h_max);
+        FxScale f; f.sg = fx_pow2(e_g); f.sh = fx_pow2(e_h); f.inv_sg = fx_pow2(-e_g); f.inv_sh = fx_pow2(-e_h);
+        fxs[k] = f;
+        Q[2 * k] = 0ull; Q[2 * k + 1] = 0ull;
+    }
 }
 
 // Multiclass gradients, FP64-VALU bound (one exp, one division and two quantisations per row and class).
@@ -167,7 +256,9 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
 __global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ score, const int32_t* __restrict__ ycol,
                                                  const double* __restrict__ class_w, const double* __restrict__ sample_w,
                                                  const uint8_t* __restrict__ row_in_bag, float2* __restrict__ gh,
-                                                 uint8_t* __restrict__ node0, long long NS, TrainConst c) {
+                                                 uint8_t* __restrict__ node0, long long NS,
+                                                 unsigned long long* __restrict__ qpart /* [gridDim.x][K][2] coarse sums of this workgroup's (g, h) (numerics v2.2), or null */,
+                                                 TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem);          // [K][64]
     double* pmax = tile + (size_t)c.K * 64;                  // [4][64]
@@ -194,15 +285,35 @@ __global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ scor
     __syncthreads();
     if (wv == 0) { double wsum = 0.0; for (int k = 0; k < K; ++k) wsum += tile[k * 64 + r]; psum[r] = wsum; }
     __syncthreads();
-    if (!valid || y < 0) return;    // not a training row: its gh stays 0 for ever
-    if (out_of_bag) { for (int k = wv; k < K; k += 4) store_gh(gh, (long long)k * c.NG + i, 0.0, 0.0); return; }
-    double wi = class_w ? class_w[y] : 1.0;
-    if (sample_w) wi = wi * sample_w[i];
+    const bool train = valid && y >= 0;     // (not a training row: its gh stays 0 for ever)
+    if (!qpart && !train) return;
+    if (train && out_of_bag) { for (int k = wv; k < K; k += 4) store_gh(gh, (long long)k * c.NG + i, 0.0, 0.0); }
+    const bool on = train && !out_of_bag;
+    if (!qpart && !on) return;
+    double wi = (on && class_w) ? class_w[y] : 1.0;
+    if (on && sample_w) wi = wi * sample_w[i];
     wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
     const double wsum = psum[r];
     for (int k = wv; k < K; k += 4) {
-        const double pk = tile[k * 64 + r] / wsum;
-        store_gh(gh, (long long)k * c.NG + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
+        double packed = 0.0;                                  // bits 0..31: coarse |g|, bits 32..63: coarse h (a double only by type: the tile's)
+        if (on) {
+            const double pk = tile[k * 64 + r] / wsum;
+            const float g32 = (float)(((y == k) ? (pk - 1.0) : pk) * wi), h32 = (float)(c.factor * pk * (1.0 - pk) * wi);
+            gh[(long long)k * c.NG + i] = make_float2(g32, h32);
+            if (qpart) packed = __hiloint2double((int)fx_coarse(h32, c.fx.c_h), (int)fx_coarse(g32, c.fx.c_g));
+        }
+        // numerics v2.2: the tile entry of (k, r) is dead once pk is known -- it takes the coarse magnitudes of this (row, class tree)
+        if (qpart) tile[k * 64 + r] = packed;
+    }
+    if (!qpart) return;
+    __syncthreads();
+    // thread t adds up the 64 rows of class t (rotated start: the 64 lanes of a wave read 64 different LDS banks pairs)
+    for (int t = threadIdx.x; t < K; t += 256) {
+        unsigned long long s0 = 0ull, s1 = 0ull;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) { const double p = tile[t * 64 + ((j + t) & 63)]; s0 += (unsigned int)__double2loint(p); s1 += (unsigned int)__double2hiint(p); }
+        unsigned long long* dst = qpart + ((size_t)blockIdx.x * K + t) * 2;
+        dst[0] = s0; dst[1] = s1;
     }
 }
 
@@ -212,32 +323,57 @@ template <int R>
 __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ score, const int32_t* __restrict__ ycol,
                                                     const double* __restrict__ class_w, const double* __restrict__ sample_w,
                                                     const uint8_t* __restrict__ row_in_bag, float2* __restrict__ gh,
-                                                    uint8_t* __restrict__ node0, long long NS, TrainConst c) {
+                                                    uint8_t* __restrict__ node0, long long NS,
+                                                    unsigned long long* __restrict__ qpart /* [gridDim.x * R / 64][K][2] coarse sums of every wave's (g, h) (numerics v2.2), or null */,
+                                                    TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* tile = reinterpret_cast<double*>(smem) + threadIdx.x;   // element k at tile[k * R]
+    double* tile0 = reinterpret_cast<double*>(smem);
+    double* tile = tile0 + threadIdx.x;   // element k at tile[k * R]
     const long long N = c.N;
     const int K = c.K;
     const long long i = (long long)blockIdx.x * R + threadIdx.x;
-    if (i >= N) return;
-    const double* sp = score + i;
+    const bool valid = i < N;
+    if (!qpart && !valid) return;
+    const long long ic = valid ? i : N - 1;
+    const double* sp = score + ic;
     double wmax = -INFINITY;
 #pragma unroll 4
     for (int k = 0; k < K; ++k) { const double v = sp[(long long)k * N]; tile[k * R] = v; if (v > wmax) wmax = v; }
-    const int y = ycol[i];
-    if (node0) {
+    const int y = ycol[ic];
+    if (node0 && valid) {
         const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
         for (int kk = 0; kk < K; ++kk) node0[(long long)kk * NS + i] = v;
     }
-    if (y < 0) return;
-    if (row_in_bag && !row_in_bag[i]) { for (int kk = 0; kk < K; ++kk) store_gh(gh, (long long)kk * c.NG + i, 0.0, 0.0); return; }
-    double wi = class_w ? class_w[y] : 1.0;
-    if (sample_w) wi = wi * sample_w[i];
-    wi = (double)(float)wi;
-    double wsum = 0.0;
-    for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
-    for (int kk = 0; kk < K; ++kk) {
-        const double pk = tile[kk * R] / wsum;
-        store_gh(gh, (long long)kk * c.NG + i, ((y == kk) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
+    const bool train = valid && y >= 0;
+    if (!qpart && !train) return;
+    const bool oob = train && row_in_bag && !row_in_bag[i];
+    if (oob) { for (int kk = 0; kk < K; ++kk) store_gh(gh, (long long)kk * c.NG + i, 0.0, 0.0); }
+    const bool on = train && !oob;
+    if (!qpart && !on) return;
+    if (on) {
+        double wi = class_w ? class_w[y] : 1.0;
+        if (sample_w) wi = wi * sample_w[i];
+        wi = (double)(float)wi;
+        double wsum = 0.0;
+        for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
+        for (int kk = 0; kk < K; ++kk) {
+            const double pk = tile[kk * R] / wsum;
+            const float g32 = (float)(((y == kk) ? (pk - 1.0) : pk) * wi), h32 = (float)(c.factor * pk * (1.0 - pk) * wi);
+            gh[(long long)kk * c.NG + i] = make_float2(g32, h32);
+            // numerics v2.2: the dead tile entry takes the coarse magnitudes (bits 0..31: |g|, bits 32..63: h)
+            if (qpart) tile[kk * R] = __hiloint2double((int)fx_coarse(h32, c.fx.c_h), (int)fx_coarse(g32, c.fx.c_g));
+        }
+    } else if (qpart) { for (int kk = 0; kk < K; ++kk) tile[kk * R] = 0.0; }
+    if (!qpart) return;
+    __syncthreads();
+    // lane t < K of every wave adds up the wave's 64 rows of class t (rotated start: different banks)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < K) {
+        unsigned long long s0 = 0ull, s1 = 0ull;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) { const double p = tile0[lane * R + wv * 64 + ((j + lane) & 63)]; s0 += (unsigned int)__double2loint(p); s1 += (unsigned int)__double2hiint(p); }
+        unsigned long long* dst = qpart + (((size_t)blockIdx.x * (R / 64) + wv) * K + lane) * 2;
+        dst[0] = s0; dst[1] = s1;
     }
 }
 
@@ -254,11 +390,12 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
                                               const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1,
                                               const int32_t* __restrict__ base_idx, const TreeState* __restrict__ state,
                                               HistBin* __restrict__ pool, const FeatMeta* __restrict__ fmeta,
-                                              const ChunkMeta* __restrict__ cmeta, TrainConst c) {
+                                              const ChunkMeta* __restrict__ cmeta, const FxScale* __restrict__ fxs, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int k = blockIdx.y, ch = blockIdx.z;
     const TreeState st = state[k];
     if (!st.do_hist) return;
+    const double sg_k = fxs[k].sg, sh_k = fxs[k].sh;          // this class tree's grid in this iteration (numerics v2.2)
     const ChunkMeta cm = cmeta[ch];
     unsigned long long* fast_g = reinterpret_cast<unsigned long long*>(smem);   // [fast_slots] replicated gradient sums, then [fast_slots] hessian sums
     unsigned long long* fast_h = fast_g + cm.fast_slots;                        // (separate arrays: a wave instruction of atomics spreads over all LDS banks)
@@ -290,7 +427,7 @@ __global__ __launch_bounds__(256) void k_hist(const uint4* __restrict__ rec, con
                 uint4 r = recc[row];
                 const float2 g = ghk[row];
                 if (g.x != 0.0f || g.y != 0.0f) {   // non-training / out-of-bag rows carry (0, 0)
-                    const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, c.sg), hq = (unsigned long long)fx_from_f32(g.y, c.sh);
+                    const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, sg_k), hq = (unsigned long long)fx_from_f32(g.y, sh_k);
                     uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
@@ -490,12 +627,13 @@ __device__ __forceinline__ void split_find_body(HistBin* __restrict__ pk, const 
 __global__ __launch_bounds__(256) void k_split_find(HistBin* __restrict__ pool, const TreeState* __restrict__ state,
                                                     Leaf* __restrict__ leaves, const FeatMeta* __restrict__ fmeta,
                                                     const uint8_t* __restrict__ used /* [K][F] */, Cand* __restrict__ cand /* [K][2][F] */,
-                                                    TrainConst c) {
+                                                    const FxScale* __restrict__ fxs, TrainConst c_model) {
     const int k = blockIdx.y;
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= c.F) return;
+    if (f >= c_model.F) return;
     const TreeState st = state[k];
     if (!st.do_hist) return;
+    const TrainConst c = tree_const(c_model, fxs, k);
     split_find_body(pool + (long long)k * c.num_leaves * c.totbins, st, leaves + (long long)k * c.num_leaves, fmeta, used + (long long)k * c.F,
                     cand + (long long)k * 2 * c.F, f, c);
 }

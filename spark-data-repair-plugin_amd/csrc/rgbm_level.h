@@ -28,9 +28,10 @@
 // Used when 1 <= max_depth <= 7 and F <= 255 (the reference fixes max_depth = 7, train.py:109);
 // every other configuration takes the leaf-wise path of rgbm_kernels.h.
 //
-// Numerics v2 (rgbm_numerics.h): (g, h) are LightGBM's float32 values; a histogram slot is a pair of
-// int64 sums on the model's fixed-point grid, updated with two 64-bit LDS atomics.  No packing, no
-// carries, no drains: a slot cannot overflow (|value| <= 2^E, E <= 62 - log2 rows).
+// Numerics v2.2 (rgbm_numerics.h): (g, h) are LightGBM's float32 values; a histogram slot is a pair of
+// int64 sums on the fixed-point grid of ITS class tree in THIS iteration (FxScale table, k_fx_scale), updated
+// with two 64-bit LDS atomics.  No packing, no carries, no drains: by construction of the grid no sum of any
+// set of rows can overflow.
 #pragma once
 #include "rgbm_kernels.h"
 
@@ -98,7 +99,6 @@ struct LevelConst {
                                     // mt_window > 0: the class-tree groups of a row block walk it in step (wave-specialised pass, see "lock-step")
     uint32_t mt_epoch, mt_pad;      // lock-step: tag of this launch in the progress words
     long long N, NS, NG;         // rows; row stride of the node-id arrays and of the (g, h) arrays (both N rounded up to a whole wave tile of 256 rows)
-    double sg, sh;               // 2^e_g, 2^e_h: float32 (g, h) -> fixed point (fx_from_f32)
 };
 
 __device__ __forceinline__ uint32_t rec_byte(const uint4& r, int j) {
@@ -162,7 +162,8 @@ constexpr int MT_ROT_DUMMY = mt_rot_dummy(MT_ROT_ALL);
 constexpr int LV_ROOT_FIXED = 256;
 // bytes k_level_mt needs besides the histogram: tree table | node -> tree map | scalars | per-feature flush table (32 features) | ring
 // heads / tails / done flags | packed
-// tree entries | route entries | built-row counters | per-wave rings (record(s) 16 / 32 B + (g, h) 8 B + slot 2 B per entry) | slack
+// tree entries | route entries | built-row counters | per-node grid (numerics v2.2: the high words of 2^e_g, 2^e_h of the node's class tree) |
+// per-wave rings (record(s) 16 / 32 B + (g, h) 8 B + slot 2 B per entry) | slack
 #if !defined(MT_SPARSE_DIV_N)
 #define MT_SPARSE_DIV_N 16
 #endif
@@ -171,7 +172,7 @@ constexpr int LV_ROOT_FIXED = 256;
 // break-even near 18 % live rows
 constexpr long long MT_SPARSE_DIV = MT_SPARSE_DIV_N;
 __host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2, bool spec = false) {
-    return ((!acc2 && !spec) ? (long long)MT_MAX_T * 8 /* live-node masks of the sparse sweep */ : 0) + (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 +
+    return ((!acc2 && !spec) ? (long long)MT_MAX_T * 8 /* live-node masks of the sparse sweep */ : 0) + (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 + (long long)MT_MAX_NODES * 8 +
            (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * mt_ring(spec) * ((acc2 ? 32 : 16) + 8 + 2) + 256;     // (consumer waves have no ring)
 }
 
@@ -207,13 +208,15 @@ __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, SN
 template <bool WIDE /* the record holds eight 16-bit joint codes (groups of up to JOINT_WIDE_CAP joint bins) instead of sixteen bytes */>
 __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __restrict__ rec, const float2* __restrict__ gh, const uint8_t* __restrict__ node,
                                                               const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
-                                                              const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta, LevelConst c) {
+                                                              const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
+                                                              const FxScale* __restrict__ fxs /* [K] this iteration's grid per class tree */, LevelConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int k, bx, nbx;
     if (c.xcd_blocks) { const unsigned id = blockIdx.x, r = id >> 3; k = (int)(r % (unsigned)c.K); bx = (int)(r / (unsigned)c.K) * 8 + (int)(id & 7u); nbx = c.gx; }
     else { k = blockIdx.y; bx = blockIdx.x; nbx = gridDim.x; }
     const int ch = blockIdx.z;
     if (plan[k].done) return;
+    const double sg_k = fxs[k].sg, sh_k = fxs[k].sh;          // (uniform: scalar loads)
     const ChunkMeta cm = cmeta[ch];
     const FeatMeta* fm = fmeta + cm.first_feat;
     const int tid = threadIdx.x, lane = tid & 63, nfeat = cm.nfeat;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
     };
     auto accumulate = [&](bool on, const uint4& r, const float2& g) __attribute__((always_inline)) {
         if (on && (g.x != 0.0f || g.y != 0.0f)) {   // out-of-bag rows carry (0, 0)
-            const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, c.sg), hq = (unsigned long long)fx_from_f32(g.y, c.sh);
+            const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, sg_k), hq = (unsigned long long)fx_from_f32(g.y, sh_k);
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g);
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #define LV_ATOM(j) { const uint32_t code_ = WIDE ? ((w[((j) & 7) >> 1] >> (16 * ((j) & 1))) & 0xFFFFu) : ((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu); \
@@ -337,12 +340,12 @@ template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers),
           bool ROUTE /* the first launch of a level: moves the rows to their children; later launches find the built rows by the final ids */,
           int THREADS /* 1024, or MT_THREADS_ACC2 */, bool ACC2 /* NCHR == 2 only: the histograms of BOTH chunks are accumulated by this launch */,
           bool SPEC /* wave-specialised: the last MT_CONSUMERS waves only run the batches (LDS atomics) out of the other waves' rings */,
-          bool ROTP = false /* feature rotation of the histogram updates (see MT_ROT): the host picks it for the launches whose LDS holds fewer than two copies */>
+          bool ROTP = false /* feature rotation of the histogram updates (see MT_ROT): the host picks it for the launches whose LDS holds fewer than three copies of their worst-case histograms (RGBM_MT_ROT_COPIES2 = 6) */>
 __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
                                                          const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                          int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
                                                          int32_t* __restrict__ err_flag, uint32_t* __restrict__ prog /* [row blocks][tree groups] lock-step progress words (SPEC), or null */,
-                                                         LevelConst c) {
+                                                         const FxScale* __restrict__ fxs /* [K] this iteration's grid per class tree */, LevelConst c) {
     static_assert(!ACC2 || NCHR == 2, "a two-chunk pass keeps both records in registers");
     constexpr int WAVES = THREADS / 64;
     constexpr int NCONS = SPEC ? MT_CONSUMERS : 0, NPROD = WAVES - NCONS;     // waves that walk the rows / waves that only run batches
@@ -385,7 +388,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     uint2* tpk = reinterpret_cast<uint2*>(ftab + 128 + 64);                                    // [MT_MAX_T + 2] what the row loop needs of a class tree: base | nlev << 8 | live << 31, rt_off | k << 16
     uint2* rt = tpk + MT_MAX_T + 2;                                                            // [MT_MAX_RT] route entries / child -> slot entries
     int32_t* cnt = reinterpret_cast<int32_t*>(rt + MT_MAX_RT);                                 // [MT_MAX_NODES][MT_CNT_REP]
-    uint4* ring_rec_all = reinterpret_cast<uint4*>(cnt + MT_MAX_NODES * MT_CNT_REP);           // [waves][MT_RING]
+    uint2* nd_sc = reinterpret_cast<uint2*>(cnt + MT_MAX_NODES * MT_CNT_REP);                  // [MT_MAX_NODES] local node -> high words of 2^e_g, 2^e_h of its class tree (the low words of a power of two are 0)
+    uint4* ring_rec_all = reinterpret_cast<uint4*>(nd_sc + MT_MAX_NODES);                      // [waves][MT_RING]
     uint4* ring_rec1_all = ring_rec_all + (ACC2 ? NRINGS * MT_RING : 0);                        // [waves][MT_RING] (two-chunk pass)
     uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec1_all + NRINGS * MT_RING);            // [waves][MT_RING]
     uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + NRINGS * MT_RING);        // [waves][MT_RING]
@@ -489,7 +493,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             }
             rt[t.rt_off + i] = e;
         }
-        for (int i = tid; i < t.nb; i += THREADS) nd_tree[t.slot0 + i] = (uint8_t)kk;
+        const uint2 sc_k = make_uint2((uint32_t)__double2hiint(fxs[t.k].sg), (uint32_t)__double2hiint(fxs[t.k].sh));
+        for (int i = tid; i < t.nb; i += THREADS) { nd_tree[t.slot0 + i] = (uint8_t)kk; nd_sc[t.slot0 + i] = sc_k; }
     }
     for (int i = tid; i < total * MT_CNT_REP; i += THREADS) cnt[i] = 0;
     if (tid < 48) rsync[tid] = 0u;            // (before the barrier below)
@@ -579,7 +584,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
 #pragma unroll
         for (int a = 0; a < NACC; ++a) { shp[a] = sh3p[a]; asm volatile("" : "+s"(shp[a])); }
         if (on) {
-            const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), c.sg), hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), c.sh);
+            const uint2 sc = nd_sc[li];                  // the grid of the entry's class tree
+            const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), __hiloint2double((int)sc.x, 0)),
+                                     hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), __hiloint2double((int)sc.y, 0));
             if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], 1);
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g) + li * spn8;
             uint32_t w[4] = {r.x, r.y, r.z, r.w};
@@ -1104,9 +1111,10 @@ __global__ __launch_bounds__(256) void k_level_split(const HistBin* __restrict__
                                                      const FeatMeta* __restrict__ fmeta, const uint8_t* __restrict__ used_all /* [NE][K][F] */,
                                                      Cand* __restrict__ cand /* [K][256][F] */, unsigned long long* __restrict__ stat_rows,
                                                      const int32_t* __restrict__ itp /* device-side iteration counter */,
-                                                     int n_hnodes, TrainConst c, LevelConst lc) {
-    const uint8_t* used = used_all + (long long)(*itp) * c.K * c.F;
+                                                     int n_hnodes, const FxScale* __restrict__ fxs, TrainConst c_model, LevelConst lc) {
     const int k = blockIdx.z, pi = blockIdx.y;
+    const TrainConst c = tree_const(c_model, fxs, k);          // sums -> doubles on this class tree's grid
+    const uint8_t* used = used_all + (long long)(*itp) * c.K * c.F;
     // ROOT: one wave per feature (4 per block).  Otherwise one wave per (feature, child side): 2 features per block,
     // so the two FindBestThreshold scans of a parent run side by side instead of back to back.
     const int wv = threadIdx.x >> 6;
@@ -1392,7 +1400,9 @@ __global__ __launch_bounds__(64) void k_level_replay(LvPlan* __restrict__ plan, 
 // training row ends in its final speculative node, whose score delta the replay has tabulated.
 // grid (gx, K), block 256, 4 rows per thread.
 // ------------------------------------------------------------------------------------------------
-template <bool COUNT_ONLY /* only the exact row counts of the deepest children: the fused k_level_final_grad_* pass does the rest */>
+// (A variant that also wrote the NEXT iteration's gradients -- one read of the K x N scores instead of two -- was built twice in round 5 and
+// measured slower both times (profiles/r5b_*, profiles/EXPERIMENTS.md); it left the tree with numerics v2.2, whose grid is measured by
+// the gradient kernels.)
 __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ rec, const uint8_t* __restrict__ node_all,
                                                      const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, const TreeOut out,
                                                      const double* __restrict__ node_delta, double* __restrict__ score, int32_t* __restrict__ count,
@@ -1405,7 +1415,6 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     if (out.L[(long long)it * c.K + k] <= 1) return;   // no split: no score change, nothing to count
     const LvPlan* pp = &plan[k];
     const bool route = !pp->done;                      // plan(max_depth) expanded at least one node
-    if (COUNT_ONLY && !route) return;                  // nothing is routed at the last level: nothing to count
     const int n_exp = route ? pp->n_exp : 0, child_first = pp->child_first;
     const int tid = threadIdx.x, lane = tid & 63;
     nd[tid] = node_delta[(long long)k * 256 + tid];
@@ -1419,42 +1428,6 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     // 4 rows per thread; node ids and scores are loaded together (independent loads), then routed and written back
     const bool aligned16 = (((unsigned long long)sk) & 15ull) == 0ull;   // uniform
     for (long long i = ((long long)blockIdx.x * 256 + tid) * 4; i < N; i += (long long)gridDim.x * 1024) {
-        if (COUNT_ONLY) {   // node ids only (1 B per row); rows outside the expanded parents of the last level cost nothing else
-            if (i + 3 < N) {
-                const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
-                if (n4 == 0xFFFFFFFFu) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = (int)((n4 >> (8 * j)) & 0xFFu);
-                    if (n == LV_INACTIVE) continue;
-                    const uint32_t w0 = route0[n];
-                    if (w0 & (1u << 24)) {
-                        const long long row = i + j;
-                        const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
-                        const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
-                        const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
-                        const uint32_t w1 = route1[n];
-                        const int ch = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
-                        if (!inbag || inbag[row]) atomicAdd(&cnt[(ch - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                    }
-                }
-                continue;
-            }
-            for (long long row = i; row < N && row < i + 4; ++row) {
-                const int n = node[row];
-                if (n == LV_INACTIVE) continue;
-                const uint32_t w0 = route0[n];
-                if (w0 & (1u << 24)) {
-                    const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
-                    const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
-                    const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
-                    const uint32_t w1 = route1[n];
-                    const int ch = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
-                    if (!inbag || inbag[row]) atomicAdd(&cnt[(ch - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
-                }
-            }
-            continue;
-        }
         if (i + 3 < N && aligned16) {
             const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
             double2 s01 = *reinterpret_cast<const double2*>(sk + i), s23 = *reinterpret_cast<const double2*>(sk + i + 2);
@@ -1500,201 +1473,6 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
         int tot = 0;
         for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
         if (tot) atomicAdd(&count[(long long)k * 256 + child_first + ci], tot);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The last pass of iteration i FUSED with the gradients of iteration i + 1 ("k_level_final and k_grad_mc both read the
-// K x N scores").  k_level_final reads node id + score and writes the score (17 B per (row, class tree)); the gradient kernel of the
-// next iteration reads the score again and writes (g, h) and the reset node id (17 B).  Fused, a score is read once, updated, written
-// once and turned into the next (g, h) while it is in a register / in the workgroup's LDS tile: 26 B instead of 34 B, one launch
-// instead of two.  Same arithmetic in the same order as k_level_final + k_grad_mc / k_grad_mc_rows / k_grad<OBJ> (the new score is
-// the double that k_level_final would have stored and the gradient kernel loaded), so every model stays bit-identical.
-//
-//   k_level_fin_table         one 32-byte entry per (class tree, node id): what a row sitting in that node needs -- the last routing step
-//                             (feature, threshold, NaN bin, default direction) and the score delta on either side.
-//   k_level_final<true>       the exact row counts of the deepest children (Tree::leaf_count_) stay a pass of their own: it reads the
-//                             node ids only (1 B per (row, class tree)) and returns at once for a class tree that routes nothing at the
-//                             last level.  (First cut: leaf counters in the LDS of persistent workgroups of the fused kernel -- those
-//                             held 3 x 43 KB of every CU's LDS for the whole launch, the level passes of the other targets in flight
-//                             could not start next to them, and the bench step went from 84.6 to 89.1 ms.)
-//   k_level_final_grad_mc     softmax, 16 <= K <= 112: k_grad_mc's layout (64 rows x 4 class-slice waves, K x 64 score tile in LDS)
-//   k_level_final_grad_rows   thread per row: binary / L2 (one class tree) and softmax with K < 16
-// Not used with bagging (the bag of iteration i + 1 is drawn between the two halves) nor for the last iteration.
-// ------------------------------------------------------------------------------------------------
-struct FinEntry {
-    uint32_t w0;          // feature | (theta+1) << 8 | nan bin << 16 | expanded << 24 | default-left << 25   (0: the node is not routed)
-    uint32_t skip;        // the class tree has no split: its scores do not change at all
-    double dl, dr;        // score delta of a row that ends on the left / right side (not routed: both = the node's own delta)
-    double pad2;
-};
-static_assert(sizeof(FinEntry) == 32, "one 16-byte gather per (row, class tree) + 8 more bytes for the rows that are routed to the right");
-
-__global__ __launch_bounds__(256) void k_level_fin_table(const LvPlan* __restrict__ plan, const TreeOut out, const double* __restrict__ node_delta,
-                                                         FinEntry* __restrict__ fin /* [K][256] */, const int32_t* __restrict__ itp, LevelConst c) {
-    const int k = blockIdx.x, n = threadIdx.x;
-    const int L = out.L[(long long)(*itp) * c.K + k];
-    const LvPlan* pp = &plan[k];
-    FinEntry e; e.w0 = 0u; e.skip = 0u; e.dl = 0.0; e.dr = 0.0; e.pad2 = 0.0;
-    if (L <= 1) e.skip = 1u;
-    else {
-        const uint32_t w0 = pp->done ? 0u : pp->route0[n];      // plan(max_depth) expanded nothing: no routing step
-        const uint32_t w1 = pp->route1[n];
-        const double* nd = node_delta + (long long)k * 256;
-        if (w0 & (1u << 24)) { e.w0 = w0; e.dl = nd[w1 & 0xFFu]; e.dr = nd[(w1 >> 8) & 0xFFu]; }
-        else { e.dl = nd[n]; e.dr = e.dl; }
-    }
-    fin[(long long)k * 256 + n] = e;
-}
-
-// The classes of a step are worked in chunks of FIN_CH: all node ids and scores of a chunk are requested first, then all table entries,
-// then the (rare) record bytes -- three memory round trips per chunk instead of two per class (a first cut with one class after the
-// other was SLOWER than the two kernels it replaces).  An entry's first 16 bytes -- routing word, skip flag, left delta -- are gathered
-// for every (row, class tree); the right delta only by the rows whose node IS routed and that go right.
-constexpr int FIN_CH = 8;
-struct FinHead { uint32_t w0, skip; double dl; };
-__device__ __forceinline__ FinHead fin_head(const FinEntry* __restrict__ fin, long long idx) {
-    const uint4 q = reinterpret_cast<const uint4*>(fin)[idx * 2];
-    FinHead h; h.w0 = q.x; h.skip = q.y; h.dl = __hiloint2double((int)q.w, (int)q.z);
-    return h;
-}
-__device__ __forceinline__ double fin_route(const FinHead& e, const FinEntry* __restrict__ fin, long long idx, const uint8_t* __restrict__ rec8, long long N, long long row) {
-    double d = e.dl;
-    if (e.w0 & (1u << 24)) {
-        const int f = (int)(e.w0 & 0xFFu), theta1 = (int)((e.w0 >> 8) & 0xFFu), nanbin = (int)((e.w0 >> 16) & 0xFFu);
-        const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
-        const bool left = (bin == nanbin) ? ((e.w0 >> 25) & 1u) != 0u : (bin < theta1);
-        if (!left) d = fin[idx].dr;
-    }
-    return d;
-}
-
-// softmax, 16 <= K <= 112.  grid: one workgroup per 64 rows; dynamic LDS = (K * 64 + 320) * 8.
-__global__ __launch_bounds__(256) void k_level_final_grad_mc(const uint4* __restrict__ rec, uint8_t* __restrict__ node_all, const FinEntry* __restrict__ fin,
-                                                             double* __restrict__ score, const int32_t* __restrict__ ycol, const double* __restrict__ class_w,
-                                                             const double* __restrict__ sample_w, float2* __restrict__ gh, LevelConst lc, TrainConst c) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* tile = reinterpret_cast<double*>(smem);          // [K][64]
-    double* pmax = tile + (size_t)c.K * 64;                  // [4][64]
-    double* psum = pmax + 256;                               // [64]
-    const long long N = c.N, NS = lc.NS;
-    // (wv through readfirstlane: the class k of a step is then a scalar for the compiler, and so is every per-class base address)
-    const int K = c.K, r = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
-    const long long i = (long long)blockIdx.x * 64 + r;
-    const bool valid = i < N;
-    const long long ic = valid ? i : N - 1;
-    const int y = ycol[ic];
-    double m = -INFINITY;
-    for (int k0 = wv; k0 < K; k0 += 4 * FIN_CH) {
-        int nn[FIN_CH]; double vv[FIN_CH]; FinHead ee[FIN_CH];
-#pragma unroll
-        for (int u = 0; u < FIN_CH; ++u) {
-            const int k = k0 + 4 * u, kc = k < K ? k : k0;
-            nn[u] = (int)(node_all + (long long)kc * NS)[(unsigned)ic];        // scalar base + 32-bit row offset (the host keeps N below 2^28 here)
-            vv[u] = (score + (long long)kc * N)[(unsigned)ic];
-        }
-#pragma unroll
-        for (int u = 0; u < FIN_CH; ++u) {
-            const int k = k0 + 4 * u, kc = k < K ? k : k0;
-            if (!(valid && k < K)) nn[u] = LV_INACTIVE;
-            ee[u] = fin_head(fin + (long long)kc * 256, (long long)(unsigned)(nn[u] != LV_INACTIVE ? nn[u] : 0));
-        }
-#pragma unroll
-        for (int u = 0; u < FIN_CH; ++u) {
-            const int k = k0 + 4 * u;
-            if (k < K) {     // (uniform)
-                double v = vv[u];
-                if (nn[u] != LV_INACTIVE) {
-                    const double d = fin_route(ee[u], fin, (long long)k * 256 + nn[u], rec8, N, i);
-                    if (!ee[u].skip) { v += d; score[(long long)k * N + i] = v; }
-                    if (nn[u] != 0) node_all[(long long)k * NS + i] = 0;          // every training row restarts in the root
-                }
-                tile[k * 64 + r] = v; if (v > m) m = v;
-            }
-        }
-    }
-    pmax[wv * 64 + r] = m;
-    __syncthreads();
-    double wmax = pmax[r];
-    { const double b1 = pmax[64 + r], b2 = pmax[128 + r], b3 = pmax[192 + r]; if (b1 > wmax) wmax = b1; if (b2 > wmax) wmax = b2; if (b3 > wmax) wmax = b3; }
-    for (int k = wv; k < K; k += 4) tile[k * 64 + r] = rg_exp(tile[k * 64 + r] - wmax);
-    __syncthreads();
-    if (wv == 0) { double wsum = 0.0; for (int k = 0; k < K; ++k) wsum += tile[k * 64 + r]; psum[r] = wsum; }
-    __syncthreads();
-    if (!valid || y < 0) return;    // not a training row: its gh stays 0 for ever
-    double wi = class_w ? class_w[y] : 1.0;
-    if (sample_w) wi = wi * sample_w[i];
-    wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
-    const double wsum = psum[r];
-    for (int k = wv; k < K; k += 4) {
-        const double pk = tile[k * 64 + r] / wsum;
-        store_gh(gh, (long long)k * c.NG + i, ((y == k) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
-    }
-}
-
-// thread per row: binary (OBJ 0) / L2 (OBJ 2) with one class tree, softmax (OBJ 1) with K < 16 (the row's K scores parked in its own LDS
-// column, as k_grad_mc_rows).  grid: one workgroup per R rows; dynamic LDS = OBJ == 1 ? K * R * 8 : 0.
-template <int OBJ, int R>
-__global__ __launch_bounds__(R) void k_level_final_grad_rows(const uint4* __restrict__ rec, uint8_t* __restrict__ node_all, const FinEntry* __restrict__ fin,
-                                                             double* __restrict__ score, const int32_t* __restrict__ ycol, const double* __restrict__ y_value,
-                                                             const double* __restrict__ class_w, const double* __restrict__ sample_w, float2* __restrict__ gh,
-                                                             LevelConst lc, TrainConst c) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int K = (OBJ == 1) ? c.K : 1;
-    double* tile = reinterpret_cast<double*>(smem) + threadIdx.x;                                         // element k at tile[k * R]  (OBJ 1)
-    const long long N = c.N, NS = lc.NS;
-    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
-    const long long i = (long long)blockIdx.x * R + threadIdx.x;
-    if (i >= N) return;
-    const int y = ycol[i];
-    double wmax = -INFINITY, s0 = 0.0;
-    for (int k0 = 0; k0 < K; k0 += FIN_CH) {
-        int nn[FIN_CH]; double vv[FIN_CH]; FinHead ee[FIN_CH];
-#pragma unroll
-        for (int u = 0; u < FIN_CH; ++u) {
-            const int kc = k0 + u < K ? k0 + u : k0;
-            nn[u] = (int)node_all[(long long)kc * NS + i];
-            vv[u] = score[(long long)kc * N + i];
-        }
-#pragma unroll
-        for (int u = 0; u < FIN_CH; ++u) {
-            const int kc = k0 + u < K ? k0 + u : k0;
-            if (k0 + u >= K) nn[u] = LV_INACTIVE;
-            ee[u] = fin_head(fin, (long long)kc * 256 + (nn[u] != LV_INACTIVE ? nn[u] : 0));
-        }
-#pragma unroll
-        for (int u = 0; u < FIN_CH; ++u) {
-            const int k = k0 + u;
-            if (k < K) {
-                double v = vv[u];
-                if (nn[u] != LV_INACTIVE) {
-                    const double d = fin_route(ee[u], fin, (long long)k * 256 + nn[u], rec8, N, i);
-                    if (!ee[u].skip) { v += d; score[(long long)k * N + i] = v; }
-                    if (nn[u] != 0) node_all[(long long)k * NS + i] = 0;
-                }
-                if (OBJ == 1) { tile[k * R] = v; if (v > wmax) wmax = v; } else s0 = v;
-            }
-        }
-    }
-    if (y < 0) return;            // not a training row: its gh stays 0 for ever
-    double wi = class_w ? class_w[y] : 1.0;
-    if (sample_w) wi = wi * sample_w[i];
-    wi = (double)(float)wi;       // LightGBM Metadata keeps weights as float32
-    if (OBJ == 0) {               // binary_objective.hpp GetGradients (sigmoid = 1, label_weight = 1)
-        const double label = (y > 0) ? 1.0 : -1.0;
-        const double response = -label / (1.0 + rg_exp(label * s0));
-        const double abs_r = fabs(response);
-        store_gh(gh, i, response * wi, abs_r * (1.0 - abs_r) * wi);
-    } else if (OBJ == 2) {        // RegressionL2loss::GetGradients
-        store_gh(gh, i, (s0 - y_value[y]) * wi, wi);
-    } else {
-        double wsum = 0.0;
-        for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
-        for (int kk = 0; kk < K; ++kk) {
-            const double pk = tile[kk * R] / wsum;
-            store_gh(gh, (long long)kk * c.NG + i, ((y == kk) ? (pk - 1.0) : pk) * wi, c.factor * pk * (1.0 - pk) * wi);
-        }
     }
 }
 

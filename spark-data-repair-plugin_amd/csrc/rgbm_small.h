@@ -16,8 +16,9 @@
 // the chip -- hundreds of class trees at once -- and an iteration of the whole batch costs what one class tree costs.
 //
 // The arithmetic IS the leaf-wise grower's: the same device functions (scan_child, split_find_body, reduce_leaf_best, tree_step_pick,
-// finish_split_body, grad_rows), the same exact integer histograms (numerics v2.1), so every model is the one rgbm_table_train
-// returns for that fit, bit for bit (tests/test_gpu_batch.py).
+// finish_split_body, grad_rows), the same exact integer histograms (numerics v2.2: the grid of a class tree is measured at the start of
+// k_small_tree, from the same coarse sums the big-table trainer takes out of its gradient kernels), so every model is the one
+// rgbm_table_train returns for that fit, bit for bit (tests/test_gpu_batch.py).
 //
 // Per-fit constants are read through a descriptor (SmallFit) instead of kernel arguments; every fit has its own bin records, because
 // LightGBM bins a fit on ITS training rows (min_data_in_bin can merge a rare value in one fold and not in another).
@@ -325,9 +326,11 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ TreeState st;
     __shared__ int wl[SM_WAVES], wr[SM_WAVES];
+    __shared__ unsigned long long fxq[SM_WAVES][2];
+    __shared__ FxScale fx_tree;
     const SmallFit& sf = fits[tree2fit[blockIdx.x]];
     if (it >= sf.n_estimators || small_fit_frozen(sf, it)) return;
-    const TrainConst c = sf.c;
+    TrainConst c = sf.c;
     const int k = (int)blockIdx.x - sf.tree0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NL = c.num_leaves, F = c.F;
     size_t off = sm_hist_area((size_t)sf.lds_hist, NL);
@@ -357,6 +360,24 @@ __global__ __launch_bounds__(SM_THREADS, 4 /* waves per SIMD: at most 128 VGPRs,
 #define SM_T(i)
 #endif
 
+    // ---- numerics v2.2: this class tree's fixed-point grid, from the coarse sums of its (g, h) (k_fx_measure + k_fx_scale of the big-table
+    // trainer; rows outside the training set / the bag carry (0, 0))
+    {
+        unsigned long long a0 = 0ull, a1 = 0ull;
+        for (long long p = tid; p < N; p += SM_THREADS) { const float2 g = ghk[p]; a0 += fx_coarse(g.x, c.fx.c_g); a1 += fx_coarse(g.y, c.fx.c_h); }
+        a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
+        if (lane == 0) { fxq[wv][0] = a0; fxq[wv][1] = a1; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long q0 = 0ull, q1 = 0ull;
+            for (int w = 0; w < SM_WAVES; ++w) { q0 += fxq[w][0]; q1 += fxq[w][1]; }
+            const int e_g = fx_tree_exponent(q0, c.fx.q_mult, c.fx.c_g, c.fx.e_g_min, c.fx.e_g_max), e_h = fx_tree_exponent(q1, c.fx.q_mult, c.fx.c_h, c.fx.e_h_min, c.fx.e_h_max);
+            FxScale f; f.sg = fx_pow2(e_g); f.sh = fx_pow2(e_h); f.inv_sg = fx_pow2(-e_g); f.inv_sh = fx_pow2(-e_h);
+            fx_tree = f;
+        }
+        __syncthreads();
+        c.sg = fx_tree.sg; c.sh = fx_tree.sh; c.inv_sg = fx_tree.inv_sg; c.inv_sh = fx_tree.inv_sh;
+    }
     // ---- k_init_iter
     if (tid == 0) {
         TreeState s; memset(&s, 0, sizeof(s));

@@ -32,7 +32,7 @@ class RgbmTrainStats(C.Structure):
     _fields_ = [
         ("hist_ms", C.c_double), ("total_ms", C.c_double), ("hist_launches", C.c_int64), ("hist_rows", C.c_int64),
         ("hist_bytes", C.c_int64), ("root_rows", C.c_int64), ("root_ms", C.c_double), ("trees", C.c_int64),
-        ("route_ms", C.c_double), ("route_launches", C.c_int64),
+        ("route_ms", C.c_double), ("route_launches", C.c_int64), ("root_atomics_per_row", C.c_int64), ("level_atomics_per_row", C.c_int64),
     ]
 
     def as_dict(self):

@@ -281,6 +281,11 @@ def max_over_ranks(x):
     return float(t.item())
 
 
+def min_over_ranks(x):
+    """The smallest value any rank holds: how ranks settle on a number derived from rank-local inputs (engine.run_job: fusion members)."""
+    return -max_over_ranks(-float(x))
+
+
 def sum_over_ranks(x):
     d = _dist()
     if d is None or d.get_world_size() == 1:

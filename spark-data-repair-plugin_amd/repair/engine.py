@@ -209,9 +209,9 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     # owns a HIP stream and ctypes releases the GIL.  A few-class target is a chain of small dependent kernels (plan / split-find /
     # replay at 10-40 us around 0.1 ms passes) that leaves the GPU idle two thirds of the time; next to a many-class target those
     # kernels fill the gaps between its passes.  Largest first (LPT), a bounded number in flight (device memory: ~26 B per row and
-    # class tree each).  The row-sharded targets stay on THIS thread, one after another in the same order on every rank (the
-    # communicator belongs to the thread, and one collective sequence per process cannot dead-lock against another).  The models do
-    # not depend on any of this.
+    # class tree each).  The row-sharded targets run next to them: in a fusion group (below: member j of the group trains big[j],
+    # big[j + M], ... on a thread and a stream of its own, the same assignment on every rank, ONE collective per step for all of them) or,
+    # without one, one after another on THIS thread in the same order on every rank.  The models do not depend on any of this.
     conc = _train_concurrency(engine, train_table, [c for c in costs if c[0] in set(mine)] + list(big), train_concurrency,
                               search_fits=getattr(param_search, "fits_in_flight", 0) if param_search is not None else 0)
     # The reference's default job trains every model on a <= 10 000-row sample (model.py:755-766): such fits are chains of tiny
@@ -253,11 +253,21 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
         # Without one (oracle engine of the CPU tests, a single target, RGBM_FUSION=0) they train one after another on this thread.
         import os
         # (members in flight: measured on one rank's share of the 100M x 32 job -- a 12.5M-row shard, eight targets -- 91.8 ms per step one
-        # after another, 79.9 with six in flight, 75.6 with all eight, 72.5 without any collective: profiles/r5g_*; a shard's targets are small,
-        # so up to eight as long as the memory budget of `conc` whole-table targets allows it)
-        n_members = min(len(big), max(1, conc, min(8, int(os.environ.get("RGBM_FUSION_MEMBERS", "8"))))) if os.environ.get("RGBM_FUSION", "1") != "0" else 1
-        if conc <= 1:
-            n_members = 1
+        # after another, 79.9 with six in flight, 75.6 with all eight, 72.5 without any collective: profiles/r5g_*.)  Up to eight, CAPPED by the
+        # same memory budget that caps `conc`: a member's fit holds ~26 B per (row of THIS rank's shard, class tree) = cost / ws, and
+        # the pool beside it keeps up to conc - 1 whole-table fits in flight.  The number fixes the collective schedule (big[j::n_members]), so
+        # the ranks AGREE on it -- it derives from rank-local inputs (this rank's share of the small targets, its free memory, its environment):
+        # the minimum over the ranks, one tiny all-reduce that every rank reaches because `big` is the same list everywhere.
+        n_members = 1
+        if big:
+            want = min(len(big), 8, max(1, int(os.environ.get("RGBM_FUSION_MEMBERS", "8")))) if (os.environ.get("RGBM_FUSION", "1") != "0" and conc > 1) else 1
+            budget = 0.5 * getattr(engine, "device_memory_bytes", lambda: 256e9)()
+            cost_of_ = dict(costs)
+            pool_need = sum(sorted((26.0 * cost_of_[t] for t in mine_single), reverse=True)[:max(0, conc - 1)])
+            shard_need = sorted((26.0 * c / max(ws, 1) for _, c in big), reverse=True)
+            while want > 1 and pool_need + sum(shard_need[:want]) > budget:
+                want -= 1
+            n_members = max(1, int(dist.min_over_ranks(want)))
         group = engine.fusion_group(n_members) if (n_members > 1 and hasattr(engine, "fusion_group")) else None
         if group is not None:
             from concurrent.futures import ThreadPoolExecutor

@@ -30,6 +30,7 @@ from oracle import oracle as O  # noqa: E402
 from repair.synth import balanced_weights, make_table  # noqa: E402
 from tests.numerics_bound import iteration_digests  # noqa: E402
 
+NUMERICS_VERSION = 220     # rgbm_version() of the library the digests pin (numerics v2.2: a fixed-point grid per class tree and iteration)
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_job_digests.json")
 
 
@@ -41,31 +42,34 @@ def main():
     ap.add_argument("--targets", default="10,0")
     ap.add_argument("--cols", type=int, default=16)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--iters-for", default="", help="per-target iteration counts that override --iters, e.g. 0:300,11:300 (the cheap targets pinned end to end)")
     ap.add_argument("--out", default=OUT, help="bench_job_digests.json (10M x 16) or bench_shard_digests.json (--rows 12500000 --cols 32 --seed 43)")
     a = ap.parse_args()
     OUT_ = a.out if os.path.isabs(a.out) else os.path.join(os.path.dirname(os.path.abspath(__file__)), a.out)
     dirty, clean, cards = make_table(a.rows, a.cols, seed=a.seed)
     del clean
     doc = {"table": {"rows": a.rows, "cols": a.cols, "seed": a.seed, "null_ratio": 0.01}, "iters": a.iters,
-           "numerics_version": 210, "generator": "tests/golden/make_bench_job_golden.py", "targets": {}}
+           "numerics_version": NUMERICS_VERSION, "generator": "tests/golden/make_bench_job_golden.py", "targets": {}}
     if os.path.exists(OUT_):
         old = json.load(open(OUT_))
-        if old.get("table") == doc["table"] and old.get("iters") == a.iters and old.get("numerics_version") == 210:
+        if old.get("table") == doc["table"] and old.get("iters") == a.iters and old.get("numerics_version") == NUMERICS_VERSION:
             doc["targets"] = old["targets"]
     O.lib().orc_set_threads(a.threads)
+    iters_for = {int(x.split(":")[0]): int(x.split(":")[1]) for x in a.iters_for.split(",") if x}
     for t in [int(x) for x in a.targets.split(",")]:
         feats = [c for c in range(a.cols) if c != t]
         K = int(cards[t])
         rows = dirty[t] >= 0
         cw = balanced_weights(dirty[t], K)
-        kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=a.iters)
+        n_it = iters_for.get(t, a.iters)      # (a target's own count: the test trains it for len(digests) iterations)
+        kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=n_it)
         t0 = time.time()
         blob = O.train(np.ascontiguousarray(dirty[feats][:, rows]), cards[feats], dirty[t][rows], K, class_weight=cw, **kw).save()
         doc["targets"]["c%d" % t] = {"K": K, "train_rows": int(rows.sum()), "digests": iteration_digests(blob),
                                       "oracle_seconds": round(time.time() - t0, 1), "threads": a.threads}
         with open(OUT_, "w") as f:
             json.dump(doc, f, indent=1)
-        print("c%d (K=%d): %d iterations in %.0f s" % (t, K, a.iters, time.time() - t0), flush=True)
+        print("c%d (K=%d): %d iterations in %.0f s" % (t, K, n_it, time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":

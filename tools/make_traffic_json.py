@@ -55,7 +55,8 @@ def main():
     n_launch = len(ks) * a.reps * a.iters
     exp_read = sum(8.0 * k * a.rows + 4.0 * a.rows for k in ks) * a.reps * a.iters
     ns = (a.rows + 255) // 256 * 256          # node-id / (g, h) rows are padded to whole wave tiles (numerics v2.1 build); the padding is never written
-    exp_write = sum(8.0 * k * a.rows * 0.99 + 1.0 * k * a.rows for k in ks) * a.reps * a.iters
+    # (numerics v2.2: + the coarse gradient sums k_grad_mc leaves per 64-row workgroup, 16 B per class tree)
+    exp_write = sum(8.0 * k * a.rows * 0.99 + 1.0 * k * a.rows + 16.0 * k * ((a.rows + 63) // 64) for k in ks) * a.reps * a.iters
     del ns
     assert fetch["grad_mc"][1] == n_launch == write["grad_mc"][1], ("k_grad_mc launches", fetch.get("grad_mc"), n_launch)
     f_cal = exp_read / (fetch["grad_mc"][0] * 1024.0)
@@ -63,6 +64,7 @@ def main():
     out = {"source": "profiles/%s_hbm_traffic_pmc.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over python tools/probe.py --iters %d "
                      "--targets %s --stats 0 (every target model of the %dM x %d workload, one after another); counters x calibration factor (FETCH %.3f, WRITE %.3f: known "
                      "reads / writes of rg::k_grad_mc in the same run)" % (a.tag, a.iters, a.targets or "0..%d" % (a.cols - 1), a.rows // 1_000_000, a.cols, f_cal, w_cal),
+           "rows": a.rows, "cols": a.cols,
            "calibration": {"fetch_factor": f_cal, "write_factor": w_cal, "kernel": "rg::k_grad_mc", "launches": n_launch}, "classes": {}}
     for cls in ("root", "level"):
         fb, fl = fetch[cls][0] * 1024.0 * f_cal, fetch[cls][1]
