@@ -20,8 +20,9 @@ says so).  With --gpus N (N > 1) and no torchrun environment the script launches
 
 Multi-GPU ("scaling": "strong", the SAME job on more GPUs): expensive targets are trained row-sharded over all ranks (every
 rank holds a row shard, librepairgbm all-reduces integer histograms over RCCL -- the model is bit-identical for any N), cheap
-ones are target-sharded (LPT), the chained repair is row-sharded.  --mode targets = pure target sharding (the reference's own
-parallel mode).
+ones are target-sharded (LPT), the chained repair is row-sharded and the repaired cells are all-gathered from device buffers
+on the same RCCL communicator (one per rank; torch's process group is gloo and carries control traffic only).
+--mode targets = pure target sharding (the reference's own parallel mode).
 """
 import argparse
 import hashlib
@@ -273,7 +274,11 @@ def main():
         import datetime
         # every wait of the job is bounded: torch's collectives by this timeout, librepairgbm's by RGBM_COMM_TIMEOUT_S (its watchdog aborts the
         # communicator and the call raises) -- a rank that is gone ends the job with an error line, not with a hang
-        dist.init_process_group("gloo" if share_gpu else "nccl", rank=rank, world_size=world,
+        # The process group carries CONTROL traffic only (barriers, a few scalars, the ncclUniqueId): gloo.  Everything that moves data between
+        # GPUs -- the integer all-reduces of row-sharded training, C1 (serialised models) and C2 (repaired cells) -- runs on librepairgbm's own
+        # RCCL communicator (repair.dist.init_row_comm), so a rank holds ONE RCCL communicator; if that communicator cannot be created the job
+        # falls back to target sharding and the gathers go through this group.
+        dist.init_process_group("gloo", rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=float(os.environ.get("BENCH_DIST_TIMEOUT_S", "900"))))
 
     from repair import dist as rdist
@@ -290,7 +295,7 @@ def main():
     # histograms: same models as on one GPU), the rank repairs the dirty rows of its shard and the repaired cells are all-gathered.
     # No rank ever holds the 12.8 GB table.  (Decided collectively: it needs the RCCL communicator on every rank.)
     shard_only = False
-    if world > 1 and a.mode == "auto" and rows * cols > 400_000_000 and not (0 < a.train_rows < rows):
+    if world > 1 and a.mode == "auto" and not share_gpu and rows * cols > 400_000_000 and not (0 < a.train_rows < rows):
         shard_only = bool(rdist.init_row_comm(local_rank))
     # ---- inputs (outside the timed region: detector + encoder outputs, resident in HBM) + the warm-up fits
     eng = HipEngine(device_id=local_rank)
@@ -336,7 +341,7 @@ def main():
         row_tab = None
         if shard_only:
             row_tab = train_tab
-        elif world > 1 and a.mode == "auto" and allow_row_comm and rdist.init_row_comm(local_rank):
+        elif world > 1 and a.mode == "auto" and not share_gpu and allow_row_comm and rdist.init_row_comm(local_rank):
             b0, c0 = rdist.shard_rows(train_src.shape[1], world, rank)
             row_tab = eng.upload(np.ascontiguousarray(train_src[:, b0:b0 + c0]), cards)
         elif world == 1 and a.force_row_sharding:
@@ -374,7 +379,7 @@ def main():
                     digests = rdist.exchange_blobs({rank: dig})      # (every rank takes part, also one whose fit failed: no rank waits for a missing peer)
                     ok = int(ok and len(set(digests.values())) == 1)
                 if world > 1:
-                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                    flag = torch.tensor([ok], dtype=torch.int32)
                     torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
                     ok = int(flag.item())
                 if not ok:
@@ -554,7 +559,9 @@ def main():
             rc = dict(rdist.ROW_COMM)
             out["config"]["rccl"] = {"asked": rc["asked"], "ranks_seen_by_ncclCommCount": rc["ranks"], "comm_init_sec": round(rc["init_sec"], 3), "fell_back": rc["fell_back"],
                                      "why": rc["why"], "timeout_s": float(os.environ.get("RGBM_COMM_TIMEOUT_S", "600")),
-                                     "fusion": res.get("fusion") or None}
+                                     "fusion": res.get("fusion") or None,
+                                     # C1 / C2: which path carried the model blobs and the repaired cells, and what it moved
+                                     "gather": dict(rdist.GATHER)}
         if not a.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (the other ranks would sit in the barrier below)
             out["cpu_baseline"] = cpu_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS, full_rows=rows if not (0 < a.train_rows < rows) else 0, cells_full=n_cells)
             out["cpu_baseline"]["true_reference"] = true_reference_baseline(cols, cfg["seed"], targets, REF_N_ESTIMATORS)

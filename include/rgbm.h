@@ -261,6 +261,19 @@ int rgbm_comm_finalize(void);
 int rgbm_comm_info(int32_t* info /* [3] = {0 none | 1 RCCL | 2 thread group | 3 member of a fusion group, rank, nranks} */);
 int rgbm_comm_count(int32_t* n_out /* ranks the communicator really spans (ncclCommCount); 1 without one */);
 /* Test transport: the ranks are host threads of one process sharing one device. */
+/* ---- C1 / C2 of a multi-GPU job on THIS communicator (device buffers, ncclAllGather over xGMI; a rank holds one RCCL communicator) -------
+ * Replace `sparkContext.broadcast(models)` (python/repair/model.py:1069: every worker gets every serialised model) and the union of the
+ * grouped-map UDF outputs (model.py:1142: the repaired cells of all row groups).  Blocks are equal-sized: callers exchange their sizes with
+ * rgbm_comm_all_gather_sizes first and pad to the largest.  Thread group / no communicator: the same calls, device copies.  Not from inside a
+ * fusion group. */
+int rgbm_comm_all_gather_sizes(const int64_t* mine, int32_t n, int64_t* all /* [nranks][n] */);
+int rgbm_comm_all_gather_bytes(const void* send, int64_t my_bytes, int64_t block_bytes /* >= every rank's my_bytes */, void* recv /* [nranks][block_bytes] */);
+/* rgbm_table_repair_chain of this rank's rows with the outputs left on the device, all-gathered there and copied out once:
+ * out_label / out_prob [nranks][T][max_rows] (a rank's block: its n_rows rows of every model, zero-padded to max_rows). */
+int rgbm_table_repair_chain_gather(rgbm_table* t, const rgbm_model* const* models, int32_t T, const int32_t* target_col,
+                                   const int32_t* feat_cols, const int32_t* feat_off, int64_t row_begin, int64_t n_rows, int64_t max_rows,
+                                   int32_t* out_label, double* out_prob);
+int rgbm_comm_gather_stats(int64_t* out /* [3] = {bytes received, nanoseconds, collectives} of this process's all-gathers */);
 int rgbm_local_group_create(int32_t nranks, int32_t device_id, void** group_out);
 void rgbm_local_group_free(void* group);
 int rgbm_comm_init_local(void* group, int32_t rank);

@@ -410,6 +410,29 @@ void all_reduce_on(Comm& c, void* buf, size_t count, int type, hipStream_t s) {
     g->barrier();
 }
 
+// all-gather of equal-sized device blocks over the calling thread's own communicator (not from inside a fusion group): recv = [nranks][bytes].
+// RCCL: ncclAllGather on the library's communicator, enqueued on s; thread group: every rank copies every rank's block (device copies
+// between two barriers); no communicator: a copy.  What the C1 / C2 exchanges of a multi-GPU job ride on (model blobs, repaired cells).
+struct GatherStats { std::atomic<long long> bytes{0}, ns{0}, calls{0}; };
+GatherStats& gather_stats() { static GatherStats g; return g; }
+void all_gather_on(Comm& c, const void* send, void* recv, size_t bytes, hipStream_t s) {
+    if (c.kind == 3) throw std::invalid_argument("all-gather from inside a fusion group");
+    if (bytes == 0) return;
+    if (c.kind == 0 || c.nranks <= 1) { if (c.kind != 1) { HIPCHK(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s)); return; } }
+    if (c.kind == 1) {
+        ncclResult_t r = ncclAllGather(send, recv, bytes, ncclUint8, c.nccl, s);
+        if (r != ncclSuccess) throw std::runtime_error(std::string("ncclAllGather failed: ") + ncclGetErrorString(r));
+        return;
+    }
+    LocalGroup* g = c.lg;
+    HIPCHK(hipStreamSynchronize(s));
+    { std::lock_guard<std::mutex> lk(g->mu); g->ptr[c.rank] = const_cast<void*>(send); }
+    g->barrier();
+    for (int r = 0; r < g->nranks; ++r) HIPCHK(hipMemcpyAsync(static_cast<char*>(recv) + (size_t)r * bytes, g->ptr[r], bytes, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    g->barrier();                                   // everyone has read every block
+}
+
 struct Feat {
     int32_t n_codes = 0, V = 0, has_nan = 0; std::vector<int32_t> ub;
     // CATEGORICAL features only (else empty): bit c set => no training row held code c.  Such a category is MISSING for this model at
@@ -2297,7 +2320,8 @@ RGBM_EXPORT int rgbm_predict(const rgbm_model* m, const int32_t* X, int64_t n, i
 
 static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* target_col, const int32_t* feat_cols, const int32_t* feat_off,
                         const int32_t* class_code, const int32_t* class_off, int32_t* d_codes, long long Ntab, long long row0, long long n,
-                        int device, hipStream_t s, int32_t* out_label, double* out_prob) {
+                        int device, hipStream_t s, int32_t* out_label, double* out_prob,
+                        int32_t* d_label_all = nullptr, double* d_prob_all = nullptr, long long sink_stride = 0 /* device sinks [T][sink_stride]: the outputs STAY on the device (C2 on device buffers) */) {
     using namespace rg;
     for (int t = 0; t < T; ++t)
         if (feat_off[t + 1] - feat_off[t] != models[t]->F) throw std::invalid_argument("chain: feature list length differs from the model's feature count");
@@ -2362,6 +2386,9 @@ static int chain_device(rgbm_model* const* models, int32_t T, const int32_t* tar
             HIPCHK(hipStreamSynchronize(s));
         }
         double t3 = now(); t_fill += t3 - t2;
+        if (d_label_all) HIPCHK(hipMemcpyAsync(d_label_all + (size_t)t * sink_stride, d_label[b].p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (d_prob_all) HIPCHK(hipMemcpyAsync(d_prob_all + (size_t)t * sink_stride, d_top[b].p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if ((d_label_all || d_prob_all) && !staged) HIPCHK(hipStreamSynchronize(s));
         if (staged) {
             char* pin = (char*)CS.p[b];
             if (out_label) HIPCHK(hipMemcpyAsync(pin, d_label[b].p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream.s));
@@ -2607,6 +2634,75 @@ RGBM_EXPORT int rgbm_comm_finalize(void) {
     if (g_comm.kind == 1 && g_comm.nccl) (void)ncclCommDestroy(g_comm.nccl);
     if (g_comm.tmp) (void)hipFree(g_comm.tmp);
     g_comm = Comm();
+    return RGBM_OK;
+}
+
+// ---- C1 / C2 of a multi-GPU job on the library's OWN communicator ("C1 / C2 on device buffers and one communicator"): the
+// serialised models (Spark broadcast, python/repair/model.py:1069) and the repaired cells (the union of the UDF outputs, model.py:1142) are
+// all-gathered by ncclAllGather over xGMI on the communicator the row-sharded trainer uses -- a rank holds ONE RCCL communicator; torch's process
+// group only carries control traffic (gloo).  Equal-sized blocks: the callers pad to the largest rank (sizes first, through the same path).
+static void gather_host_blocks(const void* send, size_t my_bytes, size_t block_bytes, void* recv) {
+    Comm& c = g_comm;
+    const int nr = std::max(1, c.nranks);
+    StreamGuard sg; hipStream_t s = sg.s;
+    const auto t0 = std::chrono::steady_clock::now();
+    DevBuf<unsigned char> d_send(std::max<size_t>(block_bytes, 1)), d_recv(std::max<size_t>(block_bytes, 1) * (size_t)nr);
+    d_send.zero(s);
+    if (my_bytes) HIPCHK(hipMemcpyAsync(d_send.p, send, my_bytes, hipMemcpyHostToDevice, s));
+    all_gather_on(c, d_send.p, d_recv.p, block_bytes, s);
+    if (block_bytes) HIPCHK(hipMemcpyAsync(recv, d_recv.p, block_bytes * (size_t)nr, hipMemcpyDeviceToHost, s));
+    stream_sync_watchdog(s);
+    GatherStats& G = gather_stats();
+    G.bytes += (long long)(block_bytes * (size_t)nr); G.calls += 1;
+    G.ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+
+RGBM_EXPORT int rgbm_comm_all_gather_sizes(const int64_t* mine, int32_t n, int64_t* all /* [nranks][n] */) {
+    if (!mine || !all || n < 1) return fail(RGBM_ERR_ARG, "rgbm_comm_all_gather_sizes: bad argument");
+    return guarded([&]() { gather_host_blocks(mine, (size_t)n * 8, (size_t)n * 8, all); return RGBM_OK; });
+}
+
+RGBM_EXPORT int rgbm_comm_all_gather_bytes(const void* send, int64_t my_bytes, int64_t block_bytes, void* recv /* [nranks][block_bytes] */) {
+    if (my_bytes < 0 || block_bytes < my_bytes || !recv || (my_bytes > 0 && !send)) return fail(RGBM_ERR_ARG, "rgbm_comm_all_gather_bytes: bad argument");
+    return guarded([&]() { gather_host_blocks(send, (size_t)my_bytes, (size_t)block_bytes, recv); return RGBM_OK; });
+}
+
+// The chained repair of this rank's rows with its outputs LEFT ON THE DEVICE, all-gathered over the communicator there, and only then copied to
+// the host: out_label / out_prob = [nranks][T][max_rows] (a rank's block holds its n_rows rows of every model, padded to max_rows = the largest
+// rank's row count -- the caller exchanged the counts with rgbm_comm_all_gather_sizes).  Same labels / probabilities as rgbm_table_repair_chain.
+RGBM_EXPORT int rgbm_table_repair_chain_gather(rgbm_table* t, const rgbm_model* const* models, int32_t T, const int32_t* target_col,
+                                               const int32_t* feat_cols, const int32_t* feat_off, int64_t row_begin, int64_t n_rows, int64_t max_rows,
+                                               int32_t* out_label, double* out_prob) {
+    if (!t || !models || T < 1 || !target_col || !feat_cols || !feat_off || row_begin < 0 || n_rows < 0 || row_begin + n_rows > t->n || max_rows < n_rows || max_rows < 1 || !out_label || !out_prob)
+        return fail(RGBM_ERR_ARG, "rgbm_table_repair_chain_gather: bad argument");
+    return guarded([&]() {
+        use_device(t->device);
+        Comm& c = g_comm;
+        const int nr = std::max(1, c.nranks);
+        StreamGuard sg; hipStream_t s = sg.s;
+        const size_t blk = (size_t)T * (size_t)max_rows;
+        DevBuf<int32_t> d_lab(blk), d_lab_all(blk * (size_t)nr); DevBuf<double> d_prob(blk), d_prob_all(blk * (size_t)nr);
+        d_lab.zero(s); d_prob.zero(s);
+        if (n_rows > 0)
+            chain_device(const_cast<rgbm_model* const*>(models), T, target_col, feat_cols, feat_off, nullptr, nullptr, t->codes.p, t->n, row_begin, n_rows,
+                         t->device, s, nullptr, nullptr, d_lab.p, d_prob.p, (long long)max_rows);
+        const auto t0 = std::chrono::steady_clock::now();
+        all_gather_on(c, d_lab.p, d_lab_all.p, blk * sizeof(int32_t), s);
+        all_gather_on(c, d_prob.p, d_prob_all.p, blk * sizeof(double), s);
+        HIPCHK(hipMemcpyAsync(out_label, d_lab_all.p, blk * (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out_prob, d_prob_all.p, blk * (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        stream_sync_watchdog(s);
+        GatherStats& G = gather_stats();
+        G.bytes += (long long)(blk * (size_t)nr * 12); G.calls += 2;
+        G.ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        return RGBM_OK;
+    });
+}
+
+RGBM_EXPORT int rgbm_comm_gather_stats(int64_t* out /* [3] = {bytes received by all-gathers of this process, nanoseconds spent in them, collectives} */) {
+    if (!out) return fail(RGBM_ERR_ARG, "rgbm_comm_gather_stats: bad argument");
+    GatherStats& G = gather_stats();
+    out[0] = G.bytes.load(); out[1] = G.ns.load(); out[2] = G.calls.load();
     return RGBM_OK;
 }
 

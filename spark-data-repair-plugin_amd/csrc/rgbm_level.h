@@ -65,6 +65,9 @@ constexpr int MT_THREADS_ACC2 = 768;
 #ifndef MT_CONSUMERS_N
 #define MT_CONSUMERS_N 4
 #endif
+#ifndef MT_SCALAR_TILE
+#define MT_SCALAR_TILE 0      // experiment (round 6): the wave index of k_level_mt through readfirstlane, whole tiles without clamps -- see profiles/EXPERIMENTS.md
+#endif
 constexpr int MT_LOCK_EVERY = 4;              // lock-step: tile rounds between two looks at the row block's progress words
 constexpr int MT_CONSUMERS = MT_CONSUMERS_N;              // wave-specialised pass: consumer waves of a workgroup (one per SIMD)         // workgroup of a two-chunk pass: 12 waves with 168 VGPRs each (two records per row stay in registers), a third less ring
 
@@ -362,7 +365,14 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     const int grp = bslot % c.mt_G, rb = (bslot / c.mt_G) * 8 + xl;
     const int k0 = grp * c.mt_T;
     const int nk = (c.K - k0) < c.mt_T ? (c.K - k0) : c.mt_T;
+    // (the wave index through readfirstlane: a wave's tile numbers and everything derived from them -- row bases, the tile-is-full test -- are then
+    // SCALAR: address arithmetic on the scalar unit, a per-lane 32-bit offset in the loads; as a VGPR value it cost the row loop ~40 64-bit VALU
+    // operations per wave tile)
+#if MT_SCALAR_TILE
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+#else
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
     const int ch = ACC2 ? 0 : c.mt_ch;
     constexpr bool route = ROUTE;
     const ChunkMeta cm = cmeta[ch];
@@ -688,9 +698,21 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     // ---- the three stages of a step = (wave tile of 256 rows: 4 consecutive rows per lane, class tree kk of the workgroup)
     // records of a wave tile (+ the bag bits of its rows); rows past the end of the table read the last row and are masked out later
     auto load_rec = [&](long long wt, uint4 (&ra)[4], uint4 (&r1)[4], uint32_t& bagmask) __attribute__((always_inline)) {
-        const long long row0 = wt * MT_WT_ROWS + lane * 4;
+        const long long tile0 = wt * MT_WT_ROWS;                 // scalar
         bagmask = 0xFu;
         if (BAG) bagmask = 0u;
+        if (MT_SCALAR_TILE && tile0 + MT_WT_ROWS <= N) {         // (uniform) a whole tile: scalar base + the lane's constant offset, no clamps
+            const uint4* rp = rec_acc + tile0; const uint4* rp1 = rec + N + tile0; const uint8_t* bp = inbag + tile0;
+            const unsigned lo = (unsigned)lane * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = rp[lo + j];
+                if (ACC2 || (route && NCHR == 2)) r1[j] = rp1[lo + j]; else r1[j] = make_uint4(0, 0, 0, 0);
+                if (BAG) bagmask |= (bp[lo + j] ? 1u : 0u) << j;
+            }
+            return;
+        }
+        const long long row0 = tile0 + lane * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             long long rr = row0 + j; if (rr >= N) rr = N - 1;
@@ -704,13 +726,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     // wave tiles (NS, NG), so the loads need neither a bounds check nor an alignment case: straight-line code, exact vmcnt bookkeeping.
     auto load_tree = [&](long long wt, int kk, uint32_t& n4, float4& g0, float4& g1) __attribute__((always_inline)) {
         // (the workgroup's class trees are not in class order when some of them are sparse: the class comes from the tree's packed entry)
-        const long long row0 = wt * MT_WT_ROWS + lane * 4, kq = SPARSE ? (long long)(tree_entry(kk).y >> 16) : (long long)(k0 + kk);
-        n4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(node + kq * NS + row0));
-        const float2* gp = gh + kq * NG + row0;
+        const long long tile0 = wt * MT_WT_ROWS, kq = SPARSE ? (long long)(tree_entry(kk).y >> 16) : (long long)(k0 + kk);      // scalar
+        const unsigned lo = (unsigned)lane * 4u;
+        n4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(node + kq * NS + tile0 + lo));
+        const float2* gp = gh + kq * NG + tile0 + lo;
         const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp)), b2 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp + 2));
         g0 = make_float4(a.x, a.y, a.z, a.w); g1 = make_float4(b2.x, b2.y, b2.z, b2.w);
     };
     auto row_mask = [&](long long wt) __attribute__((always_inline)) -> uint32_t {
+        if (MT_SCALAR_TILE && (wt + 1) * MT_WT_ROWS <= N) return 0xFu;             // (uniform) a whole tile
         const long long row0 = wt * MT_WT_ROWS + lane * 4;
         uint32_t m = 0u;
 #pragma unroll

@@ -99,6 +99,7 @@ EXPORTED_SYMBOLS = [
     "rgbm_model_save", "rgbm_model_load", "rgbm_model_free", "rgbm_model_info", "rgbm_model_importance",
     "rgbm_comm_unique_id", "rgbm_comm_init", "rgbm_comm_finalize", "rgbm_comm_info", "rgbm_comm_count",
     "rgbm_local_group_create", "rgbm_local_group_free", "rgbm_comm_init_local",
+    "rgbm_comm_all_gather_sizes", "rgbm_comm_all_gather_bytes", "rgbm_table_repair_chain_gather", "rgbm_comm_gather_stats",
     "rgbm_fusion_create", "rgbm_fusion_join", "rgbm_fusion_leave", "rgbm_fusion_info", "rgbm_fusion_free",
     "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
     "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict", "rgbm_table_shape",
@@ -190,6 +191,32 @@ def comm_count():
     n = C.c_int32(0)
     _check(lib().rgbm_comm_count(C.byref(n)), "rgbm_comm_count")
     return int(n.value)
+
+
+def comm_all_gather_sizes(values):
+    """Every rank of the calling thread's communicator contributes the int64 vector `values`; returns [nranks][len(values)]."""
+    v = np.ascontiguousarray(values, np.int64).reshape(-1)
+    out = np.zeros((max(1, comm_info()["nranks"]), v.size), np.int64)
+    _check(lib().rgbm_comm_all_gather_sizes(_p(v, C.c_int64), C.c_int32(v.size), _p(out, C.c_int64)), "rgbm_comm_all_gather_sizes")
+    return out
+
+
+def comm_all_gather_bytes(payload):
+    """Variable-size all-gather of byte strings over the calling thread's communicator (device buffers + ncclAllGather inside the library:
+    include/rgbm.h "C1 / C2"): returns the list of every rank's payload, in rank order."""
+    mine = np.frombuffer(bytes(payload), np.uint8) if not isinstance(payload, np.ndarray) else np.ascontiguousarray(payload).view(np.uint8).reshape(-1)
+    sizes = comm_all_gather_sizes([mine.size])[:, 0]
+    block = int(max(int(sizes.max()), 1))
+    recv = np.zeros((len(sizes), block), np.uint8)
+    _check(lib().rgbm_comm_all_gather_bytes(_p(mine, C.c_uint8) if mine.size else None, C.c_int64(mine.size), C.c_int64(block), _p(recv, C.c_uint8)),
+           "rgbm_comm_all_gather_bytes")
+    return [recv[r, :int(sizes[r])].copy() for r in range(len(sizes))]
+
+
+def comm_gather_stats():
+    a = np.zeros(3, np.int64)
+    _check(lib().rgbm_comm_gather_stats(_p(a, C.c_int64)), "rgbm_comm_gather_stats")
+    return dict(bytes=int(a[0]), seconds=float(a[1]) * 1e-9, collectives=int(a[2]))
 
 
 class FusionGroup:
@@ -609,6 +636,26 @@ class Table:
                                              C.c_int64(row_begin), C.c_int64(n_rows), _p(lab, C.c_int32), _p(prob, C.c_double)),
                "rgbm_table_repair_chain")
         return lab, prob
+
+    def repair_chain_gather(self, models, target_col, feat_cols, row_begin=0, n_rows=None):
+        """The chained repair of THIS rank's rows, the outputs all-gathered over the calling thread's communicator on the device (C2):
+        returns (labels [T][sum of the ranks' rows] in rank order, probs likewise, first row of this rank, rows of every rank)."""
+        T = len(models)
+        n_rows = self.n - row_begin if n_rows is None else n_rows
+        counts = comm_all_gather_sizes([n_rows])[:, 0]
+        mx = int(max(int(counts.max()), 1))
+        nr = len(counts)
+        arr, fc, fo, _, _ = _chain_args(models, feat_cols, None)
+        tc = _i32(target_col)
+        lab = np.zeros((nr, T, mx), np.int32)
+        prob = np.zeros((nr, T, mx), np.float64)
+        _check(lib().rgbm_table_repair_chain_gather(self.h, arr, C.c_int32(T), _p(tc, C.c_int32), _p(fc, C.c_int32), _p(fo, C.c_int32),
+                                                    C.c_int64(row_begin), C.c_int64(n_rows), C.c_int64(mx), _p(lab, C.c_int32), _p(prob, C.c_double)),
+               "rgbm_table_repair_chain_gather")
+        labels = np.concatenate([lab[r, :, :int(counts[r])] for r in range(nr)], axis=1)
+        probs = np.concatenate([prob[r, :, :int(counts[r])] for r in range(nr)], axis=1)
+        me = comm_info()["rank"]
+        return labels, probs, int(counts[:me].sum()), [int(x) for x in counts]
 
     def read_column(self, col):
         out = np.zeros(self.n, np.int32)

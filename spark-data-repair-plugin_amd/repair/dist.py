@@ -17,7 +17,111 @@ expensive targets to ROW-sharded training over all ranks (every rank trains the 
 shard; librepairgbm all-reduces integer histograms over RCCL, see include/rgbm.h) and keeps target
 sharding for the cheap ones.
 """
+import threading
+
 import numpy as np
+
+_tls = threading.local()
+
+
+class ThreadWorld:
+    """The ranks of a job as host THREADS of one process: `with world.rank(r): run_job(...)` on thread r.  Every function of this module
+    then sees a world of `n` ranks, and the exchanges run through this object (or, for the data path, through the thread's librepairgbm
+    communicator -- _native.LocalGroup -- when it spans the world).  Exists so that the multi-rank job logic (engine.run_job: target / row
+    sharding, fusion group, C1 / C2) can be driven on the ONE GPU the test box has; torch.distributed is process-global and cannot."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        self._bar = threading.Barrier(self.n)
+        self._slots = [None] * self.n
+
+    class _Rank:
+        def __init__(self, w, r):
+            self.w, self.r = w, r
+
+        def __enter__(self):
+            _tls.world = (self.w, self.r)
+            return self
+
+        def __exit__(self, *exc):
+            _tls.world = None
+            if exc and exc[0] is not None:
+                self.w._bar.abort()          # a failing rank must not leave its peers in a barrier
+            return False
+
+    def rank(self, r):
+        return ThreadWorld._Rank(self, int(r))
+
+    def all_gather(self, r, obj):
+        self._slots[r] = obj
+        self._bar.wait(timeout=600)
+        out = list(self._slots)
+        self._bar.wait(timeout=600)
+        return out
+
+
+def _thread_world():
+    return getattr(_tls, "world", None)
+
+
+def _lib_comm_spans_world():
+    """The calling thread's librepairgbm communicator (RCCL, or the thread group of the tests) covers exactly the ranks of the job: the data
+    path of C1 / C2 then runs on it -- device buffers, ncclAllGather over xGMI -- and torch's process group only carries control traffic."""
+    rank, ws = world()
+    if ws <= 1:
+        return False
+    try:
+        from repair import _native
+        ci = _native.comm_info()
+    except Exception:  # noqa: BLE001 - no library (CPU tests with the oracle engine)
+        return False
+    return ci["kind"] in (1, 2) and ci["nranks"] == ws and ci["rank"] == rank
+
+
+GATHER = {"via": "none", "bytes": 0, "seconds": 0.0, "collectives": 0}     # what bench.py prints as config.rccl.gather
+
+
+def _note_gather(via):
+    GATHER["via"] = via
+    if via.startswith("librepairgbm"):
+        try:
+            from repair import _native
+            st = _native.comm_gather_stats()
+            GATHER.update(bytes=st["bytes"], seconds=st["seconds"], collectives=st["collectives"])
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def _all_gather_bytes(payload):
+    """Variable-size all-gather of one uint8 array per rank -> list in rank order.  The one primitive under C1 (model blobs) and C2 (repaired
+    cells): on the library's communicator when it spans the world, else through the thread world / torch's process group."""
+    payload = np.ascontiguousarray(payload).view(np.uint8).reshape(-1)
+    tw = _thread_world()
+    if _lib_comm_spans_world():
+        from repair import _native
+        out = _native.comm_all_gather_bytes(payload)
+        _note_gather("librepairgbm communicator (device buffers, all-gather)")
+        return out
+    if tw is not None:
+        return tw[0].all_gather(tw[1], payload.copy())
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return [payload]
+    import torch
+    dev = _tensor_device()
+    ws = d.get_world_size()
+    n = torch.tensor([payload.size], dtype=torch.int64, device=dev)
+    ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    d.all_gather(ns, n)
+    counts = [int(x.item()) for x in ns]
+    mx = max(max(counts), 1)
+    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    if payload.size:
+        buf[:payload.size] = torch.from_numpy(payload.copy()).to(dev)
+    bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(ws)]
+    d.all_gather(bufs, buf)
+    _note_gather("torch.distributed (%s)" % d.get_backend())
+    return [bufs[r].cpu().numpy()[:counts[r]].copy() for r in range(ws)]
 
 
 def _dist():
@@ -31,6 +135,9 @@ def _dist():
 
 
 def world():
+    tw = _thread_world()
+    if tw is not None:
+        return (tw[1], tw[0].n)
     d = _dist()
     return (d.get_rank(), d.get_world_size()) if d else (0, 1)
 
@@ -125,7 +232,7 @@ def init_row_comm(device_id):
     falls back to plain target sharding.  ROW_COMM records what happened (ranks seen, seconds, fell back and why)."""
     import time
     d = _dist()
-    if d is None or d.get_world_size() == 1 or d.get_backend() != "nccl":
+    if d is None or d.get_world_size() == 1:
         return False
     import torch
     from repair import _native
@@ -170,34 +277,18 @@ def _tensor_device():
 
 
 def exchange_blobs(local):
-    """All-gather a dict {key(int) -> bytes} so that every rank ends up with the union."""
-    d = _dist()
-    if d is None or d.get_world_size() == 1:
+    """All-gather a dict {key(int) -> bytes} so that every rank ends up with the union (C1: the serialised models)."""
+    if world()[1] == 1:
         return dict(local)
-    import torch
-    dev = _tensor_device()
-    ws = d.get_world_size()
     keys = sorted(local)
-    # header: number of blobs, then (key, length) pairs
+    # header: number of blobs, then (key, length) pairs; then the blobs
     head = np.array([len(keys)] + [v for k in keys for v in (k, len(local[k]))], np.int64)
-    n_head = torch.tensor([head.size], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
-    d.all_gather(sizes, n_head)
-    payload = np.concatenate([head.view(np.uint8)] + [np.frombuffer(local[k], np.uint8) for k in keys]) if keys else head.view(np.uint8)
-    n_pay = torch.tensor([payload.size], dtype=torch.int64, device=dev)
-    pays = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
-    d.all_gather(pays, n_pay)
-    mx = int(max(int(p.item()) for p in pays))
-    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
-    buf[:payload.size] = torch.from_numpy(payload.copy()).to(dev)
-    bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(ws)]
-    d.all_gather(bufs, buf)
+    payload = np.concatenate([np.array([head.size], np.int64).view(np.uint8), head.view(np.uint8)] + [np.frombuffer(local[k], np.uint8) for k in keys])
     out = {}
-    for r in range(ws):
-        raw = bufs[r].cpu().numpy()
-        nh = int(sizes[r].item())
-        h = raw[:nh * 8].view(np.int64)
-        off = nh * 8
+    for raw in _all_gather_bytes(payload):
+        nh = int(raw[:8].view(np.int64)[0])
+        h = raw[8:8 + nh * 8].view(np.int64)
+        off = 8 + nh * 8
         for i in range(int(h[0])):
             k, ln = int(h[1 + 2 * i]), int(h[2 + 2 * i])
             out[k] = raw[off:off + ln].tobytes()
@@ -207,56 +298,32 @@ def exchange_blobs(local):
 
 def gather_rows(local, n_rows_total):
     """All-gather row shards: local [T][rows_of_rank] -> [T][n_rows_total] (shard order = rank order)."""
-    d = _dist()
-    if d is None or d.get_world_size() == 1:
+    if world()[1] == 1:
         return np.asarray(local)
-    import torch
-    dev = _tensor_device()
-    ws, rank = d.get_world_size(), d.get_rank()
-    local = np.ascontiguousarray(local)
-    T = local.shape[0]
-    mx = max(shard_rows(n_rows_total, ws, r)[1] for r in range(ws))
-    pad = np.zeros((T, mx), local.dtype)
-    pad[:, :local.shape[1]] = local
-    t = torch.from_numpy(pad).to(dev)
-    outs = [torch.zeros_like(t) for _ in range(ws)]
-    d.all_gather(outs, t)
-    res = np.zeros((T, n_rows_total), local.dtype)
-    for r in range(ws):
-        b, c = shard_rows(n_rows_total, ws, r)
-        res[:, b:b + c] = outs[r].cpu().numpy()[:, :c]
+    res, _ = gather_rows_var(local)
+    assert res.shape[1] == n_rows_total, (res.shape, n_rows_total)
     return res
 
 
 def gather_rows_var(local):
     """All-gather row shards whose sizes only the owning rank knows (every rank repairs the dirty rows of ITS row shard):
     local [T][rows_of_rank] -> ([T][sum of the ranks' rows] in rank order, first row of this rank)."""
-    d = _dist()
     local = np.ascontiguousarray(local)
-    if d is None or d.get_world_size() == 1:
+    rank, ws = world()
+    if ws == 1:
         return local, 0
-    import torch
-    dev = _tensor_device()
-    ws, rank = d.get_world_size(), d.get_rank()
     T = local.shape[0]
-    n = torch.tensor([local.shape[1]], dtype=torch.int64, device=dev)
-    ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
-    d.all_gather(ns, n)
-    counts = [int(x.item()) for x in ns]
-    mx = max(max(counts), 1)
-    pad = np.zeros((T, mx), local.dtype)
-    pad[:, :local.shape[1]] = local
-    t = torch.from_numpy(pad).to(dev)
-    outs = [torch.zeros_like(t) for _ in range(ws)]
-    d.all_gather(outs, t)
-    res = np.concatenate([outs[r].cpu().numpy()[:, :counts[r]] for r in range(ws)], axis=1)
-    return res, int(sum(counts[:rank]))
+    parts = [p.view(local.dtype).reshape(T, -1) if p.size else np.zeros((T, 0), local.dtype) for p in _all_gather_bytes(local)]
+    return np.concatenate(parts, axis=1), int(sum(p.shape[1] for p in parts[:rank]))
 
 
 def sum_arrays(a):
     """Element-wise sum of an integer / float array over the ranks (label counts of row shards)."""
-    d = _dist()
     a = np.ascontiguousarray(a)
+    tw = _thread_world()
+    if tw is not None:
+        return np.sum(np.stack(tw[0].all_gather(tw[1], a)), axis=0).astype(a.dtype)
+    d = _dist()
     if d is None or d.get_world_size() == 1:
         return a
     import torch
@@ -266,12 +333,19 @@ def sum_arrays(a):
 
 
 def barrier():
+    tw = _thread_world()
+    if tw is not None:
+        tw[0].all_gather(tw[1], None)
+        return
     d = _dist()
     if d is not None:
         d.barrier()
 
 
 def max_over_ranks(x):
+    tw = _thread_world()
+    if tw is not None:
+        return float(max(tw[0].all_gather(tw[1], float(x))))
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return float(x)
@@ -287,6 +361,9 @@ def min_over_ranks(x):
 
 
 def sum_over_ranks(x):
+    tw = _thread_world()
+    if tw is not None:
+        return float(sum(tw[0].all_gather(tw[1], float(x))))
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return float(x)

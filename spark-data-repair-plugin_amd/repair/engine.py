@@ -79,6 +79,12 @@ class HipEngine:
     def repair_chain(self, table, models, targets, feats, row_begin, n_rows):
         return table.repair_chain(models, targets, feats, row_begin=row_begin, n_rows=n_rows)
 
+    def repair_chain_gather(self, table, models, targets, feats, row_begin, n_rows):
+        """C2 on device buffers: the chain over this rank's rows, labels / probabilities all-gathered over the rank's communicator before
+        they leave the device (include/rgbm.h rgbm_table_repair_chain_gather) -> (labels, probs of ALL ranks' rows in rank order, first row of this rank)."""
+        lab, prob, row0, _ = table.repair_chain_gather(models, targets, feats, row_begin=row_begin, n_rows=n_rows)
+        return lab, prob, row0
+
 
 def model_params(n_classes, base, continuous=False):
     """objective pick of the reference (train.py:97-100): regression for continuous targets, else binary / multiclass."""
@@ -312,26 +318,42 @@ def run_job(engine, train_table, dirty_table, n_codes, targets, label_counts, ba
     t_xchg = time.perf_counter() - t0
     # data-parallel chained inference on this rank's row shard
     t0 = time.perf_counter()
-    D = dirty_table.n
+    # (a rank of a shard-only job whose shard holds no dirty row passes dirty_table = None: it repairs nothing and still takes part in the gathers)
+    D = dirty_table.n if dirty_table is not None else 0
     b, c = (0, D) if dirty_is_shard else dist.shard_rows(D, ws, rank)
     feats_l = [[cc for cc in range(n_cols) if cc != t] for t in targets]
-    if y_values:
-        lab, prob, val = chained_repair(engine, dirty_table, models, targets, feats_l, b, c, y_values, integral)
-    else:
-        lab, prob = engine.repair_chain(dirty_table, models, targets, feats_l, b, c)
-        val = None
-    t_infer = time.perf_counter() - t0
-    # C2: all-gather of the repaired cells
-    t0 = time.perf_counter()
     row0 = 0
-    if dirty_is_shard:
-        labels, row0 = dist.gather_rows_var(lab)
-        probs = dist.gather_rows_var(prob)[0] if prob is not None else None
-        values = dist.gather_rows_var(val)[0] if val is not None else None
+    # C2 = the union of the ranks' repaired cells (the UDF outputs, model.py:1142).  When the rank's librepairgbm communicator spans the
+    # job (RCCL; the thread group of the tests) the chain's outputs stay on the device, are all-gathered there (ncclAllGather over xGMI on
+    # the ONE communicator the rank holds) and leave it once; otherwise they are gathered from the host through the process group.
+    if not y_values and ws > 1 and hasattr(engine, "repair_chain_gather") and dist._lib_comm_spans_world():
+        labels, probs, row0 = engine.repair_chain_gather(dirty_table if dirty_table is not None else row_table, models, targets, feats_l, b, c)
+        values = None
+        dist._note_gather("librepairgbm communicator (device buffers, all-gather)")
+        t_infer = time.perf_counter() - t0
+        t_gather = 0.0           # (inside the call: config.rccl.gather has its seconds)
+        if not dirty_is_shard:
+            row0 = 0
     else:
-        labels = dist.gather_rows(lab, D)
-        probs = dist.gather_rows(prob, D) if prob is not None else None
-        values = dist.gather_rows(val, D) if val is not None else None
-    t_gather = time.perf_counter() - t0
+        if D == 0:
+            lab, prob = np.zeros((len(targets), 0), np.int32), np.zeros((len(targets), 0), np.float64)
+            val = np.zeros((len(targets), 0), np.float64) if y_values else None
+        elif y_values:
+            lab, prob, val = chained_repair(engine, dirty_table, models, targets, feats_l, b, c, y_values, integral)
+        else:
+            lab, prob = engine.repair_chain(dirty_table, models, targets, feats_l, b, c)
+            val = None
+        t_infer = time.perf_counter() - t0
+        # C2: all-gather of the repaired cells
+        t0 = time.perf_counter()
+        if dirty_is_shard:
+            labels, row0 = dist.gather_rows_var(lab)
+            probs = dist.gather_rows_var(prob)[0] if prob is not None else None
+            values = dist.gather_rows_var(val)[0] if val is not None else None
+        else:
+            labels = dist.gather_rows(lab, D)
+            probs = dist.gather_rows(prob, D) if prob is not None else None
+            values = dist.gather_rows(val, D) if val is not None else None
+        t_gather = time.perf_counter() - t0
     return dict(labels=labels, probs=probs, values=values, models=all_blobs, stats=stats, my_targets=mine, row_sharded_targets=[t for t, _ in big], fusion=fusion_stats,
                 dirty_row0=row0, times=dict(train=t_train, exchange=t_xchg, infer=t_infer, gather=t_gather))

@@ -43,12 +43,18 @@ def main():
     ap.add_argument("--cols", type=int, default=16)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--iters-for", default="", help="per-target iteration counts that override --iters, e.g. 0:300,11:300 (the cheap targets pinned end to end)")
+    ap.add_argument("--parallel", action="store_true", help="draw the table with make_table_parallel (the chunked generator bench.py uses for --config 100m32: "
+                                                            "the WHOLE-table pin of configs[3] is made with --rows 100000000 --cols 32 --seed 43 --parallel --out bench_whole_digests.json)")
     ap.add_argument("--out", default=OUT, help="bench_job_digests.json (10M x 16) or bench_shard_digests.json (--rows 12500000 --cols 32 --seed 43)")
     a = ap.parse_args()
     OUT_ = a.out if os.path.isabs(a.out) else os.path.join(os.path.dirname(os.path.abspath(__file__)), a.out)
-    dirty, clean, cards = make_table(a.rows, a.cols, seed=a.seed)
-    del clean
-    doc = {"table": {"rows": a.rows, "cols": a.cols, "seed": a.seed, "null_ratio": 0.01}, "iters": a.iters,
+    if a.parallel:
+        from repair.synth import make_table_parallel
+        dirty, _, cards = make_table_parallel(a.rows, a.cols, seed=a.seed, threads=max(1, a.threads))
+    else:
+        dirty, clean, cards = make_table(a.rows, a.cols, seed=a.seed)
+        del clean
+    doc = {"table": dict({"rows": a.rows, "cols": a.cols, "seed": a.seed, "null_ratio": 0.01}, **({"generator": "make_table_parallel"} if a.parallel else {})), "iters": a.iters,
            "numerics_version": NUMERICS_VERSION, "generator": "tests/golden/make_bench_job_golden.py", "targets": {}}
     if os.path.exists(OUT_):
         old = json.load(open(OUT_))
@@ -64,7 +70,11 @@ def main():
         n_it = iters_for.get(t, a.iters)      # (a target's own count: the test trains it for len(digests) iterations)
         kw = dict(objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=n_it)
         t0 = time.time()
-        blob = O.train(np.ascontiguousarray(dirty[feats][:, rows]), cards[feats], dirty[t][rows], K, class_weight=cw, **kw).save()
+        X = np.empty((len(feats), int(rows.sum())), np.int32)          # (column by column: a fancy-indexed copy of a 100M-row table would hold it twice)
+        for j, f in enumerate(feats):
+            X[j] = dirty[f][rows]
+        blob = O.train(X, cards[feats], dirty[t][rows], K, class_weight=cw, **kw).save()
+        del X
         doc["targets"]["c%d" % t] = {"K": K, "train_rows": int(rows.sum()), "digests": iteration_digests(blob),
                                       "oracle_seconds": round(time.time() - t0, 1), "threads": a.threads}
         with open(OUT_, "w") as f:

@@ -71,12 +71,14 @@ def test_bench_job_60_iterations_with_six_targets_in_flight_match_the_oracle_dig
     from tests.numerics_bound import iteration_digests
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_job_digests.json")))
     assert gold["numerics_version"] == N.lib().rgbm_version(), "regenerate tests/golden/bench_job_digests.json (tests/golden/make_bench_job_golden.py)"
-    iters = int(gold["iters"])
     dirty, clean, cards = make_table(gold["table"]["rows"], gold["table"]["cols"], seed=gold["table"]["seed"])
     del clean
     tab = N.Table(dirty, cards)
 
     def fit(target):
+        # a target trains for as many iterations as the golden file holds for it: 60 for most, ALL 300 of the reference's job for the cheap
+        # ones (c0, c11, c1, c12 -- round 6: four models of the benchmarked job pinned end to end)
+        iters = len(gold["targets"]["c%d" % target]["digests"]) if "c%d" % target in gold["targets"] else int(gold["iters"])
         feats = [c for c in range(dirty.shape[0]) if c != target]
         K = int(cards[target])
         return tab.train(target, feats, class_weight=balanced_weights(dirty[target], K), objective=0 if K == 2 else 1, num_class=max(K, 2), n_estimators=iters).save()
@@ -89,9 +91,9 @@ def test_bench_job_60_iterations_with_six_targets_in_flight_match_the_oracle_dig
             if g is None:
                 continue
             got = iteration_digests(blobs[t])
-            assert len(got) == len(g["digests"]) == iters
+            assert len(got) == len(g["digests"]) >= int(gold["iters"])
             bad = [i for i, (a, b) in enumerate(zip(got, g["digests"])) if a != b]
-            assert not bad, "target c%d (K=%d): iterations %s differ from the oracle (first at %d)" % (t, g["K"], bad[:8], bad[0])
+            assert not bad, "target c%d (K=%d): iterations %s of %d differ from the oracle (first at %d)" % (t, g["K"], bad[:8], len(got), bad[0])
 
 
 @pytest.mark.timeout(1800)
@@ -126,3 +128,38 @@ def test_config3_shard_30_iterations_match_the_oracle_digests():
         assert len(got) == len(g["digests"]) == iters
         bad = [i for i, (a, b) in enumerate(zip(got, g["digests"])) if a != b]
         assert not bad, "12.5M x 32 shard, target c%d (K=%d): iterations %s differ from the oracle (first at %d)" % (t, g["K"], bad[:8], bad[0])
+
+
+@pytest.mark.timeout(1800)
+def test_config3_whole_table_100m_x_32_matches_the_oracle_digests():
+    """VERDICT r5 (missing 3): the N = 1 base of the north-star scaling curve -- the WHOLE 100M x 32 table of BASELINE configs[3] on one GPU --
+    was self-consistent only (models_md5); the suite pinned a 12.5M-row shard.  tests/golden/bench_whole_digests.json (make_bench_job_golden.py
+    --rows 100000000 --cols 32 --seed 43 --parallel --targets 0,1 --iters 5: the table bench.py --config 100m32 draws, the binary target c0 and
+    the K = 3 target c1) holds the oracle's digest of every iteration: the first oracle pin with byte offsets above 2^32 (3.2 GB of bin records
+    per chunk, K x N node ids and (g, h)), on the real 100M-row fixed-point grid, through the two-chunk wave-specialised level pass."""
+    import json
+    from concurrent.futures import ThreadPoolExecutor
+    from repair import _native as N
+    from repair.synth import make_table_parallel
+    from tests.numerics_bound import iteration_digests
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_whole_digests.json")
+    gold = json.load(open(path))
+    assert gold["numerics_version"] == N.lib().rgbm_version(), "regenerate tests/golden/bench_whole_digests.json (tests/golden/make_bench_job_golden.py)"
+    assert gold["table"].get("generator") == "make_table_parallel"
+    dirty, _, cards = make_table_parallel(gold["table"]["rows"], gold["table"]["cols"], seed=gold["table"]["seed"], threads=min(32, os.cpu_count() or 1))
+    tab = N.Table(dirty, cards)
+
+    def fit(target):
+        feats = [c for c in range(dirty.shape[0]) if c != target]
+        K = int(cards[target])
+        return tab.train(target, feats, class_weight=balanced_weights(dirty[target], K), objective=0 if K == 2 else 1, num_class=max(K, 2),
+                         n_estimators=len(gold["targets"]["c%d" % target]["digests"])).save()
+
+    targets = [int(k[1:]) for k in gold["targets"]]
+    with ThreadPoolExecutor(len(targets)) as ex:
+        blobs = dict(zip(targets, ex.map(fit, targets)))
+    for t in targets:
+        g = gold["targets"]["c%d" % t]
+        got = iteration_digests(blobs[t])
+        bad = [i for i, (a, b) in enumerate(zip(got, g["digests"])) if a != b]
+        assert len(got) == len(g["digests"]) and not bad, "100M x 32, target c%d (K=%d): iterations %s differ from the oracle" % (t, g["K"], bad[:8])
