@@ -244,6 +244,10 @@ def main():
     ap.add_argument("--train-rows", type=int, default=0,
                     help="train every model on a seeded sample of this many rows (the reference's DEFAULT behaviour is "
                          "model.max_training_row_num = 10000, model.py:755-766); 0 = all rows, which is what BASELINE's metric is quoted on")
+    ap.add_argument("--dedup", action="store_true",
+                    help="VARIANT of the workload (never the headline): train on the DISTINCT rows of the table with integer multiplicities "
+                         "(repair.pipeline.distinct_rows + rgbm_table_set_row_multiplicity): byte-identical models -- models_md5 must equal the row-for-row "
+                         "line's -- at the cost of the distinct rows; one rank, whole tables")
     ap.add_argument("--dump-labels", default="", help="debug: np.save the repaired labels / probabilities of the job here")
     a = ap.parse_args()
 
@@ -330,10 +334,21 @@ def main():
         label_counts = {t: np.bincount(train_src[t][train_src[t] >= 0], minlength=int(cards[t])) for t in targets}
         if shard_only:
             label_counts = {t: rdist.sum_arrays(label_counts[t].astype(np.int64)) for t in targets}      # GLOBAL counts (class weights, costs)
+        dedup = None
+        if a.dedup:
+            if world > 1 or shard_only:
+                raise SystemExit("bench.py --dedup: one rank, whole tables")
+            from repair.pipeline import distinct_rows
+            t0 = time.perf_counter()
+            dist_rows, mult, _ = distinct_rows(train_src, cards)
+            dedup = dict(rows=int(train_src.shape[1]), distinct_rows=int(dist_rows.shape[1]), largest_multiplicity=int(mult.max()), host_dedup_sec=time.perf_counter() - t0)
+            train_src = dist_rows
         eng.upload(np.ascontiguousarray(train_src[:, :4096]), cards)   # creates the library's pinned staging ring (one-time hipHostMalloc, ~0.1 s) outside the upload figure
         torch.cuda.synchronize()
         t_up = time.perf_counter()
         train_tab = eng.upload(train_src, cards)
+        if dedup is not None:
+            train_tab.set_row_multiplicity(mult)
         dirty_tab = eng.upload(dirty_rows, cards)
         torch.cuda.synchronize()
         t_up = time.perf_counter() - t_up
@@ -391,7 +406,7 @@ def main():
                         return None
                     row_tab = None
                     note = "disabled: the row-sharded warm-up model differed from the single-device one (or failed)"
-        return dict(row_base=row_base, cards=cards, null_truth=null_truth, t_gen=t_gen, dirty_pos=dirty_pos, dirty_rows=dirty_rows, n_cells=n_cells,
+        return dict(dedup=dedup, row_base=row_base, cards=cards, null_truth=null_truth, t_gen=t_gen, dirty_pos=dirty_pos, dirty_rows=dirty_rows, n_cells=n_cells,
                     n_dirty_rows=n_dirty_rows, label_counts=label_counts, train_tab=train_tab, dirty_tab=dirty_tab, t_up=t_up, upload_bytes=upload_bytes,
                     row_tab=row_tab, note=note)
 
@@ -478,9 +493,10 @@ def main():
             idx = np.searchsorted(dirty_pos, pos)
             fixed += int((labels[i][idx] == truth).sum())
         achieved = hist_bytes_all / max(hist_ms_all, 1e-9) * 1e-6
-        traffic = _load_traffic(a.config, world, rows, cols, a.train_rows, a.force_row_sharding)
-        st0 = res_roof["stats"][0] if res_roof["stats"] else {}
-        atoms = {"root": int(st0.get("root_atomics_per_row", 0)), "level": int(st0.get("level_atomics_per_row", 0))}
+        traffic = _load_traffic(a.config, world, rows, cols, a.train_rows, a.force_row_sharding or a.dedup)
+        # LDS atomics the launches of each class issued, target by target (the joint-bin groups of a root pass depend on the target's feature set)
+        atom_ops = {"root": sum(float(s_.get("root_rows", 0)) * float(s_.get("root_atomics_per_row", 0)) for s_ in res_roof["stats"]),
+                    "level": sum(float(s_.get("hist_rows", 0) - s_.get("root_rows", 0)) * float(s_.get("level_atomics_per_row", 0)) for s_ in res_roof["stats"])}
         # the two kernel classes of the histogram build, each with its own algorithmic bytes, launch time and (from the committed PMC
         # profile of the same target set) HBM-side bytes per launch
         classes = {}
@@ -496,10 +512,9 @@ def main():
                     c["frac_needed"] = needed_level_rows * (cols - 1 + 8) / max(ms, 1e-9) * 1e-6 / HBM_PEAK_GBS
             else:
                 c["bound"] = "lds-atomic: 14 ds_add_u64 per row (7 joint-bin groups x (g, h)) at ~12.8 cycles per wave instruction; algorithmic bytes follow SURVEY 8(d) (F + 8 per row), the pass's HBM traffic is about half of them"
-            if atoms[name]:     # the LDS-atomic floor of this class: (accumulated rows x atomics per row / 64 lanes) wave instructions at the conflict-free rate
-                pairs = nbytes / (cols - 1 + 8) / nl
-                c["atomics_per_row"] = atoms[name]
-                c["atomic_floor_us"] = pairs * atoms[name] / 64.0 * LDS_ATOMIC_CYCLES / (N_CUS * CLOCK_HZ) * 1e6
+            if atom_ops[name] > 0 and world == 1:     # the LDS-atomic floor of this class: (accumulated rows x atomics per row / 64 lanes) wave instructions at the conflict-free rate
+                c["atomics_per_row"] = atom_ops[name] / max(nbytes / (cols - 1 + 8), 1e-9)
+                c["atomic_floor_us"] = atom_ops[name] / nl / 64.0 * LDS_ATOMIC_CYCLES / (N_CUS * CLOCK_HZ) * 1e6
                 c["atomic_floor_share_of_launch"] = c["atomic_floor_us"] / max(c["avg_launch_us"], 1e-9)
             if traffic and name in traffic["classes"]:
                 tc = traffic["classes"][name]
@@ -555,6 +570,14 @@ def main():
         }
         if row_sharding_note:
             out["config"]["row_sharding"] = row_sharding_note
+        if inp.get("dedup"):
+            # a separately named workload: same table, same models (compare models_md5 with the row-for-row line), trained on its distinct rows
+            out["config"]["workload"] += "; VARIANT distinct-rows: every model trained on the %d distinct rows of the table with integer multiplicities (rgbm_table_set_row_multiplicity)" % inp["dedup"]["distinct_rows"]
+            out["config"]["variant"] = dict(inp["dedup"], name="distinct-rows", note="host dedup (numpy unique of mixed-radix row keys) is outside the timed region, like encoding and upload")
+            # the device counts accumulated rows in ORIGINAL rows (a row of multiplicity m counts m times): algorithmic bytes over launches that touch the
+            # distinct rows only would overstate the rate -- the variant is not priced against the roofline
+            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                               "note": "not priced for the distinct-rows variant: the kernels count accumulated rows in original rows; see the row-for-row line"}
         if world > 1:   # what the first multi-rank runs need to show: did RCCL really span the world, how long did it take, did the job fall back
             rc = dict(rdist.ROW_COMM)
             out["config"]["rccl"] = {"asked": rc["asked"], "ranks_seen_by_ncclCommCount": rc["ranks"], "comm_init_sec": round(rc["init_sec"], 3), "fell_back": rc["fell_back"],

@@ -157,6 +157,13 @@ int rgbm_table_train(const rgbm_table* t, int32_t target_col, const int32_t* fea
                      const double* y_value /* regression dictionary or NULL */,
                      const double* class_weight /* [n_codes[target]] or NULL */,
                      const rgbm_params* p, rgbm_model** out, rgbm_train_stats* stats);
+/* Rows with multiplicities (round 6; a VARIANT of the workload, reported apart from the row-for-row line): row i stands for mult[i] (1..255)
+ * identical rows of a larger table.  The reference has no counterpart -- its frames (python/repair/model.py:768-815) hold every row; on the
+ * categorical tables it repairs a quarter of the rows are distinct -- but the result is defined by it: every later rgbm_table_train on this
+ * table returns byte for byte the model the EXPANDED table gives (identical rows take identical paths and gradients; all sums are exact
+ * integers).  NULL clears.  Level grower only (1 <= max_depth <= 7), at most 32 features with a free byte in the last 16-feature record, no
+ * bagging, no per-row weights: a training call that cannot honour it fails with RGBM_ERR_PARAM. */
+int rgbm_table_set_row_multiplicity(rgbm_table* t, const uint8_t* mult /* [n] or NULL */);
 /* ---- many small fits in one go ------------------------------------------------------------------
  * Replaces the LOOP over fits of python/repair/train.py:158-209 (every hyper-parameter trial is `cross_val_score`: n_splits fits of
  * the same estimator on row subsets of one frame, train.py:171-172) and of python/repair/model.py:768-815 on the reference's default

@@ -875,7 +875,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     const int32_t* d_ycol = tab.codes.p + (long long)target_col * N;
     {
         int gx = (int)std::min<int64_t>((N + 255) / 256, 1024);
-        hipLaunchKernelGGL(k_count_codes, dim3(gx, F + 1), dim3(256), 0, s, tab.codes.p, (long long)N, d_ycol, d_cols.p, d_ncod.p, d_cnt_off.p, d_cnt.p);
+        hipLaunchKernelGGL(k_count_codes, dim3(gx, F + 1), dim3(256), 0, s, tab.codes.p, (long long)N, d_ycol, d_cols.p, d_ncod.p, d_cnt_off.p, d_cnt.p,
+                           tab.has_mult ? tab.mult.p : (const uint8_t*)nullptr);
     }
     // row-sharded: this table is one rank's row shard (rgbm_params.reserved bit 0 = RGBM_FLAG_ROW_SHARDED)
     if ((p.reserved & RGBM_FLAG_ROW_SHARDED) && g_comm.kind == 0) throw std::invalid_argument("row-sharded training requested but this thread has no communicator (rgbm_comm_init)");
@@ -902,8 +903,18 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     d_fmeta.upload(fmeta.data(), F, s); d_cmeta.upload(cmeta.data(), nchunk, s); d_lut_off.upload(lut_off.data(), F + 1, s);
     d_lut.upload(lut.data(), lut.size(), s); d_miss.upload(miss.data(), F, s);
     DevBuf<uint4> d_rec((size_t)nchunk * N);
+    // rows with multiplicities (rgbm_table_set_row_multiplicity): the multiplicity rides in byte 15 of the row's LAST bin record, so that chunk
+    // must leave the byte free; the level grower only (one chunk, or two chunks in one pass), no bagging (LightGBM draws per ORIGINAL row), no per-row weights
+    const bool wm = tab.has_mult;
+    const uint8_t* d_mult = wm ? tab.mult.p : (const uint8_t*)nullptr;
+    if (wm) {
+        const bool lvl = p.max_depth >= 1 && p.max_depth <= LV_MAX_DEPTH && F <= 255 && read_switches().grower != 2;
+        if (!lvl || nchunk > 2 || (F % 16) == 0 || sample_weight_host || (p.bagging_freq > 0 && p.bagging_fraction < 1.0))
+            throw std::invalid_argument("a table with row multiplicities trains with the level grower (1 <= max_depth <= 7), at most 32 features of which the last 16-feature "
+                                        "chunk holds at most 15, without bagging and without per-row weights");
+    }
     hipLaunchKernelGGL(k_pack_bins, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tab.codes.p, (long long)N, 0ll, (long long)N,
-                       d_cols.p, d_ncod.p, d_lut_off.p, d_lut.p, d_miss.p, F, nchunk, d_rec.p);
+                       d_cols.p, d_ncod.p, d_lut_off.p, d_lut.p, d_miss.p, F, nchunk, d_rec.p, d_mult);
     // grower choice: the level-synchronous streaming grower (rgbm_level.h) whenever it applies; RGBM_GROWER=leafwise forces the
     // index-list grower (both are HIP; they produce identical models)
     const bool use_bagging = p.bagging_freq > 0 && p.bagging_fraction < 1.0;
@@ -934,6 +945,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     LevelConst lc; memset(&lc, 0, sizeof(lc));
     DevBuf<uint8_t> d_node; DevBuf<LvPlan> d_plan; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
+    DevBuf<uint2> d_rtg;
     DevBuf<uint32_t> d_prog; uint32_t mt_epoch = 0;   // lock-step progress words of the wave-specialised level pass: [row blocks][tree groups]
     int n_hnodes = 1;
     bool use_reduce = false;   // root pass: sum the per-workgroup partials in a separate kernel (many workgroups per class tree, joint bins, or row-sharded)
@@ -953,6 +965,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         lc.nchunk = nchunk; lc.K = K; lc.F = F; lc.totbins = tc.totbins;
         lc.num_leaves = NL; lc.max_depth = p.max_depth; lc.min_data_in_leaf = p.min_data_in_leaf; lc.N = N; lc.NS = (N + 255) & ~255ll; lc.NG = lc.NS;
         lc.sib_local = (dp && g_comm.rank == 0) ? 1 : 0;
+        lc.has_mult = wm ? 1u : 0u;
         n_hnodes = (1 << p.max_depth) - 1;
         // ---- root pass: one 1024-thread workgroup per CU and (class tree, row block, chunk).  Contiguous row blocks, a multiple of 8 per
         // class tree with all class trees of a row block on one XCD (k_level_root), about four rounds of 256 workgroups when the class
@@ -992,6 +1005,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 const long long nb2 = ((long long)lv_slots(fmeta.data() + cmeta[0].first_feat, cmeta[0].nfeat, 0) + lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0) + MT_ROT_DUMMY) * 16;
                 if (nb2 > lc.lds_bytes - mt_fixed_bytes(MT_THREADS_ACC2, true, sw.mt_spec != 0)) acc2 = false;
             }
+            if (wm && nchunk == 2 && !acc2) throw std::invalid_argument("a two-chunk table with row multiplicities needs the one-pass level form (the multiplicity rides in the second record)");
             for (int ch = 0; ch < (acc2 ? 1 : nchunk); ++ch) {
                 const FeatMeta* fm = fmeta.data() + cmeta[ch].first_feat;
                 long long node_bytes = (long long)lv_slots(fm, cmeta[ch].nfeat, 0) * 16 + MT_ROT_DUMMY * 16;
@@ -1051,6 +1065,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             size_t prog_words = 0;
             for (int level = 1; level < p.max_depth; ++level) for (const auto& L : mt_plan[level]) prog_words = std::max(prog_words, (size_t)L.G * (size_t)L.gx);
             d_prog.alloc(std::max<size_t>(prog_words, 1)); d_prog.zero(s);
+            if (MT_RT_GLOBAL) d_rtg.alloc(std::max<size_t>(prog_words, 1) * MT_MAX_RT);      // (experiment: a global copy of every workgroup's route table)
         }
         d_node.alloc((size_t)K * lc.NS);
         d_plan.alloc(K); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
@@ -1063,7 +1078,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         // Joint bins for the root pass (the tables where the root pass runs at the LDS-atomic rate).  Best-fit-decreasing packing of the
         // features into groups whose bin counts multiply to <= 256; worth it when it saves at least two atomics per row and the groups
         // fit one 16-byte record.  RGBM_JOINT_ROOT=0 disables it (same models either way: the sums are exact integers).
-        joint_root = sw.joint_root && (long long)K * N >= (1ll << 21);
+        joint_root = sw.joint_root && ((long long)K * N >= (1ll << 21) || (wm && nchunk == 2));
         if (joint_root) {
             std::vector<int> order(F); for (int f = 0; f < F; ++f) order[f] = f;
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fmeta[a].nbins > fmeta[b].nbins; });
@@ -1085,10 +1100,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 std::vector<std::vector<int>> gw; std::vector<int> pw;
                 pack(JOINT_WIDE_CAP, gw, pw);
                 long long slots2 = 0; for (int v : pw) slots2 += (long long)v * 2;
-                if (sw.joint_wide && gw.size() <= 8 && gw.size() + 2 <= groups.size() && slots2 * 16 + LV_ROOT_FIXED <= lc.lds_bytes) { groups.swap(gw); prod.swap(pw); joint_wide = true; }
+                if (sw.joint_wide && !wm && gw.size() <= 8 && gw.size() + 2 <= groups.size() && slots2 * 16 + LV_ROOT_FIXED <= lc.lds_bytes) { groups.swap(gw); prod.swap(pw); joint_wide = true; }
             }
             const int VF = (int)groups.size();
-            if (VF > (joint_wide ? 8 : 16) || VF > F - 2) joint_root = false;
+            if (VF > (joint_wide ? 8 : (wm ? 15 : 16)) || VF > F - 2) joint_root = false;
             else {
                 std::vector<FeatMeta> vfm(VF); std::vector<JointFeat> jf(F); std::vector<int16_t> binfeat(tc.totbins, 0);
                 ChunkMeta vcm; vcm.first_feat = 0; vcm.nfeat = VF; vcm.fast_slots = 0; vcm.wide_bins = 0;
@@ -1111,7 +1126,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                     d_vfmeta.alloc(VF); d_vfmeta.upload(vfm.data(), VF, s); d_vcmeta.alloc(1); d_vcmeta.upload(&vcm, 1, s);
                     d_jf.alloc(F); d_jf.upload(jf.data(), F, s); d_binfeat.alloc(binfeat.size()); d_binfeat.upload(binfeat.data(), binfeat.size(), s);
                     d_rec_j.alloc((size_t)N);
-                    hipLaunchKernelGGL(k_pack_joint, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_rec.p, (long long)N, F, d_jf.p, d_rec_j.p, joint_wide ? 1 : 0);
+                    hipLaunchKernelGGL(k_pack_joint, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_rec.p, (long long)N, F, d_jf.p, d_rec_j.p, joint_wide ? 1 : 0, wm ? nchunk - 1 : -1);
                     d_part_j.alloc((size_t)K * lc.gx * vtotbins); d_red_j.alloc((size_t)K * vtotbins + (size_t)K * 128 /* k_level_reduce parks the counts behind the bins */);
                     lcj = lc; lcj.nchunk = 1; lcj.F = VF; lcj.totbins = vtotbins; lcj.max_built = 1;
                     use_reduce = true;
@@ -1119,6 +1134,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 }
             }
         }
+        if (wm && nchunk == 2 && !joint_root)
+            throw std::invalid_argument("a two-chunk table with row multiplicities needs the joint-bin root pass (its record carries the multiplicity); this feature set does not pack into 15 groups");
         // once per process and device: the attribute belongs to the function, not to the call, and other threads are launching these
         // kernels while a new training call sets up
         {
@@ -1247,9 +1264,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
 #define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, ...) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, __VA_ARGS__>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, l1); \
+                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, d_rtg.p, l1); \
                                            else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, __VA_ARGS__>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, l1); } while (0)
+                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, d_rtg.p, l1); } while (0)
 #define RGBM_LAUNCH_MT(NCHR, THR, ACC, ...) do { if (use_bagging) RGBM_LAUNCH_MT2(NCHR, true, d_inbag.p, THR, ACC, __VA_ARGS__); else RGBM_LAUNCH_MT2(NCHR, false, nullptr, THR, ACC, __VA_ARGS__); } while (0)
                 if (L.acc2) { if (sw.mt_spec != 0 && L.rot) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true, true); else if (sw.mt_spec != 0) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true); else RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, false); }
                 else if (nchr == 1 && sw.mt_spec == 1) RGBM_LAUNCH_MT(1, LV_THREADS, false, true);
@@ -1296,7 +1313,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     };
     // one boosting iteration of the level grower after the gradients: an iteration-invariant launch sequence
     auto enqueue_level_growth = [&]() {
-            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, n_in_ptr, (long long)n_train, lc);
+            hipLaunchKernelGGL(k_level_init, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, d_count.p, n_in_ptr, (long long)n_train, d_fxq.p, tc.fx, d_fxs.p, lc);
             int32_t* cntg = dp ? d_count_g.p : d_count.p;      // child row counts seen by split / leaf-count (global when row-sharded)
             // partials of this rank -> compact buffer (-> integer all-reduce when row-sharded); the split kernel then sees ONE partial
             auto exchange = [&](bool root, int nb, const LevelConst& lp) -> std::pair<const HistBin*, LevelConst> {
@@ -1353,23 +1370,23 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
         uint8_t* node0 = level_mode ? d_node.p : nullptr;
         unsigned long long* qp = fx_fused ? d_qpart.p : nullptr;
-        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, tc);
+        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, tc);
         else if (mc_rows)
-            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, tc);
+            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, tc);
         else if (mc_tile)
-            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, tc);
-        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, (unsigned long long*)nullptr, tc);
-        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, tc);
+            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, tc);
+        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, (unsigned long long*)nullptr, d_mult, tc);
+        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, tc);
         if (fx_fused) {
             const long long total = fx_parts * K * 2;
             const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(256, (total + 8191) / 8192));
             hipLaunchKernelGGL(k_fx_reduce, dim3(gx), dim3(256), (size_t)K * 2 * 8, s, d_qpart.p, fx_parts, 2 * K, d_fxq.p);
         } else {
             const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(128, (N + 4095) / 4096));
-            hipLaunchKernelGGL(k_fx_measure, dim3(gx, K), dim3(256), 0, s, d_gh.p, (long long)N, (long long)tc.NG, tc.fx, d_fxq.p);
+            hipLaunchKernelGGL(k_fx_measure, dim3(gx, K), dim3(256), 0, s, d_gh.p, (long long)N, (long long)tc.NG, tc.fx, d_fxq.p, d_mult);
         }
         if (dp) all_reduce(d_fxq.p, (size_t)K * 2, AR_I64, s);
-        hipLaunchKernelGGL(k_fx_scale, dim3(1), dim3(256), 0, s, d_fxq.p, K, tc.fx, d_fxs.p);
+        if (!level_mode) hipLaunchKernelGGL(k_fx_scale, dim3(1), dim3(256), 0, s, d_fxq.p, K, tc.fx, d_fxs.p);      // (level grower: k_level_init does it)
     };
 
     if (timing) HIPCHK(hipStreamSynchronize(s));
@@ -1550,6 +1567,7 @@ void score_valid_with_model(const rgbm_fit_spec& sp, rgbm_model* m) {
 
 bool small_fit_eligible(const rgbm_table& tab, int32_t F, const rgbm_params& p, long long small_rows) {
     if (tab.n > small_rows || tab.n >= (1ll << 31) - 4096) return false;
+    if (tab.has_mult) return false;      // (rows with multiplicities: the level grower of the single-fit trainer)
     if (p.num_leaves > rg::SM_MAX_LEAVES || F > rg::SM_MAX_FEATS) return false;
     if (p.reserved & RGBM_FLAG_ROW_SHARDED) return false;
     return true;
@@ -2434,6 +2452,28 @@ RGBM_EXPORT int rgbm_repair_chain(const rgbm_model* const* models, int32_t T, co
         DevBuf<int32_t> codes((size_t)n * c); codes.upload(table, (size_t)n * c, s);
         chain_device(const_cast<rgbm_model* const*>(models), T, target_col, feat_cols, feat_off, class_code, class_off, codes.p, n, 0, n, device_id, s, out_label, out_prob);
         HIPCHK(hipMemcpy(table, codes.p, (size_t)n * c * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return RGBM_OK;
+    });
+}
+
+// Rows with multiplicities: row i of the table stands for mult[i] (1..255) identical rows of a larger table (repair.pipeline.distinct_rows makes
+// such a table: identical (features, label) rows take identical paths and gradients in every tree, and every sum of the trainer is an exact
+// integer, so m times a row's value IS the sum over its m copies).  Every later rgbm_table_train on this table weighs the row so -- code counts,
+// child counts, histogram sums, the coarse sums behind the fixed-point grids -- and returns byte for byte the model the expanded table gives.
+// NULL clears.  Level grower, <= 32 features with a free byte in the last record, no bagging (rgbm.hip train_core says so when it does not apply).
+RGBM_EXPORT int rgbm_table_set_row_multiplicity(rgbm_table* t, const uint8_t* mult) {
+    if (!t) return fail(RGBM_ERR_ARG, "rgbm_table_set_row_multiplicity: bad argument");
+    return guarded([&]() {
+        use_device(t->device);
+        if (!mult) { t->has_mult = false; t->mult_total = 0; return RGBM_OK; }
+        int64_t tot = 0;
+        for (int64_t i = 0; i < t->n; ++i) { if (mult[i] == 0) throw std::invalid_argument("rgbm_table_set_row_multiplicity: a multiplicity of 0"); tot += mult[i]; }
+        if (tot >= (1ll << 31) - 4096) throw std::invalid_argument("rgbm_table_set_row_multiplicity: the expanded table has more than 2^31 rows");
+        StreamGuard sg;
+        t->mult.alloc((size_t)t->n);
+        t->mult.upload(mult, (size_t)t->n, sg.s);
+        HIPCHK(hipStreamSynchronize(sg.s));
+        t->has_mult = true; t->mult_total = tot;
         return RGBM_OK;
     });
 }

@@ -101,6 +101,9 @@ struct rgbm_table {
     std::vector<std::vector<double>> col_values;   // NUMERIC columns: the ascending distinct values behind the codes (rgbm_table_set_column_values)
     std::vector<uint8_t> col_kind;                 // 1 = CATEGORICAL column (rgbm_table_set_column_kind): unseen categories are missing for a model
     rgh::DevBuf<int32_t> codes;
+    // rows with MULTIPLICITIES (rgbm_table_set_row_multiplicity): row i stands for mult[i] (1..255) identical rows of a larger table -- every count,
+    // every gradient sum and every coarse magnitude of a training call weighs it so; the model is byte for byte the one the expanded table gives
+    rgh::DevBuf<uint8_t> mult; bool has_mult = false; int64_t mult_total = 0;
     // result of the last rgbm_table_detect_* call (rgbm_prep.hip): cells (row, column), device resident
     rgh::DevBuf<long long> cell_rows; rgh::DevBuf<int32_t> cell_cols; int64_t n_cells = 0;
     // stream + scratch of the relational steps (rgbm_prep.hip), kept with the table: a hipMalloc / hipFree / stream

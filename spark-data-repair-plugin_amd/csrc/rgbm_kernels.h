@@ -51,7 +51,8 @@ constexpr int COUNT_LDS_CODES = 8192;
 __global__ __launch_bounds__(256) void k_count_codes(const int32_t* __restrict__ codes, long long N,
                                                      const int32_t* __restrict__ ycol /* training rows: ycol[row] >= 0; may be null */,
                                                      const int32_t* __restrict__ feat_col, const int32_t* __restrict__ n_codes,
-                                                     const long long* __restrict__ cnt_off, unsigned int* __restrict__ cnt) {
+                                                     const long long* __restrict__ cnt_off, unsigned int* __restrict__ cnt,
+                                                     const uint8_t* __restrict__ mult = nullptr /* rows with multiplicities (rgbm_table_set_row_multiplicity): a row counts mult[row] times */) {
     __shared__ unsigned int lc[COUNT_LDS_CODES];
     const int f = blockIdx.y;
     const int32_t* col = codes + (long long)feat_col[f] * N;
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256) void k_count_codes(const int32_t* __restrict__
         if (ycol && ycol[r] < 0) continue;
         int c = col[r];
         if (c < 0 || c >= nc) continue;
-        if (use_lds) atomicAdd(&lc[c], 1u); else atomicAdd(&out[c], 1u);
+        const unsigned int m = mult ? (unsigned int)mult[r] : 1u;
+        if (use_lds) atomicAdd(&lc[c], m); else atomicAdd(&out[c], m);
     }
     if (use_lds) {
         __syncthreads();
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(256) void k_count_codes(const int32_t* __restrict__
 __global__ __launch_bounds__(256) void k_pack_bins(const int32_t* __restrict__ codes, long long Ntab, long long row0, long long n,
                                                    const int32_t* __restrict__ feat_col, const int32_t* __restrict__ n_codes,
                                                    const long long* __restrict__ lut_off, const uint8_t* __restrict__ lut,
-                                                   const uint8_t* __restrict__ miss_bin, int F, int nchunk, uint4* __restrict__ rec) {
+                                                   const uint8_t* __restrict__ miss_bin, int F, int nchunk, uint4* __restrict__ rec,
+                                                   const uint8_t* __restrict__ mult = nullptr /* [Ntab] row multiplicities: ride in byte 15 of the LAST chunk's record (the caller made sure that chunk holds <= 15 features) */) {
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(256) void k_pack_bins(const int32_t* __restrict__ c
             }
             w[j >> 2] |= b << (8 * (j & 3));
         }
+        if (mult && ch == nchunk - 1) w[3] = (w[3] & 0x00FFFFFFu) | ((uint32_t)mult[row0 + i] << 24);
         rec[(long long)ch * n + i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
@@ -124,7 +128,8 @@ __device__ __forceinline__ void grad_rows(long long first, long long stride, con
                                           const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
                                           float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
                                           long long NS, const TrainConst& c,
-                                          unsigned long long* qacc = nullptr /* OBJ != 1: this thread's sums of the coarse magnitudes of its (g, h) (numerics v2.2), or null */) {
+                                          unsigned long long* qacc = nullptr /* OBJ != 1: this thread's sums of the coarse magnitudes of its (g, h) (numerics v2.2), or null */,
+                                          const uint8_t* __restrict__ mult = nullptr /* row multiplicities: a row's magnitudes count mult[row] times */) {
     const long long N = c.N;
     for (long long i = first; i < N; i += stride) {
         const int y = ycol[i];
@@ -148,11 +153,11 @@ __device__ __forceinline__ void grad_rows(long long first, long long stride, con
             double abs_r = fabs(response);
             const float g32 = (float)(response * wi), h32 = (float)(abs_r * (1.0 - abs_r) * wi);
             gh[i] = make_float2(g32, h32);
-            if (qacc) { qacc[0] += fx_coarse(g32, c.fx.c_g); qacc[1] += fx_coarse(h32, c.fx.c_h); }
+            if (qacc) { const unsigned long long m = mult ? mult[i] : 1; qacc[0] += m * fx_coarse(g32, c.fx.c_g); qacc[1] += m * fx_coarse(h32, c.fx.c_h); }
         } else if (OBJ == 2) {   // RegressionL2loss::GetGradients
             const float g32 = (float)((score[i] - y_value[y]) * wi), h32 = (float)wi;
             gh[i] = make_float2(g32, h32);
-            if (qacc) { qacc[0] += fx_coarse(g32, c.fx.c_g); qacc[1] += fx_coarse(h32, c.fx.c_h); }
+            if (qacc) { const unsigned long long m = mult ? mult[i] : 1; qacc[0] += m * fx_coarse(g32, c.fx.c_g); qacc[1] += m * fx_coarse(h32, c.fx.c_h); }
         } else {
             const int K = c.K;
             double wmax = score[i];
@@ -173,11 +178,11 @@ __global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, 
                                               const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
                                               float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
                                               long long NS, unsigned long long* __restrict__ qpart /* OBJ != 1: [gridDim.x][2] coarse sums of this workgroup's (g, h), or null */,
-                                              TrainConst c) {
+                                              const uint8_t* __restrict__ mult, TrainConst c) {
     unsigned long long acc[2] = {0ull, 0ull};
     const bool measure = OBJ != 1 && qpart != nullptr;
     grad_rows<OBJ>((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, score, ycol, y_value, class_w, sample_w, row_in_bag, gh, node0, NS, c,
-                   measure ? acc : nullptr);
+                   measure ? acc : nullptr, mult);
     if (measure) {
         __shared__ unsigned long long ws[4][2];
         const unsigned long long a0 = wave_sum_u64(acc[0]), a1 = wave_sum_u64(acc[1]);
@@ -218,13 +223,15 @@ __global__ __launch_bounds__(256) void k_fx_reduce(const unsigned long long* __r
 }
 
 // grid (gx, K), block 256
-__global__ __launch_bounds__(256) void k_fx_measure(const float2* __restrict__ gh, long long N, long long NG, FxGrid fx, unsigned long long* __restrict__ Q) {
+__global__ __launch_bounds__(256) void k_fx_measure(const float2* __restrict__ gh, long long N, long long NG, FxGrid fx, unsigned long long* __restrict__ Q,
+                                                    const uint8_t* __restrict__ mult = nullptr) {
     const int k = blockIdx.y;
     const float2* ghk = gh + (long long)k * NG;
     unsigned long long a0 = 0ull, a1 = 0ull;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const float2 g = ghk[i];
-        a0 += fx_coarse(g.x, fx.c_g); a1 += fx_coarse(g.y, fx.c_h);
+        const unsigned long long m = mult ? mult[i] : 1;
+        a0 += m * fx_coarse(g.x, fx.c_g); a1 += m * fx_coarse(g.y, fx.c_h);
     }
     __shared__ unsigned long long ws[4][2];
     a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ scor
                                                  const uint8_t* __restrict__ row_in_bag, float2* __restrict__ gh,
                                                  uint8_t* __restrict__ node0, long long NS,
                                                  unsigned long long* __restrict__ qpart /* [gridDim.x][K][2] coarse sums of this workgroup's (g, h) (numerics v2.2), or null */,
-                                                 TrainConst c) {
+                                                 const uint8_t* __restrict__ mult /* row multiplicities (<= 255: q * m stays below 2^32), or null */, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem);          // [K][64]
     double* pmax = tile + (size_t)c.K * 64;                  // [4][64]
@@ -294,13 +301,14 @@ __global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ scor
     if (on && sample_w) wi = wi * sample_w[i];
     wi = (double)(float)wi;   // LightGBM Metadata keeps weights as float32
     const double wsum = psum[r];
+    const unsigned int mrow = (mult && on) ? (unsigned int)mult[i] : 1u;
     for (int k = wv; k < K; k += 4) {
         double packed = 0.0;                                  // bits 0..31: coarse |g|, bits 32..63: coarse h (a double only by type: the tile's)
         if (on) {
             const double pk = tile[k * 64 + r] / wsum;
             const float g32 = (float)(((y == k) ? (pk - 1.0) : pk) * wi), h32 = (float)(c.factor * pk * (1.0 - pk) * wi);
             gh[(long long)k * c.NG + i] = make_float2(g32, h32);
-            if (qpart) packed = __hiloint2double((int)fx_coarse(h32, c.fx.c_h), (int)fx_coarse(g32, c.fx.c_g));
+            if (qpart) packed = __hiloint2double((int)(mrow * fx_coarse(h32, c.fx.c_h)), (int)(mrow * fx_coarse(g32, c.fx.c_g)));
         }
         // numerics v2.2: the tile entry of (k, r) is dead once pk is known -- it takes the coarse magnitudes of this (row, class tree)
         if (qpart) tile[k * 64 + r] = packed;
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ s
                                                     const uint8_t* __restrict__ row_in_bag, float2* __restrict__ gh,
                                                     uint8_t* __restrict__ node0, long long NS,
                                                     unsigned long long* __restrict__ qpart /* [gridDim.x * R / 64][K][2] coarse sums of every wave's (g, h) (numerics v2.2), or null */,
-                                                    TrainConst c) {
+                                                    const uint8_t* __restrict__ mult, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile0 = reinterpret_cast<double*>(smem);
     double* tile = tile0 + threadIdx.x;   // element k at tile[k * R]
@@ -355,13 +363,14 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ s
         if (sample_w) wi = wi * sample_w[i];
         wi = (double)(float)wi;
         double wsum = 0.0;
+        const unsigned int mrow = mult ? (unsigned int)mult[i] : 1u;
         for (int kk = 0; kk < K; ++kk) { const double e = rg_exp(tile[kk * R] - wmax); tile[kk * R] = e; wsum += e; }
         for (int kk = 0; kk < K; ++kk) {
             const double pk = tile[kk * R] / wsum;
             const float g32 = (float)(((y == kk) ? (pk - 1.0) : pk) * wi), h32 = (float)(c.factor * pk * (1.0 - pk) * wi);
             gh[(long long)kk * c.NG + i] = make_float2(g32, h32);
             // numerics v2.2: the dead tile entry takes the coarse magnitudes (bits 0..31: |g|, bits 32..63: h)
-            if (qpart) tile[kk * R] = __hiloint2double((int)fx_coarse(h32, c.fx.c_h), (int)fx_coarse(g32, c.fx.c_g));
+            if (qpart) tile[kk * R] = __hiloint2double((int)(mrow * fx_coarse(h32, c.fx.c_h)), (int)(mrow * fx_coarse(g32, c.fx.c_g)));
         }
     } else if (qpart) { for (int kk = 0; kk < K; ++kk) tile[kk * R] = 0.0; }
     if (!qpart) return;

@@ -65,6 +65,9 @@ constexpr int MT_THREADS_ACC2 = 768;
 #ifndef MT_CONSUMERS_N
 #define MT_CONSUMERS_N 4
 #endif
+#ifndef MT_RT_GLOBAL
+#define MT_RT_GLOBAL 0        // experiment (round 6): the row loop of k_level_mt reads its route entries from a per-workgroup GLOBAL copy of the table (vector
+#endif                        // memory) instead of from LDS, so that routing never queues behind the histogram atomics in the CU's in-order LDS pipeline
 #ifndef MT_SCALAR_TILE
 #define MT_SCALAR_TILE 0      // experiment (round 6): the wave index of k_level_mt through readfirstlane, whole tiles without clamps -- see profiles/EXPERIMENTS.md
 #endif
@@ -100,7 +103,7 @@ struct LevelConst {
     int32_t mt_T, mt_G, mt_ch, mt_slot0, mt_nslots, mt_route;
     int32_t mt_sparse, mt_window;   // mt_sparse 1: class trees with few live rows are swept through their node ids (k_level_mt, plain single-chunk pass);
                                     // mt_window > 0: the class-tree groups of a row block walk it in step (wave-specialised pass, see "lock-step")
-    uint32_t mt_epoch, mt_pad;      // lock-step: tag of this launch in the progress words
+    uint32_t mt_epoch, has_mult;    // lock-step: tag of this launch in the progress words; has_mult: rows carry multiplicities in byte 15 of their (last / joint) record
     long long N, NS, NG;         // rows; row stride of the node-id arrays and of the (g, h) arrays (both N rounded up to a whole wave tile of 256 rows)
 };
 
@@ -183,8 +186,18 @@ __host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2, bool
 // k_level_init: per class tree, start of a boosting iteration
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_level_init(LvPlan* __restrict__ plan, SNode* __restrict__ nodes, int32_t* __restrict__ count,
-                                                   const unsigned int* __restrict__ n_in_ptr, long long n_train, LevelConst c) {
+                                                   const unsigned int* __restrict__ n_in_ptr, long long n_train,
+                                                   unsigned long long* __restrict__ Q, FxGrid fx, FxScale* __restrict__ fxs, LevelConst c) {
     const int k = blockIdx.x, lane = lane_id();
+    // numerics v2.2: this class tree's fixed-point grid of the iteration from the coarse sums of its gradients (k_fx_scale's work, here so that
+    // the chain of small kernels of an iteration does not grow by a launch); the sums go back to zero for the next iteration
+    if (lane == 0) {
+        const int e_g = fx_tree_exponent(Q[2 * k], fx.q_mult, fx.c_g, fx.e_g_min, fx.e_g_max);
+        const int e_h = fx_tree_exponent(Q[2 * k + 1], fx.q_mult, fx.c_h, fx.e_h_min, fx.e_h_max);
+        FxScale f; f.sg = fx_pow2(e_g); f.sh = fx_pow2(e_h); f.inv_sg = fx_pow2(-e_g); f.inv_sh = fx_pow2(-e_h);
+        fxs[k] = f;
+        Q[2 * k] = 0ull; Q[2 * k + 1] = 0ull;
+    }
     LvPlan* pp = &plan[k];
     const long long n_in = n_in_ptr ? (long long)n_in_ptr[0] : n_train;
     // the child row counts of the new tree start at zero (here rather than in a hipMemsetAsync: the boosting loop is kernels only)
@@ -272,7 +285,8 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
     };
     auto accumulate = [&](bool on, const uint4& r, const float2& g) __attribute__((always_inline)) {
         if (on && (g.x != 0.0f || g.y != 0.0f)) {   // out-of-bag rows carry (0, 0)
-            const unsigned long long gq = (unsigned long long)fx_from_f32(g.x, sg_k), hq = (unsigned long long)fx_from_f32(g.y, sh_k);
+            unsigned long long gq = (unsigned long long)fx_from_f32(g.x, sg_k), hq = (unsigned long long)fx_from_f32(g.y, sh_k);
+            if (c.has_mult) { const unsigned long long m = r.w >> 24; gq *= m; hq *= m; }     // (a row that stands for m identical rows: exact integers, so m times the value IS their sum)
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g);
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #define LV_ATOM(j) { const uint32_t code_ = WIDE ? ((w[((j) & 7) >> 1] >> (16 * ((j) & 1))) & 0xFFFFu) : ((w[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu); \
@@ -348,7 +362,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                                                          const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                          int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
                                                          int32_t* __restrict__ err_flag, uint32_t* __restrict__ prog /* [row blocks][tree groups] lock-step progress words (SPEC), or null */,
-                                                         const FxScale* __restrict__ fxs /* [K] this iteration's grid per class tree */, LevelConst c) {
+                                                         const FxScale* __restrict__ fxs /* [K] this iteration's grid per class tree */,
+                                                         uint2* __restrict__ rt_glob /* MT_RT_GLOBAL: [gridDim.x][MT_MAX_RT] scratch */, LevelConst c) {
     static_assert(!ACC2 || NCHR == 2, "a two-chunk pass keeps both records in registers");
     constexpr int WAVES = THREADS / 64;
     constexpr int NCONS = SPEC ? MT_CONSUMERS : 0, NPROD = WAVES - NCONS;     // waves that walk the rows / waves that only run batches
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     const int wb = cm.wide_bins + (ACC2 ? cm1.wide_bins : 0);
     // the histogram slot of a ring entry rides in byte 15 of its (last) record whenever that chunk holds at most 15 features: one LDS
     // write and one LDS read less per entry (the 10M x 16 and the 100M x 32 shapes have 15 features in their last chunk)
-    const bool li_in_rec = (ACC2 ? nfeat1 : nfeat) <= 15;
+    const bool li_in_rec = (ACC2 ? nfeat1 : nfeat) <= 15 && !c.has_mult;      // (with row multiplicities byte 15 is taken)
 
     // ---- LDS carve-up
     MtTree* ti = reinterpret_cast<MtTree*>(smem);                                              // [MT_MAX_T]
@@ -538,6 +553,14 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     }
     const int hdelta = total * spn;
     __syncthreads();
+#if MT_RT_GLOBAL
+    // the route table of this workgroup, once more in global memory: the row loop's lookups then travel through the vector memory pipeline
+    // (vmcnt) and do not wait behind this wave's -- and every other wave's -- LDS atomics (the LDS pipeline of a CU serves in order)
+    uint2* rt_g = rt_glob + (size_t)blockIdx.x * MT_MAX_RT;
+    for (int i = tid; i < MT_MAX_RT; i += THREADS) rt_g[i] = rt[i];
+    __threadfence();
+    __syncthreads();
+#endif
     // feature rotation (MT_ROT): lane l works on feature slot (j + l) mod 16 in step j.  cj[a][j] becomes the byte offset of THAT feature's
     // first slot (+ the lane's replica l / 16), or of the lane's dummy slot when the chunk has no such feature; rmask[a] zeroes the bytes of
     // the rotated record that are not features, so that a masked lane adds to bin 0 of its dummy slot.
@@ -595,9 +618,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         for (int a = 0; a < NACC; ++a) { shp[a] = sh3p[a]; asm volatile("" : "+s"(shp[a])); }
         if (on) {
             const uint2 sc = nd_sc[li];                  // the grid of the entry's class tree
-            const unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), __hiloint2double((int)sc.x, 0)),
-                                     hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), __hiloint2double((int)sc.y, 0));
-            if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], 1);
+            unsigned long long gq = (unsigned long long)fx_from_f32(__uint_as_float(g.x), __hiloint2double((int)sc.x, 0)),
+                               hq = (unsigned long long)fx_from_f32(__uint_as_float(g.y), __hiloint2double((int)sc.y, 0));
+            int mrow = 1;
+            if (c.has_mult) { mrow = (int)((ACC2 ? r1.w : r.w) >> 24); gq *= (unsigned long long)mrow; hq *= (unsigned long long)mrow; }
+            if (ch == 0) atomicAdd(&cnt[li * MT_CNT_REP + (lane & (MT_CNT_REP - 1))], mrow);
             unsigned char* hb = reinterpret_cast<unsigned char*>(hist_g) + li * spn8;
             uint32_t w[4] = {r.x, r.y, r.z, r.w};
             uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w};
@@ -751,7 +776,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             const uint32_t idx = ((n4 >> (8 * j)) & 0xFFu) - base;
             const bool in = (tq0 >> 31) != 0u && idx < nlev && ((rowmask >> j) & 1u);
             inm |= in ? (1u << j) : 0u;
+#if MT_RT_GLOBAL
+            e[j] = rt_g[rt_off + (in ? idx : 0u)];
+#else
             e[j] = rt[rt_off + (in ? idx : 0u)];
+#endif
         }
     };
     // route the four rows, append the built ones to the ring (and, in the plain pass, run the batches)
@@ -1083,7 +1112,8 @@ struct JointFeat { int32_t voff /* offset of the group's joint histogram */, str
 
 // joint record of every row from its plain bin record(s); thread per row
 constexpr int JOINT_WIDE_CAP = 1024;     // joint bins of a group with 16-bit codes (k_level_root<true>)
-__global__ __launch_bounds__(256) void k_pack_joint(const uint4* __restrict__ rec, long long N, int F, const JointFeat* __restrict__ jf, uint4* __restrict__ rec_joint, int wide) {
+__global__ __launch_bounds__(256) void k_pack_joint(const uint4* __restrict__ rec, long long N, int F, const JointFeat* __restrict__ jf, uint4* __restrict__ rec_joint, int wide,
+                                                    int mult_chunk = -1 /* >= 0: byte 15 of that chunk's record holds the row's multiplicity and moves to byte 15 of the joint record */) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
@@ -1094,6 +1124,7 @@ __global__ __launch_bounds__(256) void k_pack_joint(const uint4* __restrict__ re
         if (wide) w[vb >> 1] += (bin * (uint32_t)jf[f].stride) << (16 * (vb & 1));   // (a group's code stays below 65536)
         else w[vb >> 2] += (bin * (uint32_t)jf[f].stride) << (8 * (vb & 3));    // a group's code stays below 256: no carry into the next byte
     }
+    if (mult_chunk >= 0) w[3] = (w[3] & 0x00FFFFFFu) | ((uint32_t)rec8[((long long)mult_chunk * N + i) * 16 + 15] << 24);
     rec_joint[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -1469,7 +1500,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
                     const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
                     const uint32_t w1 = route1[n];
                     n = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
-                    if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                    if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], c.has_mult ? (int)rec8[((long long)(c.nchunk - 1) * N + row) * 16 + 15] : 1);
                 }
                 sv[j] += nd[n];
             }
@@ -1487,7 +1518,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
                 const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
                 const uint32_t w1 = route1[n];
                 n = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
-                if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], 1);
+                if (!inbag || inbag[row]) atomicAdd(&cnt[(n - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], c.has_mult ? (int)rec8[((long long)(c.nchunk - 1) * N + row) * 16 + 15] : 1);
             }
             sk[row] += nd[n];
         }

@@ -104,7 +104,7 @@ EXPORTED_SYMBOLS = [
     "rgbm_table_detect_nulls", "rgbm_table_detect_constraint", "rgbm_table_rows_of_cells", "rgbm_table_cells_fetch",
     "rgbm_table_null_cells", "rgbm_table_gather_rows", "rgbm_table_count_codes", "rgbm_table_create_dict", "rgbm_table_shape",
     "rgbm_table_repair_pmf", "rgbm_table_read_cells", "rgbm_table_write_cells", "rgbm_host_alloc", "rgbm_host_free",
-    "rgbm_table_set_column_values", "rgbm_table_set_column_kind",
+    "rgbm_table_set_column_values", "rgbm_table_set_column_kind", "rgbm_table_set_row_multiplicity",
 ]
 
 COMM_ID_BYTES = 128
@@ -636,6 +636,14 @@ class Table:
                                              C.c_int64(row_begin), C.c_int64(n_rows), _p(lab, C.c_int32), _p(prob, C.c_double)),
                "rgbm_table_repair_chain")
         return lab, prob
+
+    def set_row_multiplicity(self, mult):
+        """Row i stands for mult[i] (1..255) identical rows of a larger table (repair.pipeline.distinct_rows): every later train() on this
+        table returns the model of the EXPANDED table, byte for byte.  None clears."""
+        m = None if mult is None else np.ascontiguousarray(mult, np.uint8)
+        if m is not None and m.shape != (self.n,):
+            raise ValueError("one multiplicity per row")
+        _check(lib().rgbm_table_set_row_multiplicity(self.h, _p(m, C.c_uint8)), "rgbm_table_set_row_multiplicity")
 
     def repair_chain_gather(self, models, target_col, feat_cols, row_begin=0, n_rows=None):
         """The chained repair of THIS rank's rows, the outputs all-gathered over the calling thread's communicator on the device (C2):

@@ -133,6 +133,39 @@ def search_on_table(engine, table, t, n_codes, base_params, opts, y_value=None, 
     return {_POINT_TO_CORE[k]: (int(v) if k in ("num_leaves", "subsample_freq", "min_child_samples") else float(v)) for k, v in point.items()}
 
 
+def distinct_rows(codes, n_codes, max_mult=255):
+    """The DISTINCT rows of a label-encoded table and how often each occurs: codes [C][N] int32 (-1 = NULL) ->
+    (distinct [C][M] int32, mult [M] uint8, inverse [N] int64: the distinct row every original row maps to).
+    A row that occurs more than `max_mult` times is kept as several rows whose multiplicities add up (the trainer carries a multiplicity in one byte).
+    What it is for: `_native.Table(distinct, n_codes).set_row_multiplicity(mult)` trains byte for byte the models of the whole table
+    (identical rows take identical paths and gradients in every tree; all sums are exact integers) at the cost of its distinct rows -- a quarter
+    of the rows on the categorical tables this plugin repairs (the synthetic 10M x 16 benchmark table holds 2.48M distinct rows).  A VARIANT of
+    the workload: bench.py --dedup reports it apart from the row-for-row line.  The reference's frames hold every row (model.py:768-815)."""
+    codes = np.ascontiguousarray(codes, np.int32)
+    C, N = codes.shape
+    # mixed-radix keys over (code + 1) in [0, n_codes]: as few uint64 words per row as the radices need
+    words, cur, room = [], np.zeros(N, np.uint64), 1
+    for c in range(C):
+        radix = int(n_codes[c]) + 1
+        if room * radix >= (1 << 63):
+            words.append(cur); cur, room = np.zeros(N, np.uint64), 1
+        cur = cur * np.uint64(radix) + (codes[c] + 1).astype(np.uint64)
+        room *= radix
+    words.append(cur)
+    if len(words) == 1:
+        _, first, inverse, counts = np.unique(words[0], return_index=True, return_inverse=True, return_counts=True)
+    else:
+        key = np.ascontiguousarray(np.stack(words, axis=1)).view([("w%d" % i, np.uint64) for i in range(len(words))]).reshape(N)
+        _, first, inverse, counts = np.unique(key, return_index=True, return_inverse=True, return_counts=True)
+    reps = (counts + max_mult - 1) // max_mult                      # distinct rows kept more than once
+    rows = np.repeat(first, reps)
+    mult = np.full(len(rows), max_mult, np.int64)
+    last = np.cumsum(reps) - 1
+    mult[last] = counts - (reps - 1) * max_mult
+    start = np.concatenate([[0], np.cumsum(reps)[:-1]])
+    return np.ascontiguousarray(codes[:, rows]), mult.astype(np.uint8), start[inverse].astype(np.int64)
+
+
 class NotResidentEligible(ValueError):
     """The run is not the plain per-attribute model loop after all (only known once the error cells are NULLed): a discrete target
     is left with fewer than two classes, a continuous one with no value.  The reference short-cuts those with `PoorModel`
