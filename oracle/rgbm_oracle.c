@@ -14,16 +14,17 @@
  * leaf-wise growth, gbdt.cpp TrainOneIter, tree.h NumericalDecision, sklearn.py predict_proba)
  * from memory.
  *
- * PARITY STATUS: "parity unpinned" against real LightGBM bits (cannot be run here).  What IS
- * pinned: the reference's own golden labels (bin/testdata/adult_repair.csv, test_model.py
- * inline goldens) -- see tests/test_oracle_golden.py -- and agreement in accuracy with
- * scikit-learn's HistGradientBoosting.  The HIP product is held bit-exact against THIS file.
+ * PARITY STATUS: "parity unpinned" against real LightGBM bits (cannot be run here; tests/test_true_reference_optional.py is the
+ * hook for the day the wheel exists).  What IS pinned: the reference's own golden labels (bin/testdata/adult_repair.csv,
+ * test_model.py inline goldens) -- tests/test_oracle_golden.py --, tree growth node by node against a hand-computed tree and
+ * scikit-learn's histogram GBDT for all three objectives (tests/test_oracle_split_pin.py), and the `spec` mode against the
+ * `lightgbm_f32` mode of this file (tests/test_numerics_bound.py).  The HIP product is held bit-exact against THIS file.
  *
- * Deliberate, documented deviations from LightGBM 3.3.1 (DESIGN.md "Numerics"):
- *  D1. (numerics v2) gradients/hessians are LightGBM's float32 values; a histogram sum is their EXACT integer sum on a per-model
- *      fixed-point grid (2^-40 of the gradient bound for up to 4M rows) instead of a double accumulated in row order
- *      => order independent => bit-reproducible on a GPU, and equal to LightGBM's double sums wherever those did not round
- *      (rgbm_oracle_train.inc builds both; tests/test_numerics_bound.py compares them).
+ * Deliberate, documented deviations from LightGBM 3.3.1:
+ *  D1. (numerics v2.2) gradients/hessians are LightGBM's float32 values; a histogram sum is their EXACT integer sum on a fixed-point
+ *      grid chosen per class tree and boosting iteration from the coarse sum of that tree's gradient magnitudes (see "Numerics v2.2"
+ *      below) instead of a double accumulated in row order => order independent => bit-reproducible on a GPU, and equal to LightGBM's
+ *      double sums wherever those did not round (rgbm_oracle_train.inc builds both; tests/test_numerics_bound.py compares them).
  *  D2. exp() is an own polynomial (rg_exp) so CPU and GPU produce identical bits.
  *  D3. features are the int32 label codes (ordinal, order preserving); NULL/unknown = -1 is
  *      LightGBM's NaN.  Bin boundaries are found on ALL training rows (no 200k sub-sample).

@@ -4,7 +4,7 @@
 //   codes   int32 [C][N]            the label-encoded table, column-major, resident (rgbm_table)
 //   rec     u8    [nchunk][N][16]   per-model bin records: 16 features per 16-byte record so one
 //                                   lane loads one row with a single dwordx4; chunk-major
-//   gh      f32x2 [K][N]            (gradient, hessian) of every class tree: LightGBM's float32 values (numerics v2)
+//   gh      f32x2 [K][N]            (gradient, hessian) of every class tree: LightGBM's float32 values (numerics v2.2)
 //   score   f64   [K][N]            raw scores
 //   idx     i32   2 x [K][n_train]  ping-pong row-index lists, partitioned per leaf
 //   pool    i64x2 [K][NL][totbins]  per-leaf histograms (exact integer sums)

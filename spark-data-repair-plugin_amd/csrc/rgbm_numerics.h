@@ -4,7 +4,7 @@
 // -ffp-contract=off for both the host (clang) and the gfx950 device pass, so the same IEEE
 // double operations run in the same order on the CPU and on the GPU:
 //   * rg_exp      own exp(): 2^k * P13(r), plain mul/add Horner (no libm/ocml dependence)
-//   * fx_from_f32 float32 gradient / hessian -> the model's fixed-point grid (exact integer histogram sums, numerics v2)
+//   * fx_from_f32 float32 gradient / hessian -> the model's fixed-point grid (exact integer histogram sums, numerics v2.2)
 //   * leaf_gain / leaf_output / threshold_l1   LightGBM feature_histogram.hpp formulas
 //     (GetLeafGain, CalculateSplittedLeafOutput, ThresholdL1) as reached from
 //     python/repair/train.py:102-115 (no max_delta_step, no path smoothing, no monotone).

@@ -3,12 +3,13 @@ probabilities within 1e-4 of the reference's float32 path).
 
 Both modes of the CPU oracle (oracle/rgbm_oracle_train.inc) train with the reference's fixed parameters for the full 300
 iterations (python/repair/train.py:102-131) on the reference's tables and on a synthetic table with a K = 64 target:
-  spec          numerics v2 -- LightGBM's float32 g / h per row, exact integer histogram sums (what the HIP kernels implement),
+  spec          numerics v2.2 -- LightGBM's float32 g / h per row, exact integer histogram sums on a fixed-point grid chosen per class
+                tree and boosting iteration (what the HIP kernels implement),
   lightgbm_f32  the same float32 g / h, double sums in row order (GetGradients / ConstructHistograms of LightGBM 3.3.1).
-Asserted: the repaired label of EVERY dirty cell is the same, every probability is within north_star's 1e-4, and -- since numerics
-v2.1 (fixed-point grid of up to 2^50 per value instead of 2^40: every float32 gradient of these tables is on the grid exactly) -- every
-tree of all 300 iterations is IDENTICAL on every table measured, hospital's 55- and 303-class attributes included (v2.0: first
-differing tree at iteration 116 / 33, max |dp| 4.2e-3, because its 2^40 grid rounded the small gradients).
+Asserted: the repaired label of EVERY dirty cell is the same, every probability is within north_star's 1e-4, and every tree of all 300
+iterations is IDENTICAL on every table measured, hospital's 55- and 303-class attributes included (v2.0: first differing tree at iteration
+116 / 33, max |dp| 4.2e-3, because its 2^40 grid rounded the small gradients) -- since round 6 also on the grids a 10M- / 100M-row table
+of the same kind gets (second half of this file).
 tools/numerics_bound.py prints the full table (profiles/r04a_*); profiles/r03b_* is the v2.0 table and
 profiles/r03a_* the one of the round-1/2 numerics (2^-20 fixed point + hessian from the quantised gradient), which failed this test."""
 import numpy as np
