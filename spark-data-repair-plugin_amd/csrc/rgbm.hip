@@ -1068,6 +1068,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             if (MT_RT_GLOBAL) d_rtg.alloc(std::max<size_t>(prog_words, 1) * MT_MAX_RT);      // (experiment: a global copy of every workgroup's route table)
         }
         d_node.alloc((size_t)K * lc.NS);
+        // the padding rows [N, NS) of every class tree stay LV_INACTIVE for the whole fit (the gradient kernels reset rows < N only): the level pass
+        // routes rows by their id alone, and an id past the end of a class tree's table takes the dummy entry
+        HIPCHK(hipMemsetAsync(d_node.p, 0xFF, (size_t)K * lc.NS, s));
         d_plan.alloc(K); d_snodes.alloc((size_t)K * 256); d_lcand.alloc((size_t)K * 256 * F);
         d_part.alloc(part_items * tc.totbins); d_lpool.alloc((size_t)K * n_hnodes * tc.totbins);
         d_count.alloc((size_t)K * 256); use_reduce = dp || lc.gx > 4;
@@ -1263,9 +1266,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const dim3 grid((unsigned)L.G * (unsigned)L.gx);
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
-#define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, ...) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, __VA_ARGS__>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+#define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, ...) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, __VA_ARGS__>), grid, dim3(THR), LV_LDS_BYTES /* (always the CU's whole LDS: the hessian sums sit a compile-time distance behind the gradient sums; lc.lds_bytes, the test hook, only sizes the histograms) */, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
                                                                           d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, d_rtg.p, l1); \
-                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, __VA_ARGS__>), grid, dim3(THR), lc.lds_bytes, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
+                                           else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, __VA_ARGS__>), grid, dim3(THR), LV_LDS_BYTES, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
                                                                    d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, d_rtg.p, l1); } while (0)
 #define RGBM_LAUNCH_MT(NCHR, THR, ACC, ...) do { if (use_bagging) RGBM_LAUNCH_MT2(NCHR, true, d_inbag.p, THR, ACC, __VA_ARGS__); else RGBM_LAUNCH_MT2(NCHR, false, nullptr, THR, ACC, __VA_ARGS__); } while (0)
                 if (L.acc2) { if (sw.mt_spec != 0 && L.rot) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true, true); else if (sw.mt_spec != 0) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true); else RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, false); }

@@ -177,7 +177,7 @@ constexpr int LV_ROOT_FIXED = 256;
 // filter + one dense step (~430 with the gathers) per 64 groups of 4 rows that hold a live row, against ~330 per 256 rows tile by tile:
 // break-even near 18 % live rows
 constexpr long long MT_SPARSE_DIV = MT_SPARSE_DIV_N;
-__host__ __device__ inline long long mt_fixed_bytes(int threads, bool acc2, bool spec = false) {
+__host__ __device__ constexpr long long mt_fixed_bytes(int threads, bool acc2, bool spec = false) {
     return ((!acc2 && !spec) ? (long long)MT_MAX_T * 8 /* live-node masks of the sparse sweep */ : 0) + (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 + (long long)MT_MAX_NODES * 8 +
            (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * mt_ring(spec) * ((acc2 ? 32 : 16) + 8 + 2) + 256;     // (consumer waves have no ring)
 }
@@ -422,8 +422,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     off = (off + 15) & ~(size_t)15;
     unsigned long long* xmask = reinterpret_cast<unsigned long long*>(smem + off);            // [MT_MAX_T] sparse sweep: bit i = node base + i of the class tree is live
     if (!ACC2 && !SPEC) off += (size_t)MT_MAX_T * 8;                                            // (reserved for every plain pass: mt_fixed_bytes)
-    unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem + off);     // [total][spn] gradient sums, then [total][spn] hessian sums (see k_level_root)
-    const long long avail = (long long)c.lds_bytes - (long long)off;
+    unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem + off);     // [total][spn] gradient sums; the hessian sums [total][spn] (see k_level_root) start
+    // MT_HD bytes further on: a COMPILE-TIME distance, half of what the instantiation's fixed part leaves of the CU's LDS, so that the second atomic of a
+    // (g, h) pair is the first one's address register with an immediate offset (one VALU per feature and batch less than with a run-time distance)
+    constexpr int MT_HD = (int)(((LV_LDS_TOTAL - mt_fixed_bytes(THREADS, ACC2, SPEC)) / 2) & ~15ll);
+    long long avail = (long long)c.lds_bytes - (long long)off;
+    if (avail > 2ll * MT_HD) avail = 2ll * MT_HD;
+    if (tid == 0 && (long long)off + 2ll * MT_HD > (long long)LV_LDS_TOTAL) atomicOr(err_flag, 2);     // (never: mt_fixed_bytes covers the carve-up above)
 
     // ---- the class trees of this workgroup and their built slots inside this launch's window
     if (tid < 64) {   // wave 0: lane kk reads the plan of class tree k0 + kk; exclusive prefix sums place its built slots and table entries
@@ -447,10 +452,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             const long long lr = route ? (long long)pp->live_rows : 0ll;     // (later launches of a level: not sparse -- they look for the built children)
             sparse_t = route && lr * MT_SPARSE_DIV < pp->n_in && c.mt_sparse != 0;
         }
-        int inc_nb = t.nb, inc_rt = t.nlev;
+        // entries of the class tree in the LDS table.  A ROUTING launch indexes its table by the node id itself: entries [0, child_first) -- the
+        // nodes of the older levels and the unexpanded ones route to themselves -- plus ONE dummy entry at child_first that every larger id
+        // (only LV_INACTIVE occurs) is clamped to and that routes to LV_INACTIVE: the row loop needs no "is the row in a node of this level" test,
+        // no subtraction and no select -- the entry alone says where the row goes.  <= 2^L entries per class tree = what the host sizes T for.
+        const int ntab = route ? (lane < nk ? (t.live ? t.child_first : 0) + 1 : 0) : t.nlev;
+        int inc_nb = t.nb, inc_rt = ntab;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(inc_nb, o), b2 = __shfl_up(inc_rt, o); if (lane >= o) { inc_nb += a; inc_rt += b2; } }
-        t.slot0 = inc_nb - t.nb; t.rt_off = inc_rt - t.nlev;
+        t.slot0 = inc_nb - t.nb; t.rt_off = inc_rt - ntab;
         const int total = __shfl(inc_nb, 63), rt_total = __shfl(inc_rt, 63);
         const unsigned long long livem = __ballot(t.live != 0);
         // the host sizes T for the worst case of the level (2^(L-1) expanded parents per class tree), so this always holds; if it ever did
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         const unsigned long long below = (1ull << lane) - 1ull;
         const int pos = lane >= nk ? lane : (sparse_t ? nkd_ + __popcll(smask & below) : __popcll(dmask & below));
         if (lane < nk) ti[pos] = t;
-        tpk[pos] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
+        tpk[pos] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (uint32_t)(route && ntab > 0 ? ntab - 1 : 0) << 17 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
         if (lane < 2) tpk[64 + lane] = make_uint2(0u, 0u);
         if (SPARSE) xmask[lane] = 0ull;
         if (lane == 0) {
@@ -485,13 +495,17 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     for (int kk = 0; kk < nk; ++kk) {
         const MtTree t = ti[kk];
         const LvPlan* pp = &plan[t.k];
-        for (int i = tid; i < t.nlev; i += THREADS) {
-            const int n = t.base + i;
+        const int ntab_k = route ? (t.live ? t.child_first : 0) + 1 : t.nlev;
+        for (int i = tid; i < ntab_k; i += THREADS) {
+            const int n = route ? i : t.base + i;
             uint2 e;
             if (route) {
                 // LDS copy of the route table, specialised: built slots become workgroup-local (0xFF = that child's histogram is not built
-                // in this launch) and an unexpanded node routes to itself
-                const uint32_t w0 = pp->route0[n]; const uint32_t w1 = pp->route1[n];
+                // in this launch) and an unexpanded node routes to itself.  Entry layout (what the row loop's instructions want):
+                //   x: byte 0 = the split byte's index inside its half record (f & 7; NCHR == 0: the feature) | thr << 8 | off << 16 | expanded << 24 |
+                //      second record << 30 | upper half of the record << 31;   y: left child | left built slot << 8 | right child << 16 | right built slot << 24
+                const bool cur = i < ntab_k - 1 && n >= t.base;         // a node of the level being split (older ids: finished leaves; the last entry: the dummy)
+                const uint32_t w0 = cur ? pp->route0[n] : 0u; const uint32_t w1 = cur ? pp->route1[n] : 0u;
                 if (w0 & (1u << 24)) {
                     const int ls = (int)((w1 >> 16) & 0xFFu) - c.mt_slot0, rs = (int)(w1 >> 24) - c.mt_slot0;
                     const bool lb = ((w1 >> 16) & 0xFFu) != 0xFFu && ls >= 0 && ls < t.nb, rbb = (w1 >> 24) != 0xFFu && rs >= 0 && rs < t.nb;
@@ -506,10 +520,14 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                     if (nanbin != 255u && dleft) { offb = nanbin; thr = (theta1 - 1u - nanbin) & 0xFFu; }
                     else if (theta1 == 0u) { offb = 255u; thr = 0u; }
                     else { offb = 0u; thr = theta1 - 1u; }
-                    e = make_uint2((w0 & 0xFFu) | thr << 8 | offb << 16 | 1u << 24,
-                                   (w1 & 0xFFFFu) | (lb ? (uint32_t)(t.slot0 + ls) : 0xFFu) << 16 | (rbb ? (uint32_t)(t.slot0 + rs) : 0xFFu) << 24);
-                    if (SPARSE && kk >= nkd && i < 64) atomicOr(&xmask[kk], 1ull << i);
-                } else e = make_uint2(0u, (uint32_t)n | (uint32_t)n << 8 | 0xFFFF0000u);
+                    const uint32_t f = w0 & 0xFFu;
+                    e = make_uint2((NCHR == 0 ? f : (f & 7u) | ((f >> 4) & 1u) << 30 | ((f >> 3) & 1u) << 31) | thr << 8 | offb << 16 | 1u << 24,
+                                   (w1 & 0xFFu) | (lb ? (uint32_t)(t.slot0 + ls) : 0xFFu) << 8 | ((w1 >> 8) & 0xFFu) << 16 | (rbb ? (uint32_t)(t.slot0 + rs) : 0xFFu) << 24);
+                    if (SPARSE && kk >= nkd && n - t.base < 64) atomicOr(&xmask[kk], 1ull << (n - t.base));
+                } else {
+                    const uint32_t self = i < ntab_k - 1 ? (uint32_t)n : (uint32_t)LV_INACTIVE;
+                    e = make_uint2(0u, self | 0xFF00u | self << 16 | 0xFF000000u);
+                }
             } else {
                 // children are numbered child_first + 2 ei (left), + 1 (right); one of the two is built, in slot ei
                 const int ei = i >> 1, ls = ei - c.mt_slot0;
@@ -523,8 +541,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     }
     for (int i = tid; i < total * MT_CNT_REP; i += THREADS) cnt[i] = 0;
     if (tid < 48) rsync[tid] = 0u;            // (before the barrier below)
-    unsigned long long* hist_h = hist_g + (size_t)total * spn;
-    for (int i = tid; i < 2 * total * spn; i += THREADS) hist_g[i] = 0ull;
+    unsigned long long* hist_h = hist_g + MT_HD / 8;
+    for (int i = tid; i < total * spn; i += THREADS) { hist_g[i] = 0ull; hist_h[i] = 0ull; }
     // per accumulated feature: replication shift (scalar) and this lane's byte offset inside a node's slots (first slot + replica)
     // the shifts, 4 bits each, packed into one 64-bit SCALAR per chunk (16 separate scalars cost the row loop ~80 spill reloads per step)
     unsigned long long sh3p[NACC];
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pk >> 32)) << 32;
         }
     }
-    const int hdelta = total * spn;
+    constexpr int hdelta = MT_HD / 8;
     __syncthreads();
 #if MT_RT_GLOBAL
     // the route table of this workgroup, once more in global memory: the row loop's lookups then travel through the vector memory pipeline
@@ -771,6 +789,17 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         const uint32_t tq0 = tq.x, tq1 = tq.y;       // scalar (tree_entry)
         const uint32_t base = tq0 & 0xFFu, nlev = (tq0 >> 8) & 0x1FFu, rt_off = tq1 & 0xFFFFu;
         inm = 0u;
+        if (ROUTE) {   // the table is indexed by the node id; ids past its end (LV_INACTIVE) take the dummy entry
+            const uint32_t tabn = (tq0 >> 17) & 0xFFu;
+            // (rows past the end of the table and the idle lanes of a sparse batch carry LV_INACTIVE: the node-id arrays are padded with it)
+            const uint2* rtk = rt + rt_off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t id = (n4 >> (8 * j)) & 0xFFu;
+                e[j] = rtk[id < tabn ? id : tabn];
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t idx = ((n4 >> (8 * j)) & 0xFFu) - base;
@@ -786,36 +815,36 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     // route the four rows, append the built ones to the ring (and, in the plain pass, run the batches)
     auto stage_c = [&](const long long row0 /* first of the lane's four rows */, const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t bagmask, uint32_t n4, const float4 g0, const float4 g1,
                        const uint2 (&e)[4], uint32_t inm, const uint2 tq) __attribute__((always_inline)) {
-        if (__ballot(inm != 0u) == 0ull) return;               // no row of this wave tile sits in a node of the level (or the tree is finished)
+        if (ROUTE) { if ((tq.x >> 31) == 0u) return; }           // (scalar) the class tree is finished or has nothing to split at this level
+        else if (__ballot(inm != 0u) == 0ull) return;            // no row of this wave tile sits in a built child of this launch
         uint32_t out4 = n4;
+        uint32_t selv[4];
         const float gg[4] = {g0.x, g0.z, g1.x, g1.z}, hh[4] = {g0.y, g0.w, g1.y, g1.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool in = ((inm >> j) & 1u) != 0u;
             unsigned li;
             bool built;
             if (ROUTE) {
+                // every row takes the entry it looked up: a row outside the level's nodes got an entry that routes to itself (or the dummy) and has no built slot
                 const uint32_t ex = e[j].x, ey = e[j].y;
-                const bool expd = in && (ex & (1u << 24)) != 0u;
-                const unsigned f = ex & 0xFFu;
                 unsigned bin;
                 if (NCHR == 0) {
                     bin = 0u;
-                    if (expd) bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)];
+                    if (ex & (1u << 24)) { const unsigned f = ex & 0xFFu; bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)]; }
                 } else {
                     uint32_t rx = ra[j].x, ry = ra[j].y, rz = ra[j].z, rw = ra[j].w;
-                    if (NCHR == 2) { const bool second = (f >> 4) != 0u; rx = second ? r1[j].x : rx; ry = second ? r1[j].y : ry; rz = second ? r1[j].z : rz; rw = second ? r1[j].w : rw; }
-                    const bool hi = (f & 8u) != 0u;
+                    if (NCHR == 2) { const bool second = (ex & (1u << 30)) != 0u; rx = second ? r1[j].x : rx; ry = second ? r1[j].y : ry; rz = second ? r1[j].z : rz; rw = second ? r1[j].w : rw; }
+                    const bool hi = (int32_t)ex < 0;
                     const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
-                    bin = __builtin_amdgcn_perm(hi32, lo32, (f & 7u) | 0x0C0C0C00u);   // byte (f & 15) of the record
+                    bin = __builtin_amdgcn_perm(hi32, lo32, ex) & 0xFFu;      // selector byte 0 = f & 7: byte (f & 15) of the record (the other result bytes are not used)
                 }
-                // left = (bin == nan bin) ? default-left : (bin <= theta), as one byte compare (the route entry holds off and thr: see above)
                 const bool left = ((bin - ((ex >> 16) & 0xFFu)) & 0xFFu) <= ((ex >> 8) & 0xFFu);
-                const unsigned sel = left ? ey : (ey >> 8);           // child in bits 0..7, workgroup-local built slot in bits 16..23
-                out4 = expd ? ((out4 & ~(0xFFu << (8 * j))) | ((sel & 0xFFu) << (8 * j))) : out4;
-                li = (sel >> 16) & 0xFFu;
-                built = expd && li != 0xFFu;
+                const uint32_t sel = left ? (ey & 0xFFFFu) : (ey >> 16);          // child in bits 0..7, workgroup-local built slot in bits 8..15
+                selv[j] = sel;
+                li = sel >> 8;
+                built = li != 0xFFu;
             } else {
+                const bool in = ((inm >> j) & 1u) != 0u;
                 li = e[j].y & 0xFFu;
                 built = in && e[j].x != 0u;
             }
@@ -835,10 +864,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                 // waiting ones: those leave first, as a partial batch (never taken with 128 entries: <= 63 wait, <= 64 arrive)
                 if (!SPEC && MT_RING < 128 && r_cnt + (int)__popcll(m) > MT_RING) run_batch(r_cnt);
                 if (built) {
-                    const int pos = SPEC ? (int)((p_tail + (uint32_t)__popcll(m & lane_lt)) & (uint32_t)(MT_RING - 1))
-                                         : (r_head + r_cnt + (int)__popcll(m & lane_lt)) & (MT_RING - 1);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));     // built lanes below this one
+                    const int pos = SPEC ? (int)((p_tail + below) & (uint32_t)(MT_RING - 1)) : (r_head + r_cnt + (int)below) & (MT_RING - 1);
                     uint4 q0 = ra[j], q1 = r1[j];
-                    if (li_in_rec) { if (ACC2) q1.w = (q1.w & 0x00FFFFFFu) | (li << 24); else q0.w = (q0.w & 0x00FFFFFFu) | (li << 24); }
+                    // (one v_perm: bytes 0..2 of the word, the slot as byte 3)
+                    if (li_in_rec) { if (ACC2) q1.w = __builtin_amdgcn_perm(li, q1.w, 0x04020100u); else q0.w = __builtin_amdgcn_perm(li, q0.w, 0x04020100u); }
                     else ring_li[pos] = (uint16_t)li;
                     ring_rec[pos] = q0;
                     if (ACC2) ring_rec1[pos] = q1;
@@ -849,7 +879,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             }
         }
         if (SPEC) { asm volatile("" ::: "memory"); if (lane == 0) RS_STORE(wave, p_tail); }     // publish (after the entries: in-order LDS)
-        if (ROUTE && out4 != n4) __builtin_nontemporal_store(out4, reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0));
+        if (ROUTE) {   // the four child bytes side by side
+            out4 = __builtin_amdgcn_perm(selv[1], selv[0], 0x0C0C0400u) | __builtin_amdgcn_perm(selv[3], selv[2], 0x04000C0Cu);
+            if (out4 != n4) __builtin_nontemporal_store(out4, reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0));
+        }
     };
 
     if (SPEC) {
@@ -981,7 +1014,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                         if (BAG) bagmask |= (inbag[rr] ? 1u : 0u) << j;
                         if (on && row0 + j < N) rowmask |= 1u << j;
                     }
-                    const uint32_t n4 = *reinterpret_cast<const uint32_t*>(nd_k + row0);
+                    const uint32_t n4 = on ? *reinterpret_cast<const uint32_t*>(nd_k + row0) : 0xFFFFFFFFu;     // (idle lanes: LV_INACTIVE, the dummy entry)
                     const float4 g0 = *reinterpret_cast<const float4*>(gh_k + row0), g1 = *reinterpret_cast<const float4*>(gh_k + row0 + 2);
                     uint2 e[4]; uint32_t inm = 0u;
                     lookup(n4, tq, rowmask, e, inm);
