@@ -68,6 +68,9 @@ constexpr int MT_THREADS_ACC2 = 768;
 #ifndef MT_RT_GLOBAL
 #define MT_RT_GLOBAL 0        // experiment (round 6): the row loop of k_level_mt reads its route entries from a per-workgroup GLOBAL copy of the table (vector
 #endif                        // memory) instead of from LDS, so that routing never queues behind the histogram atomics in the CU's in-order LDS pipeline
+#ifndef MT_FLAT_PIPE
+#define MT_FLAT_PIPE 1        // round 6: the routing launch of the plain pass runs one software pipeline over all its steps, its load register sets rotate by name
+#endif
 #ifndef MT_SCALAR_TILE
 #define MT_SCALAR_TILE 0      // experiment (round 6): the wave index of k_level_mt through readfirstlane, whole tiles without clamps -- see profiles/EXPERIMENTS.md
 #endif
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         }
     }
 
-    const int my_ring = wave < NRINGS ? wave : 0;               // (consumer waves never append)
+    const int my_ring = __builtin_amdgcn_readfirstlane(wave < NRINGS ? wave : 0);               // (consumer waves never append; scalar: the ring bases live in SGPRs)
     uint4* ring_rec = ring_rec_all + my_ring * MT_RING;
     uint4* ring_rec1 = ring_rec1_all + my_ring * MT_RING;
     uint2* ring_gh = ring_gh_all + my_ring * MT_RING;
@@ -812,44 +815,45 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
 #endif
         }
     };
-    // route the four rows, append the built ones to the ring (and, in the plain pass, run the batches)
-    auto stage_c = [&](const long long row0 /* first of the lane's four rows */, const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t bagmask, uint32_t n4, const float4 g0, const float4 g1,
-                       const uint2 (&e)[4], uint32_t inm, const uint2 tq) __attribute__((always_inline)) {
-        if (ROUTE) { if ((tq.x >> 31) == 0u) return; }           // (scalar) the class tree is finished or has nothing to split at this level
-        else if (__ballot(inm != 0u) == 0ull) return;            // no row of this wave tile sits in a built child of this launch
-        uint32_t out4 = n4;
+    // ---- stage C of a step, in two halves: route4 (pure VALU: where do the four rows go, which of them fall into a built child) and append4 (the built rows
+    // go to the wave's ring; in the plain pass full batches leave it as histogram updates).  Between the two the flat pipeline issues the route
+    // lookups of the NEXT step into the same registers the entries of this step just left.
+    // route4 (routing launch): liv[j] = workgroup-local built slot of row j's child, 0xFF = not built; the new node ids are stored
+    auto route4 = [&](const long long row0 /* first of the lane's four rows */, const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t n4, const uint2 (&e)[4], const uint2 tq,
+                      uint32_t (&liv)[4]) __attribute__((always_inline)) {
         uint32_t selv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // every row takes the entry it looked up: a row outside the level's nodes got an entry that routes to itself (or the dummy) and has no built slot
+            const uint32_t ex = e[j].x, ey = e[j].y;
+            unsigned bin;
+            if (NCHR == 0) {
+                bin = 0u;
+                if (ex & (1u << 24)) { const unsigned f = ex & 0xFFu; bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)]; }
+            } else {
+                uint32_t rx = ra[j].x, ry = ra[j].y, rz = ra[j].z, rw = ra[j].w;
+                if (NCHR == 2) { const bool second = (ex & (1u << 30)) != 0u; rx = second ? r1[j].x : rx; ry = second ? r1[j].y : ry; rz = second ? r1[j].z : rz; rw = second ? r1[j].w : rw; }
+                const bool hi = (int32_t)ex < 0;
+                const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
+                bin = __builtin_amdgcn_perm(hi32, lo32, ex) & 0xFFu;      // selector byte 0 = f & 7: byte (f & 15) of the record (the other result bytes are not used)
+            }
+            // left = (bin == nan bin) ? default-left : (bin <= theta), as one byte compare (the route entry holds off and thr: see the table fill)
+            const bool left = ((bin - ((ex >> 16) & 0xFFu)) & 0xFFu) <= ((ex >> 8) & 0xFFu);
+            selv[j] = left ? (ey & 0xFFFFu) : (ey >> 16);          // child in bits 0..7, workgroup-local built slot in bits 8..15
+            liv[j] = selv[j] >> 8;
+        }
+        // the four child bytes side by side
+        const uint32_t out4 = __builtin_amdgcn_perm(selv[1], selv[0], 0x0C0C0400u) | __builtin_amdgcn_perm(selv[3], selv[2], 0x04000C0Cu);
+        if (out4 != n4) __builtin_nontemporal_store(out4, reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0));
+    };
+    auto append4 = [&](const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t bagmask, const float4 g0, const float4 g1, const uint32_t (&liv)[4]) __attribute__((always_inline)) {
         const float gg[4] = {g0.x, g0.z, g1.x, g1.z}, hh[4] = {g0.y, g0.w, g1.y, g1.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsigned li;
-            bool built;
-            if (ROUTE) {
-                // every row takes the entry it looked up: a row outside the level's nodes got an entry that routes to itself (or the dummy) and has no built slot
-                const uint32_t ex = e[j].x, ey = e[j].y;
-                unsigned bin;
-                if (NCHR == 0) {
-                    bin = 0u;
-                    if (ex & (1u << 24)) { const unsigned f = ex & 0xFFu; bin = rec8[((long long)(f >> 4) * N + row0 + j) * 16 + (f & 15u)]; }
-                } else {
-                    uint32_t rx = ra[j].x, ry = ra[j].y, rz = ra[j].z, rw = ra[j].w;
-                    if (NCHR == 2) { const bool second = (ex & (1u << 30)) != 0u; rx = second ? r1[j].x : rx; ry = second ? r1[j].y : ry; rz = second ? r1[j].z : rz; rw = second ? r1[j].w : rw; }
-                    const bool hi = (int32_t)ex < 0;
-                    const uint32_t lo32 = hi ? rz : rx, hi32 = hi ? rw : ry;
-                    bin = __builtin_amdgcn_perm(hi32, lo32, ex) & 0xFFu;      // selector byte 0 = f & 7: byte (f & 15) of the record (the other result bytes are not used)
-                }
-                const bool left = ((bin - ((ex >> 16) & 0xFFu)) & 0xFFu) <= ((ex >> 8) & 0xFFu);
-                const uint32_t sel = left ? (ey & 0xFFFFu) : (ey >> 16);          // child in bits 0..7, workgroup-local built slot in bits 8..15
-                selv[j] = sel;
-                li = sel >> 8;
-                built = li != 0xFFu;
-            } else {
-                const bool in = ((inm >> j) & 1u) != 0u;
-                li = e[j].y & 0xFFu;
-                built = in && e[j].x != 0u;
-            }
+            const unsigned li = liv[j];
+            bool built = li != 0xFFu;
             if (BAG) built = built && ((bagmask >> j) & 1u);
-            const unsigned long long m = __ballot(built);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(built);
             if (m != 0ull) {                                      // uniform
                 if (SPEC) {   // room for this row step's entries?  (the consumer is at most one batch behind a full ring)
                     const uint32_t n_new = (uint32_t)__popcll(m);
@@ -879,10 +883,20 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             }
         }
         if (SPEC) { asm volatile("" ::: "memory"); if (lane == 0) RS_STORE(wave, p_tail); }     // publish (after the entries: in-order LDS)
-        if (ROUTE) {   // the four child bytes side by side
-            out4 = __builtin_amdgcn_perm(selv[1], selv[0], 0x0C0C0400u) | __builtin_amdgcn_perm(selv[3], selv[2], 0x04000C0Cu);
-            if (out4 != n4) __builtin_nontemporal_store(out4, reinterpret_cast<uint32_t*>(node + (long long)(tq.y >> 16) * NS + row0));
+    };
+    // both halves back to back (the per-tile pipelines: wave-specialised producer, sparse batches, the later launches of a level)
+    auto stage_c = [&](const long long row0, const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t bagmask, uint32_t n4, const float4 g0, const float4 g1,
+                       const uint2 (&e)[4], uint32_t inm, const uint2 tq) __attribute__((always_inline)) {
+        uint32_t liv[4];
+        if (ROUTE) {
+            if ((tq.x >> 31) == 0u) return;           // (scalar) the class tree is finished or has nothing to split at this level
+            route4(row0, ra, r1, n4, e, tq, liv);
+        } else {
+            if (__ballot(inm != 0u) == 0ull) return;            // no row of this wave tile sits in a built child of this launch
+#pragma unroll
+            for (int j = 0; j < 4; ++j) liv[j] = (((inm >> j) & 1u) != 0u && e[j].x != 0u) ? (e[j].y & 0xFFu) : 0xFFu;
         }
+        append4(ra, r1, bagmask, g0, g1, liv);
     };
 
     if (SPEC) {
@@ -957,6 +971,64 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     } else {
         // ---- plain pass: per wave tile, a pipeline over the class trees of the workgroup (node ids, g, h requested two trees ahead)
         const int nkw = SPARSE ? nkd : nk;          // class trees walked tile by tile
+#if MT_FLAT_PIPE
+        // ---- routing launch: ONE software pipeline over all steps of the wave (tile-major, class trees inside).  What bounds the pass is the number of
+        // bytes a CU keeps in flight (round 6: a wave's loads were waited for at the end of the step that issued them -- the register copies of a
+        // rotating pipeline need the loaded values -- so a CU held ~1 step x 16 waves = 37 KB in flight for half of the time: 2.2 TB/s).  Here the
+        // three register sets of (node ids, g, h) rotate by NAME (the loop body is written three times), so a set loaded in step q is first touched
+        // in step q + 1 (node ids: the route lookup) / q + 2 (g, h): two whole steps in flight, also across wave tiles; the records of the next tile
+        // are requested when the last class tree of a tile has been routed.
+        if (ROUTE) {
+            // (the wave index through readfirstlane: tile numbers, step counters and everything derived from them are then SCALAR -- as a VGPR value
+            // the compiler keeps the whole step bookkeeping in 64-bit VALU operations)
+            const long long my_first = wt_lo + __builtin_amdgcn_readfirstlane(wave);
+            const long long ntile_w = (nkw > 0 && my_first < wt_hi) ? (wt_hi - my_first + WAVES - 1) / WAVES : 0;
+            const long long Q = ntile_w * nkw;
+            if (Q > 0) {
+                struct TS { uint32_t n4; float4 g0, g1; };
+                TS S0, S1, S2;
+                uint2 e_cur[4]; uint32_t in_dummy = 0u;
+                bool cross = false;                                                               // (uniform) the step about to start is the first of a wave tile: its records wait in rn
+                long long wt_c = my_first, wt_n = my_first, wt_l = my_first; int kk_c = 0, kk_n = 0, kk_l = 0;     // steps q, min(q + 1, Q - 1), min(q + 2, Q - 1)
+                auto fwd = [&](long long& wt, int& kk) __attribute__((always_inline)) { if (++kk == nkw) { kk = 0; wt += WAVES; } };
+                if (Q > 1) fwd(wt_n, kk_n);
+                wt_l = wt_n; kk_l = kk_n;
+                if (Q > 2) fwd(wt_l, kk_l);
+                uint4 ra[4], r1[4], rn[4], r1n[4]; uint32_t bagmask, bagmask_n = 0u;
+                load_rec(wt_c, ra, r1, bagmask);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { rn[j] = ra[j]; r1n[j] = r1[j]; }
+                load_tree(wt_c, kk_c, S0.n4, S0.g0, S0.g1);
+                load_tree(wt_n, kk_n, S1.n4, S1.g0, S1.g1);
+                lookup(S0.n4, tree_entry(kk_c), 0xFu, e_cur, in_dummy);
+                long long q = 0;
+                auto step = [&](TS& cur, TS& nxt, TS& in) __attribute__((always_inline)) {
+                    if (cross) {      // (before this step's loads are requested: what has to have arrived is at least a step old)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { ra[j] = rn[j]; r1[j] = r1n[j]; }
+                        bagmask = bagmask_n;
+                    }
+                    load_tree(wt_l, kk_l, in.n4, in.g0, in.g1);                              // step q + 2 (past the end: the last step once more, never used)
+                    if (kk_c == 0 && wt_c + WAVES < wt_hi) load_rec(wt_c + WAVES, rn, r1n, bagmask_n);     // (uniform) first step of a wave tile: the records of the wave's next tile
+                    const uint2 tq_c = tree_entry(kk_c);
+                    const bool live = (tq_c.x >> 31) != 0u;                                  // (scalar) else: the class tree is finished or has nothing to split at this level
+                    uint32_t liv[4] = {0xFFu, 0xFFu, 0xFFu, 0xFFu};
+                    if (live) route4(wt_c * MT_WT_ROWS + lane * 4, ra, r1, cur.n4, e_cur, tq_c, liv);
+                    lookup(nxt.n4, tree_entry(kk_n), 0xFu, e_cur, in_dummy);                 // step q + 1, into the registers this step's entries just left
+                    if (live) append4(ra, r1, bagmask, cur.g0, cur.g1, liv);
+                    cross = wt_n != wt_c;
+                    wt_c = wt_n; kk_c = kk_n; wt_n = wt_l; kk_n = kk_l;
+                    if (q + 3 < Q) fwd(wt_l, kk_l);
+                    ++q;
+                };
+                while (q < Q) {
+                    step(S0, S1, S2);
+                    if (q < Q) step(S1, S2, S0);
+                    if (q < Q) step(S2, S0, S1);
+                }
+            }
+        } else
+#endif
         if (nkw > 0)
         for (long long wt = wt_lo + wave; wt < wt_hi; wt += WAVES) {
             uint4 ra[4], r1[4]; uint32_t bagmask;
