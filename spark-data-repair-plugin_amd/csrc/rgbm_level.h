@@ -899,8 +899,100 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         append4(ra, r1, bagmask, g0, g1, liv);
     };
 
-    if (SPEC) {
-        // ---- producer wave: ONE software pipeline over all its steps (tile-major, class trees inside), so that a wave always has the
+    constexpr bool FLAT = MT_FLAT_PIPE != 0 && ROUTE;       // the routing launch (plain and wave-specialised) runs the flat pipeline below
+    // ---- lock-step of the class-tree groups of a row block (round 5; wave-specialised pass; off by default).  Every group's workgroup reads the block's bin
+    // records; they run on one XCD at the same time (launch order), but nothing keeps them at the same place: on the 100M x 32 shape the groups
+    // drifted further apart than the XCD's 4 MB L2 holds and a level pass moved 25.5 GB for 8.3 GB of (node id, g, h) stream and
+    // 3.2 GB of records (profiles/traffic.json, round 4).  Wave 0 of a workgroup publishes the tile round it is in (a word per
+    // (row block, group), tagged with the launch's epoch), and every producer wave looks at the block's words every MT_LOCK_EVERY
+    // rounds: it sleeps while the slowest group that HAS STARTED in this launch and has not finished is more than mt_window rounds
+    // behind.  The slowest started group never waits, so the wait ends; a group that is not resident yet is not waited for.
+    // Measured: -63 % fetch, +23 % time (profiles/r5e_*): the pass is not bound by that traffic.
+    const bool lock = SPEC && c.mt_window > 0 && prog != nullptr && c.mt_G > 1;
+    uint32_t* prog_rb = prog + (size_t)rb * (size_t)c.mt_G;
+    const uint32_t ep_tag = c.mt_epoch << 20;
+    auto lock_step = [&](const uint32_t round) __attribute__((always_inline)) {
+        if ((round & (MT_LOCK_EVERY - 1)) != 0u) return;
+        if (wave == 0 && lane == 0) __hip_atomic_store(prog_rb + grp, ep_tag | (round < 0xFFFFEu ? round + 1u : 0xFFFFEu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; spin < 4096; ++spin) {        // (bounded: a lost update can cost time, never the pass)
+            uint32_t slow = 0xFFFFFFFFu;
+            for (int g0 = 0; g0 < c.mt_G; g0 += 64) {
+                uint32_t v = 0xFFFFFFFFu;
+                if (g0 + lane < c.mt_G) {
+                    const uint32_t w = __hip_atomic_load(prog_rb + g0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((w >> 20) == c.mt_epoch && (w & 0xFFFFFu) != 0xFFFFFu) v = w & 0xFFFFFu;     // started in this launch, not finished
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { const uint32_t v2 = (uint32_t)__shfl_xor((int)v, o); v = v2 < v ? v2 : v; }
+                slow = v < slow ? v : slow;
+            }
+            if (slow == 0xFFFFFFFFu || round + 1u <= slow + (uint32_t)c.mt_window) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+    };
+
+        // ---- routing launch: ONE software pipeline over all steps of the wave (tile-major, class trees inside).  What bounds the pass is the number of
+        // bytes a CU keeps in flight (round 6: a wave's loads were waited for at the end of the step that issued them -- the register copies of a
+        // rotating pipeline need the loaded values -- so a CU held ~1 step x 16 waves = 37 KB in flight for half of the time: 2.2 TB/s).  Here the
+        // three register sets of (node ids, g, h) rotate by NAME (the loop body is written three times), so a set loaded in step q is first touched
+        // in step q + 1 (node ids: the route lookup) / q + 2 (g, h): two whole steps in flight, also across wave tiles; the records of the next tile
+        // are requested when the last class tree of a tile has been routed.
+    if (FLAT && wave < NPROD) {
+        const int nkw = (!SPEC && SPARSE) ? nkd : nk;          // class trees walked tile by tile (the sparse ones are swept below)
+        {
+            // (the wave index through readfirstlane: tile numbers, step counters and everything derived from them are then SCALAR -- as a VGPR value
+            // the compiler keeps the whole step bookkeeping in 64-bit VALU operations)
+            const long long my_first = wt_lo + __builtin_amdgcn_readfirstlane(wave);
+            const long long ntile_w = (nkw > 0 && my_first < wt_hi) ? (wt_hi - my_first + NPROD - 1) / NPROD : 0;
+            const long long Q = ntile_w * nkw;
+            if (Q > 0) {
+                struct TS { uint32_t n4; float4 g0, g1; };
+                TS S0, S1, S2;
+                uint2 e_cur[4]; uint32_t in_dummy = 0u;
+                bool cross = false;                                                               // (uniform) the step about to start is the first of a wave tile: its records wait in rn
+                long long wt_c = my_first, wt_n = my_first, wt_l = my_first; int kk_c = 0, kk_n = 0, kk_l = 0;     // steps q, min(q + 1, Q - 1), min(q + 2, Q - 1)
+                auto fwd = [&](long long& wt, int& kk) __attribute__((always_inline)) { if (++kk == nkw) { kk = 0; wt += NPROD; } };
+                if (Q > 1) fwd(wt_n, kk_n);
+                wt_l = wt_n; kk_l = kk_n;
+                if (Q > 2) fwd(wt_l, kk_l);
+                uint4 ra[4], r1[4], rn[4], r1n[4]; uint32_t bagmask, bagmask_n = 0u;
+                load_rec(wt_c, ra, r1, bagmask);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { rn[j] = ra[j]; r1n[j] = r1[j]; }
+                load_tree(wt_c, kk_c, S0.n4, S0.g0, S0.g1);
+                load_tree(wt_n, kk_n, S1.n4, S1.g0, S1.g1);
+                lookup(S0.n4, tree_entry(kk_c), 0xFu, e_cur, in_dummy);
+                long long q = 0;
+                auto step = [&](TS& cur, TS& nxt, TS& in) __attribute__((always_inline)) {
+                    if (SPEC && lock && kk_c == 0) lock_step((uint32_t)((wt_c - my_first) / NPROD));
+                    if (cross) {      // (before this step's loads are requested: what has to have arrived is at least a step old)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { ra[j] = rn[j]; r1[j] = r1n[j]; }
+                        bagmask = bagmask_n;
+                    }
+                    load_tree(wt_l, kk_l, in.n4, in.g0, in.g1);                              // step q + 2 (past the end: the last step once more, never used)
+                    if (kk_c == 0 && wt_c + NPROD < wt_hi) load_rec(wt_c + NPROD, rn, r1n, bagmask_n);     // (uniform) first step of a wave tile: the records of the wave's next tile
+                    const uint2 tq_c = tree_entry(kk_c);
+                    const bool live = (tq_c.x >> 31) != 0u;                                  // (scalar) else: the class tree is finished or has nothing to split at this level
+                    uint32_t liv[4] = {0xFFu, 0xFFu, 0xFFu, 0xFFu};
+                    if (live) route4(wt_c * MT_WT_ROWS + lane * 4, ra, r1, cur.n4, e_cur, tq_c, liv);
+                    lookup(nxt.n4, tree_entry(kk_n), 0xFu, e_cur, in_dummy);                 // step q + 1, into the registers this step's entries just left
+                    if (live) append4(ra, r1, bagmask, cur.g0, cur.g1, liv);
+                    cross = wt_n != wt_c;
+                    wt_c = wt_n; kk_c = kk_n; wt_n = wt_l; kk_n = kk_l;
+                    if (q + 3 < Q) fwd(wt_l, kk_l);
+                    ++q;
+                };
+                while (q < Q) {
+                    step(S0, S1, S2);
+                    if (q < Q) step(S1, S2, S0);
+                    if (q < Q) step(S2, S0, S1);
+                }
+            }
+        }
+    }
+    if (SPEC) { if (!FLAT) {
+        // ---- producer wave (the later launches of a level): ONE software pipeline over all its steps (tile-major, class trees inside), so that a wave always has the
         // loads of two further steps in flight -- also when the workgroup holds a single class tree (deep levels: T = 1), where a
         // per-tile pipeline has nothing to prefetch and every tile costs a full memory + LDS round trip (Little's law: 16 waves x one
         // 6 KB step in flight per CU sustained ~3 TB/s).  Per iteration, in this order and unconditionally:
@@ -923,38 +1015,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             load_tree(wt_c, kk_c, n4_a, ga0, ga1);
             load_tree(wt_b, kk_b, n4_b, gb0, gb1);
             lookup(n4_a, tree_entry(kk_c), row_mask(wt_c), e_a, in_a);
-            // ---- lock-step of the class-tree groups of a row block (round 5).  Every group's workgroup reads the block's bin records; they
-            // run on one XCD at the same time (launch order), but nothing keeps them at the same place: on the 100M x 32 shape the groups
-            // drifted further apart than the XCD's 4 MB L2 holds and a level pass moved 25.5 GB for 8.3 GB of (node id, g, h) stream and
-            // 3.2 GB of records (profiles/traffic.json, round 4).  Now wave 0 of a workgroup publishes the tile round it is in (a word per
-            // (row block, group), tagged with the launch's epoch), and every producer wave looks at the block's words every MT_LOCK_EVERY
-            // rounds: it sleeps while the slowest group that HAS STARTED in this launch and has not finished is more than mt_window rounds
-            // behind.  The slowest started group never waits, so the wait ends; a group that is not resident yet is not waited for.
-            const bool lock = c.mt_window > 0 && prog != nullptr && c.mt_G > 1;
-            uint32_t* prog_rb = prog + (size_t)rb * (size_t)c.mt_G;
-            const uint32_t ep_tag = c.mt_epoch << 20;
             for (long long q = 0; q < Q; ++q) {
-                if (lock && kk_c == 0) {
-                    const uint32_t round = (uint32_t)((wt_c - my_first) / NPROD);
-                    if ((round & (MT_LOCK_EVERY - 1)) == 0u) {
-                        if (wave == 0 && lane == 0) __hip_atomic_store(prog_rb + grp, ep_tag | (round < 0xFFFFEu ? round + 1u : 0xFFFFEu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        for (int spin = 0; spin < 4096; ++spin) {        // (bounded: a lost update can cost time, never the pass)
-                            uint32_t slow = 0xFFFFFFFFu;
-                            for (int g0 = 0; g0 < c.mt_G; g0 += 64) {
-                                uint32_t v = 0xFFFFFFFFu;
-                                if (g0 + lane < c.mt_G) {
-                                    const uint32_t w = __hip_atomic_load(prog_rb + g0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    if ((w >> 20) == c.mt_epoch && (w & 0xFFFFFu) != 0xFFFFFu) v = w & 0xFFFFFu;     // started in this launch, not finished
-                                }
-#pragma unroll
-                                for (int o = 32; o >= 1; o >>= 1) { const uint32_t v2 = (uint32_t)__shfl_xor((int)v, o); v = v2 < v ? v2 : v; }
-                                slow = v < slow ? v : slow;
-                            }
-                            if (slow == 0xFFFFFFFFu || round + 1u <= slow + (uint32_t)c.mt_window) break;
-                            __builtin_amdgcn_s_sleep(32);
-                        }
-                    }
-                }
+                if (lock && kk_c == 0) lock_step((uint32_t)((wt_c - my_first) / NPROD));
                 load_rec(wt_b, rn, r1n, bag_n);                                        // stage R
                 load_tree(wt_a, kk_a, n4_c, gc0, gc1);                                 // stage A
                 lookup(n4_b, tree_entry(kk_b), row_mask(wt_b), e_b, in_b);             // stage B
@@ -968,67 +1030,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                 if (q + 3 < Q) step_fwd(wt_a, kk_a);
             }
         }
-    } else {
+    } } else {
         // ---- plain pass: per wave tile, a pipeline over the class trees of the workgroup (node ids, g, h requested two trees ahead)
         const int nkw = SPARSE ? nkd : nk;          // class trees walked tile by tile
-#if MT_FLAT_PIPE
-        // ---- routing launch: ONE software pipeline over all steps of the wave (tile-major, class trees inside).  What bounds the pass is the number of
-        // bytes a CU keeps in flight (round 6: a wave's loads were waited for at the end of the step that issued them -- the register copies of a
-        // rotating pipeline need the loaded values -- so a CU held ~1 step x 16 waves = 37 KB in flight for half of the time: 2.2 TB/s).  Here the
-        // three register sets of (node ids, g, h) rotate by NAME (the loop body is written three times), so a set loaded in step q is first touched
-        // in step q + 1 (node ids: the route lookup) / q + 2 (g, h): two whole steps in flight, also across wave tiles; the records of the next tile
-        // are requested when the last class tree of a tile has been routed.
-        if (ROUTE) {
-            // (the wave index through readfirstlane: tile numbers, step counters and everything derived from them are then SCALAR -- as a VGPR value
-            // the compiler keeps the whole step bookkeeping in 64-bit VALU operations)
-            const long long my_first = wt_lo + __builtin_amdgcn_readfirstlane(wave);
-            const long long ntile_w = (nkw > 0 && my_first < wt_hi) ? (wt_hi - my_first + WAVES - 1) / WAVES : 0;
-            const long long Q = ntile_w * nkw;
-            if (Q > 0) {
-                struct TS { uint32_t n4; float4 g0, g1; };
-                TS S0, S1, S2;
-                uint2 e_cur[4]; uint32_t in_dummy = 0u;
-                bool cross = false;                                                               // (uniform) the step about to start is the first of a wave tile: its records wait in rn
-                long long wt_c = my_first, wt_n = my_first, wt_l = my_first; int kk_c = 0, kk_n = 0, kk_l = 0;     // steps q, min(q + 1, Q - 1), min(q + 2, Q - 1)
-                auto fwd = [&](long long& wt, int& kk) __attribute__((always_inline)) { if (++kk == nkw) { kk = 0; wt += WAVES; } };
-                if (Q > 1) fwd(wt_n, kk_n);
-                wt_l = wt_n; kk_l = kk_n;
-                if (Q > 2) fwd(wt_l, kk_l);
-                uint4 ra[4], r1[4], rn[4], r1n[4]; uint32_t bagmask, bagmask_n = 0u;
-                load_rec(wt_c, ra, r1, bagmask);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { rn[j] = ra[j]; r1n[j] = r1[j]; }
-                load_tree(wt_c, kk_c, S0.n4, S0.g0, S0.g1);
-                load_tree(wt_n, kk_n, S1.n4, S1.g0, S1.g1);
-                lookup(S0.n4, tree_entry(kk_c), 0xFu, e_cur, in_dummy);
-                long long q = 0;
-                auto step = [&](TS& cur, TS& nxt, TS& in) __attribute__((always_inline)) {
-                    if (cross) {      // (before this step's loads are requested: what has to have arrived is at least a step old)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { ra[j] = rn[j]; r1[j] = r1n[j]; }
-                        bagmask = bagmask_n;
-                    }
-                    load_tree(wt_l, kk_l, in.n4, in.g0, in.g1);                              // step q + 2 (past the end: the last step once more, never used)
-                    if (kk_c == 0 && wt_c + WAVES < wt_hi) load_rec(wt_c + WAVES, rn, r1n, bagmask_n);     // (uniform) first step of a wave tile: the records of the wave's next tile
-                    const uint2 tq_c = tree_entry(kk_c);
-                    const bool live = (tq_c.x >> 31) != 0u;                                  // (scalar) else: the class tree is finished or has nothing to split at this level
-                    uint32_t liv[4] = {0xFFu, 0xFFu, 0xFFu, 0xFFu};
-                    if (live) route4(wt_c * MT_WT_ROWS + lane * 4, ra, r1, cur.n4, e_cur, tq_c, liv);
-                    lookup(nxt.n4, tree_entry(kk_n), 0xFu, e_cur, in_dummy);                 // step q + 1, into the registers this step's entries just left
-                    if (live) append4(ra, r1, bagmask, cur.g0, cur.g1, liv);
-                    cross = wt_n != wt_c;
-                    wt_c = wt_n; kk_c = kk_n; wt_n = wt_l; kk_n = kk_l;
-                    if (q + 3 < Q) fwd(wt_l, kk_l);
-                    ++q;
-                };
-                while (q < Q) {
-                    step(S0, S1, S2);
-                    if (q < Q) step(S1, S2, S0);
-                    if (q < Q) step(S2, S0, S1);
-                }
-            }
-        } else
-#endif
+        if (!(MT_FLAT_PIPE && ROUTE))
         if (nkw > 0)
         for (long long wt = wt_lo + wave; wt < wt_hi; wt += WAVES) {
             uint4 ra[4], r1[4]; uint32_t bagmask;
