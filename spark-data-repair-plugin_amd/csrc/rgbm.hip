@@ -574,7 +574,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // numerics v2.2 from a pass of their own instead of out of the gradient kernels), RGBM_TEST_HOOKS=1 + RGBM_FX_ROWS=R (TEST hook: the fixed-point grid of a
 // table of R rows; the oracle reads the same pair; a warning goes to stderr when it is active).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than mt_rot_copies2 / 2 = THREE copies of the launch's worst-case histograms (default), 0 = never, 1 = every pass that has the instantiation */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 6 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (6 = three copies) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fx_separate = false /* RGBM_FX_MEASURE=separate: the coarse sums behind every class tree's fixed-point grid come from a pass of their own over the (g, h) array (k_fx_measure) instead of out of the gradient kernels -- same sums, same models; the tests run both */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than mt_rot_copies2 / 2 = EIGHT copies of the launch's worst-case histograms (default), 0 = never, 1 = every pass that has the instantiation */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 16 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (16 = eight copies: every launch that cannot have the eight copies the replicated layout is sized for; round 5 had 6 -- the flat pipeline of round 6 moved the balance, profiles/r6r_*) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fx_separate = false /* RGBM_FX_MEASURE=separate: the coarse sums behind every class tree's fixed-point grid come from a pass of their own over the (g, h) array (k_fx_measure) instead of out of the gradient kernels -- same sums, same models; the tests run both */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -945,7 +945,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     LevelConst lc; memset(&lc, 0, sizeof(lc));
     DevBuf<uint8_t> d_node; DevBuf<LvPlan> d_plan; DevBuf<SNode> d_snodes; DevBuf<Cand> d_lcand;
     DevBuf<HistBin> d_part, d_lpool; DevBuf<int32_t> d_count, d_count_g, d_err, d_leafnode; DevBuf<HistBin> d_part_red; DevBuf<double> d_ndelta; DevBuf<unsigned long long> d_statrows;
-    DevBuf<uint2> d_rtg;
     DevBuf<uint32_t> d_prog; uint32_t mt_epoch = 0;   // lock-step progress words of the wave-specialised level pass: [row blocks][tree groups]
     int n_hnodes = 1;
     bool use_reduce = false;   // root pass: sum the per-workgroup partials in a separate kernel (many workgroups per class tree, joint bins, or row-sharded)
@@ -1023,7 +1022,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 // re-read come out of the XCD's L2 (all class tree groups of a row block run on one XCD at the same time).
                 const long long rep_target = std::max(1, sw.mt_rep);
                 const long long t_nodes = std::max<long long>(win, cap / rep_target);
-                int T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(t_nodes / win, MT_MAX_T), std::min<long long>(K, MT_MAX_RT / (2 * worst))));
+                int T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(t_nodes / win, MT_MAX_T), std::min<long long>(K, MT_RT_BUDGET / (2 * worst))));
                 if (sw.mt_T >= 1) T = std::max(1, std::min(T, sw.mt_T));
                 // Feature rotation of the histogram updates (rgbm_level.h, MT_ROT) for the launches whose LDS holds fewer than three copies of their
                 // worst-case histograms -- the deepest dense levels, where rows of one cluster pile up on one address per feature: measured -11 % at
@@ -1037,7 +1036,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 // a rotated launch needs ONE copy: as many class trees per workgroup as the LDS holds (RGBM_MT_ROT_T=0: keep the T sized for replication)
                 if (rot && sw.mt_rot_T && sw.mt_T < 1) {
                     const long long cap_rot = std::min<long long>((lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec)) / (node_bytes + mt_rot_dummy(true) * 16), MT_MAX_NODES);
-                    T = (int)std::max<long long>(T, std::min<long long>(std::min<long long>(cap_rot / win, MT_MAX_T), std::min<long long>(K, MT_MAX_RT / (2 * worst))));
+                    T = (int)std::max<long long>(T, std::min<long long>(std::min<long long>(cap_rot / win, MT_MAX_T), std::min<long long>(K, MT_RT_BUDGET / (2 * worst))));
                 }
                 const int G = (K + T - 1) / T;
                 if (ch == 0) G_first = G;
@@ -1065,7 +1064,6 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             size_t prog_words = 0;
             for (int level = 1; level < p.max_depth; ++level) for (const auto& L : mt_plan[level]) prog_words = std::max(prog_words, (size_t)L.G * (size_t)L.gx);
             d_prog.alloc(std::max<size_t>(prog_words, 1)); d_prog.zero(s);
-            if (MT_RT_GLOBAL) d_rtg.alloc(std::max<size_t>(prog_words, 1) * MT_MAX_RT);      // (experiment: a global copy of every workgroup's route table)
         }
         d_node.alloc((size_t)K * lc.NS);
         // the padding rows [N, NS) of every class tree stay LV_INACTIVE for the whole fit (the gradient kernels reset rows < N only): the level pass
@@ -1267,9 +1265,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             const int nchr = nchunk == 1 ? 1 : (nchunk == 2 ? 2 : 0);
             timed(false, [&]() {
 #define RGBM_LAUNCH_MT2(NCHR, BAG, INBAG, THR, ACC, ...) do { if (L.route) hipLaunchKernelGGL((k_level_mt<NCHR, BAG, true, THR, ACC, __VA_ARGS__>), grid, dim3(THR), LV_LDS_BYTES /* (always the CU's whole LDS: the hessian sums sit a compile-time distance behind the gradient sums; lc.lds_bytes, the test hook, only sizes the histograms) */, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, d_rtg.p, l1); \
+                                                                          d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, l1); \
                                            else hipLaunchKernelGGL((k_level_mt<NCHR, BAG, false, THR, ACC, __VA_ARGS__>), grid, dim3(THR), LV_LDS_BYTES, s, d_rec.p, d_gh.p, d_node.p, (const uint8_t*)(INBAG), d_plan.p, \
-                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, d_rtg.p, l1); } while (0)
+                                                                   d_part.p, d_count.p, d_fmeta.p, d_cmeta.p, d_err.p, d_prog.p, d_fxs.p, l1); } while (0)
 #define RGBM_LAUNCH_MT(NCHR, THR, ACC, ...) do { if (use_bagging) RGBM_LAUNCH_MT2(NCHR, true, d_inbag.p, THR, ACC, __VA_ARGS__); else RGBM_LAUNCH_MT2(NCHR, false, nullptr, THR, ACC, __VA_ARGS__); } while (0)
                 if (L.acc2) { if (sw.mt_spec != 0 && L.rot) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true, true); else if (sw.mt_spec != 0) RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, true); else RGBM_LAUNCH_MT(2, MT_THREADS_ACC2, true, false); }
                 else if (nchr == 1 && sw.mt_spec == 1) RGBM_LAUNCH_MT(1, LV_THREADS, false, true);

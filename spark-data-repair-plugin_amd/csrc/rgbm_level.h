@@ -51,7 +51,8 @@ constexpr int LV_MAX_LEAVES = 128;
 // multi-tree level pass (k_level_mt)
 constexpr int MT_MAX_T = 64;                 // class trees per workgroup
 constexpr int MT_MAX_NODES = 128;            // built nodes per workgroup (all its class trees together)
-constexpr int MT_MAX_RT = 256;               // route / child-lookup entries per workgroup (<= 2^L per class tree)
+constexpr int MT_RT_BUDGET = 256;            // table entries the host sizes T for: 2^L per class tree (the nodes so far / the children of the level)
+constexpr int MT_MAX_RT = MT_RT_BUDGET + MT_MAX_T;      // ... + one dummy entry per class tree (ids past the end of a table are clamped to it)
 constexpr int MT_WT_ROWS = 256;              // rows of one wave tile: 4 consecutive rows per lane
 #ifndef MT_RING_N
 #define MT_RING_N 128
@@ -64,15 +65,6 @@ constexpr int MT_CNT_REP = 8;
 constexpr int MT_THREADS_ACC2 = 768;
 #ifndef MT_CONSUMERS_N
 #define MT_CONSUMERS_N 4
-#endif
-#ifndef MT_RT_GLOBAL
-#define MT_RT_GLOBAL 0        // experiment (round 6): the row loop of k_level_mt reads its route entries from a per-workgroup GLOBAL copy of the table (vector
-#endif                        // memory) instead of from LDS, so that routing never queues behind the histogram atomics in the CU's in-order LDS pipeline
-#ifndef MT_FLAT_PIPE
-#define MT_FLAT_PIPE 1        // round 6: the routing launch of the plain pass runs one software pipeline over all its steps, its load register sets rotate by name
-#endif
-#ifndef MT_SCALAR_TILE
-#define MT_SCALAR_TILE 0      // experiment (round 6): the wave index of k_level_mt through readfirstlane, whole tiles without clamps -- see profiles/EXPERIMENTS.md
 #endif
 constexpr int MT_LOCK_EVERY = 4;              // lock-step: tile rounds between two looks at the row block's progress words
 constexpr int MT_CONSUMERS = MT_CONSUMERS_N;              // wave-specialised pass: consumer waves of a workgroup (one per SIMD)         // workgroup of a two-chunk pass: 12 waves with 168 VGPRs each (two records per row stay in registers), a third less ring
@@ -365,8 +357,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                                                          const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                          int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,
                                                          int32_t* __restrict__ err_flag, uint32_t* __restrict__ prog /* [row blocks][tree groups] lock-step progress words (SPEC), or null */,
-                                                         const FxScale* __restrict__ fxs /* [K] this iteration's grid per class tree */,
-                                                         uint2* __restrict__ rt_glob /* MT_RT_GLOBAL: [gridDim.x][MT_MAX_RT] scratch */, LevelConst c) {
+                                                         const FxScale* __restrict__ fxs /* [K] this iteration's grid per class tree */, LevelConst c) {
     static_assert(!ACC2 || NCHR == 2, "a two-chunk pass keeps both records in registers");
     constexpr int WAVES = THREADS / 64;
     constexpr int NCONS = SPEC ? MT_CONSUMERS : 0, NPROD = WAVES - NCONS;     // waves that walk the rows / waves that only run batches
@@ -383,14 +374,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     const int grp = bslot % c.mt_G, rb = (bslot / c.mt_G) * 8 + xl;
     const int k0 = grp * c.mt_T;
     const int nk = (c.K - k0) < c.mt_T ? (c.K - k0) : c.mt_T;
-    // (the wave index through readfirstlane: a wave's tile numbers and everything derived from them -- row bases, the tile-is-full test -- are then
-    // SCALAR: address arithmetic on the scalar unit, a per-lane 32-bit offset in the loads; as a VGPR value it cost the row loop ~40 64-bit VALU
-    // operations per wave tile)
-#if MT_SCALAR_TILE
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-#else
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#endif
     const int ch = ACC2 ? 0 : c.mt_ch;
     constexpr bool route = ROUTE;
     const ChunkMeta cm = cmeta[ch];
@@ -459,7 +443,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         // nodes of the older levels and the unexpanded ones route to themselves -- plus ONE dummy entry at child_first that every larger id
         // (only LV_INACTIVE occurs) is clamped to and that routes to LV_INACTIVE: the row loop needs no "is the row in a node of this level" test,
         // no subtraction and no select -- the entry alone says where the row goes.  <= 2^L entries per class tree = what the host sizes T for.
-        const int ntab = route ? (lane < nk ? (t.live ? t.child_first : 0) + 1 : 0) : t.nlev;
+        // A LATER launch of a level (more chunks / built-slot windows) looks for the rows of ITS built children by the final node ids: entries
+        // [0, 2 n_exp) for the children (indexed id - child_first) and the same dummy behind them (an id below child_first wraps around to a large index).
+        const int ntab = lane < nk ? (route ? (t.live ? t.child_first : 0) : t.nlev) + 1 : 0;
         int inc_nb = t.nb, inc_rt = ntab;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(inc_nb, o), b2 = __shfl_up(inc_rt, o); if (lane >= o) { inc_nb += a; inc_rt += b2; } }
@@ -476,7 +462,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         const unsigned long long below = (1ull << lane) - 1ull;
         const int pos = lane >= nk ? lane : (sparse_t ? nkd_ + __popcll(smask & below) : __popcll(dmask & below));
         if (lane < nk) ti[pos] = t;
-        tpk[pos] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (uint32_t)(route && ntab > 0 ? ntab - 1 : 0) << 17 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
+        tpk[pos] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (uint32_t)(ntab > 0 ? ntab - 1 : 0) << 17 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
         if (lane < 2) tpk[64 + lane] = make_uint2(0u, 0u);
         if (SPARSE) xmask[lane] = 0ull;
         if (lane == 0) {
@@ -498,7 +484,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     for (int kk = 0; kk < nk; ++kk) {
         const MtTree t = ti[kk];
         const LvPlan* pp = &plan[t.k];
-        const int ntab_k = route ? (t.live ? t.child_first : 0) + 1 : t.nlev;
+        const int ntab_k = (route ? (t.live ? t.child_first : 0) : t.nlev) + 1;
         for (int i = tid; i < ntab_k; i += THREADS) {
             const int n = route ? i : t.base + i;
             uint2 e;
@@ -532,9 +518,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                     e = make_uint2(0u, self | 0xFF00u | self << 16 | 0xFF000000u);
                 }
             } else {
-                // children are numbered child_first + 2 ei (left), + 1 (right); one of the two is built, in slot ei
+                // children are numbered child_first + 2 ei (left), + 1 (right); one of the two is built, in slot ei.  y = the workgroup-local slot of a child
+                // built by THIS launch, else 0xFF (every other child, the dummy)
                 const int ei = i >> 1, ls = ei - c.mt_slot0;
-                const bool mine = (pp->built_is_left[ei] ? 0 : 1) == (i & 1) && ls >= 0 && ls < t.nb;
+                const bool mine = i < ntab_k - 1 && (pp->built_is_left[ei] ? 0 : 1) == (i & 1) && ls >= 0 && ls < t.nb;
                 e = make_uint2(mine ? 1u : 0u, mine ? (uint32_t)(t.slot0 + ls) : 0xFFu);
             }
             rt[t.rt_off + i] = e;
@@ -574,14 +561,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     }
     constexpr int hdelta = MT_HD / 8;
     __syncthreads();
-#if MT_RT_GLOBAL
-    // the route table of this workgroup, once more in global memory: the row loop's lookups then travel through the vector memory pipeline
-    // (vmcnt) and do not wait behind this wave's -- and every other wave's -- LDS atomics (the LDS pipeline of a CU serves in order)
-    uint2* rt_g = rt_glob + (size_t)blockIdx.x * MT_MAX_RT;
-    for (int i = tid; i < MT_MAX_RT; i += THREADS) rt_g[i] = rt[i];
-    __threadfence();
-    __syncthreads();
-#endif
     // feature rotation (MT_ROT): lane l works on feature slot (j + l) mod 16 in step j.  cj[a][j] becomes the byte offset of THAT feature's
     // first slot (+ the lane's replica l / 16), or of the lane's dummy slot when the chunk has no such feature; rmask[a] zeroes the bytes of
     // the rotated record that are not features, so that a masked lane adds to bin 0 of its dummy slot.
@@ -747,17 +726,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         const long long tile0 = wt * MT_WT_ROWS;                 // scalar
         bagmask = 0xFu;
         if (BAG) bagmask = 0u;
-        if (MT_SCALAR_TILE && tile0 + MT_WT_ROWS <= N) {         // (uniform) a whole tile: scalar base + the lane's constant offset, no clamps
-            const uint4* rp = rec_acc + tile0; const uint4* rp1 = rec + N + tile0; const uint8_t* bp = inbag + tile0;
-            const unsigned lo = (unsigned)lane * 4u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = rp[lo + j];
-                if (ACC2 || (route && NCHR == 2)) r1[j] = rp1[lo + j]; else r1[j] = make_uint4(0, 0, 0, 0);
-                if (BAG) bagmask |= (bp[lo + j] ? 1u : 0u) << j;
-            }
-            return;
-        }
         const long long row0 = tile0 + lane * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -779,40 +747,18 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp)), b2 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gp + 2));
         g0 = make_float4(a.x, a.y, a.z, a.w); g1 = make_float4(b2.x, b2.y, b2.z, b2.w);
     };
-    auto row_mask = [&](long long wt) __attribute__((always_inline)) -> uint32_t {
-        if (MT_SCALAR_TILE && (wt + 1) * MT_WT_ROWS <= N) return 0xFu;             // (uniform) a whole tile
-        const long long row0 = wt * MT_WT_ROWS + lane * 4;
-        uint32_t m = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (row0 + j < N) m |= 1u << j;
-        return m;
-    };
-    // table indices of the four rows -> LDS reads of their route entries
-    auto lookup = [&](uint32_t n4, const uint2 tq, uint32_t rowmask, uint2 (&e)[4], uint32_t& inm) __attribute__((always_inline)) {
+    // table indices of the four rows -> LDS reads of their entries.  A routing launch indexes by the node id, a later launch by id - child_first; whatever lies
+    // past the end of the class tree's table -- LV_INACTIVE, which also pads the node-id arrays behind the last row and fills the idle lanes of a sparse
+    // batch -- is clamped to the dummy entry: no "is the row in a node of this level" test, no row mask, no select.
+    auto lookup = [&](uint32_t n4, const uint2 tq, uint2 (&e)[4]) __attribute__((always_inline)) {
         const uint32_t tq0 = tq.x, tq1 = tq.y;       // scalar (tree_entry)
-        const uint32_t base = tq0 & 0xFFu, nlev = (tq0 >> 8) & 0x1FFu, rt_off = tq1 & 0xFFFFu;
-        inm = 0u;
-        if (ROUTE) {   // the table is indexed by the node id; ids past its end (LV_INACTIVE) take the dummy entry
-            const uint32_t tabn = (tq0 >> 17) & 0xFFu;
-            // (rows past the end of the table and the idle lanes of a sparse batch carry LV_INACTIVE: the node-id arrays are padded with it)
-            const uint2* rtk = rt + rt_off;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t id = (n4 >> (8 * j)) & 0xFFu;
-                e[j] = rtk[id < tabn ? id : tabn];
-            }
-            return;
-        }
+        const uint32_t base = tq0 & 0xFFu, tabn = (tq0 >> 17) & 0xFFu, rt_off = tq1 & 0xFFFFu;
+        const uint2* rtk = rt + rt_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t idx = ((n4 >> (8 * j)) & 0xFFu) - base;
-            const bool in = (tq0 >> 31) != 0u && idx < nlev && ((rowmask >> j) & 1u);
-            inm |= in ? (1u << j) : 0u;
-#if MT_RT_GLOBAL
-            e[j] = rt_g[rt_off + (in ? idx : 0u)];
-#else
-            e[j] = rt[rt_off + (in ? idx : 0u)];
-#endif
+            uint32_t id = (n4 >> (8 * j)) & 0xFFu;
+            if (!ROUTE) id -= base;                  // (unsigned: an id below the children wraps around and is clamped as well)
+            e[j] = rtk[id < tabn ? id : tabn];
         }
     };
     // ---- stage C of a step, in two halves: route4 (pure VALU: where do the four rows go, which of them fall into a built child) and append4 (the built rows
@@ -884,22 +830,19 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         }
         if (SPEC) { asm volatile("" ::: "memory"); if (lane == 0) RS_STORE(wave, p_tail); }     // publish (after the entries: in-order LDS)
     };
-    // both halves back to back (the per-tile pipelines: wave-specialised producer, sparse batches, the later launches of a level)
+    // both halves back to back (the batches of the sparse sweep)
     auto stage_c = [&](const long long row0, const uint4 (&ra)[4], const uint4 (&r1)[4], uint32_t bagmask, uint32_t n4, const float4 g0, const float4 g1,
-                       const uint2 (&e)[4], uint32_t inm, const uint2 tq) __attribute__((always_inline)) {
+                       const uint2 (&e)[4], const uint2 tq) __attribute__((always_inline)) {
+        if ((tq.x >> 31) == 0u) return;           // (scalar) the class tree is finished or has nothing to split at this level
         uint32_t liv[4];
-        if (ROUTE) {
-            if ((tq.x >> 31) == 0u) return;           // (scalar) the class tree is finished or has nothing to split at this level
-            route4(row0, ra, r1, n4, e, tq, liv);
-        } else {
-            if (__ballot(inm != 0u) == 0ull) return;            // no row of this wave tile sits in a built child of this launch
+        if (ROUTE) route4(row0, ra, r1, n4, e, tq, liv);
+        else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) liv[j] = (((inm >> j) & 1u) != 0u && e[j].x != 0u) ? (e[j].y & 0xFFu) : 0xFFu;
+            for (int j = 0; j < 4; ++j) liv[j] = e[j].y & 0xFFu;
         }
         append4(ra, r1, bagmask, g0, g1, liv);
     };
 
-    constexpr bool FLAT = MT_FLAT_PIPE != 0 && ROUTE;       // the routing launch (plain and wave-specialised) runs the flat pipeline below
     // ---- lock-step of the class-tree groups of a row block (round 5; wave-specialised pass; off by default).  Every group's workgroup reads the block's bin
     // records; they run on one XCD at the same time (launch order), but nothing keeps them at the same place: on the 100M x 32 shape the groups
     // drifted further apart than the XCD's 4 MB L2 holds and a level pass moved 25.5 GB for 8.3 GB of (node id, g, h) stream and
@@ -937,7 +880,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         // three register sets of (node ids, g, h) rotate by NAME (the loop body is written three times), so a set loaded in step q is first touched
         // in step q + 1 (node ids: the route lookup) / q + 2 (g, h): two whole steps in flight, also across wave tiles; the records of the next tile
         // are requested when the last class tree of a tile has been routed.
-    if (FLAT && wave < NPROD) {
+    if (wave < NPROD) {
         const int nkw = (!SPEC && SPARSE) ? nkd : nk;          // class trees walked tile by tile (the sparse ones are swept below)
         {
             // (the wave index through readfirstlane: tile numbers, step counters and everything derived from them are then SCALAR -- as a VGPR value
@@ -948,7 +891,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             if (Q > 0) {
                 struct TS { uint32_t n4; float4 g0, g1; };
                 TS S0, S1, S2;
-                uint2 e_cur[4]; uint32_t in_dummy = 0u;
+                uint2 e_cur[4];
                 bool cross = false;                                                               // (uniform) the step about to start is the first of a wave tile: its records wait in rn
                 long long wt_c = my_first, wt_n = my_first, wt_l = my_first; int kk_c = 0, kk_n = 0, kk_l = 0;     // steps q, min(q + 1, Q - 1), min(q + 2, Q - 1)
                 auto fwd = [&](long long& wt, int& kk) __attribute__((always_inline)) { if (++kk == nkw) { kk = 0; wt += NPROD; } };
@@ -961,7 +904,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                 for (int j = 0; j < 4; ++j) { rn[j] = ra[j]; r1n[j] = r1[j]; }
                 load_tree(wt_c, kk_c, S0.n4, S0.g0, S0.g1);
                 load_tree(wt_n, kk_n, S1.n4, S1.g0, S1.g1);
-                lookup(S0.n4, tree_entry(kk_c), 0xFu, e_cur, in_dummy);
+                lookup(S0.n4, tree_entry(kk_c), e_cur);
                 long long q = 0;
                 auto step = [&](TS& cur, TS& nxt, TS& in) __attribute__((always_inline)) {
                     if (SPEC && lock && kk_c == 0) lock_step((uint32_t)((wt_c - my_first) / NPROD));
@@ -975,8 +918,12 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                     const uint2 tq_c = tree_entry(kk_c);
                     const bool live = (tq_c.x >> 31) != 0u;                                  // (scalar) else: the class tree is finished or has nothing to split at this level
                     uint32_t liv[4] = {0xFFu, 0xFFu, 0xFFu, 0xFFu};
-                    if (live) route4(wt_c * MT_WT_ROWS + lane * 4, ra, r1, cur.n4, e_cur, tq_c, liv);
-                    lookup(nxt.n4, tree_entry(kk_n), 0xFu, e_cur, in_dummy);                 // step q + 1, into the registers this step's entries just left
+                    if (ROUTE) { if (live) route4(wt_c * MT_WT_ROWS + lane * 4, ra, r1, cur.n4, e_cur, tq_c, liv); }
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) liv[j] = e_cur[j].y & 0xFFu;
+                    }
+                    lookup(nxt.n4, tree_entry(kk_n), e_cur);                                  // step q + 1, into the registers this step's entries just left
                     if (live) append4(ra, r1, bagmask, cur.g0, cur.g1, liv);
                     cross = wt_n != wt_c;
                     wt_c = wt_n; kk_c = kk_n; wt_n = wt_l; kk_n = kk_l;
@@ -991,74 +938,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             }
         }
     }
-    if (SPEC) { if (!FLAT) {
-        // ---- producer wave (the later launches of a level): ONE software pipeline over all its steps (tile-major, class trees inside), so that a wave always has the
-        // loads of two further steps in flight -- also when the workgroup holds a single class tree (deep levels: T = 1), where a
-        // per-tile pipeline has nothing to prefetch and every tile costs a full memory + LDS round trip (Little's law: 16 waves x one
-        // 6 KB step in flight per CU sustained ~3 TB/s).  Per iteration, in this order and unconditionally:
-        //   stage R (step q + 1): the tile's records;   stage A (step q + 2): node ids + (g, h);
-        //   stage B (step q + 1): route-table lookups;   stage C (step q): route + append.
-        // Past the last step the stages re-load the last step (never used), which keeps the loop body branch-free for the loads.
-        const long long my_first = wt_lo + wave;
-        const long long ntile_w = (wave < NPROD && my_first < wt_hi) ? (wt_hi - my_first + NPROD - 1) / NPROD : 0;
-        const long long Q = ntile_w * nk;
-        if (Q > 0) {
-            auto step_fwd = [&](long long& wt, int& kk) __attribute__((always_inline)) { if (++kk == nk) { kk = 0; wt += NPROD; } };
-            long long wt_c = my_first, wt_b = my_first, wt_a = my_first; int kk_c = 0, kk_b = 0, kk_a = 0;   // steps q, min(q + 1, Q - 1), min(q + 2, Q - 1)
-            if (Q > 1) step_fwd(wt_b, kk_b);
-            wt_a = wt_b; kk_a = kk_b;
-            if (Q > 2) step_fwd(wt_a, kk_a);
-            uint4 ra[4], r1[4], rn[4], r1n[4]; uint32_t bag_c, bag_n;
-            uint32_t n4_a, n4_b, n4_c; float4 ga0, ga1, gb0, gb1, gc0, gc1;
-            uint2 e_a[4], e_b[4]; uint32_t in_a = 0u, in_b = 0u;
-            load_rec(wt_c, ra, r1, bag_c);
-            load_tree(wt_c, kk_c, n4_a, ga0, ga1);
-            load_tree(wt_b, kk_b, n4_b, gb0, gb1);
-            lookup(n4_a, tree_entry(kk_c), row_mask(wt_c), e_a, in_a);
-            for (long long q = 0; q < Q; ++q) {
-                if (lock && kk_c == 0) lock_step((uint32_t)((wt_c - my_first) / NPROD));
-                load_rec(wt_b, rn, r1n, bag_n);                                        // stage R
-                load_tree(wt_a, kk_a, n4_c, gc0, gc1);                                 // stage A
-                lookup(n4_b, tree_entry(kk_b), row_mask(wt_b), e_b, in_b);             // stage B
-                stage_c(wt_c * MT_WT_ROWS + lane * 4, ra, r1, bag_c, n4_a, ga0, ga1, e_a, in_a, tree_entry(kk_c));   // stage C
-                // rotate
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { ra[j] = rn[j]; r1[j] = r1n[j]; e_a[j] = e_b[j]; }
-                bag_c = bag_n; in_a = in_b;
-                n4_a = n4_b; ga0 = gb0; ga1 = gb1; n4_b = n4_c; gb0 = gc0; gb1 = gc1;
-                wt_c = wt_b; kk_c = kk_b; wt_b = wt_a; kk_b = kk_a;
-                if (q + 3 < Q) step_fwd(wt_a, kk_a);
-            }
-        }
-    } } else {
-        // ---- plain pass: per wave tile, a pipeline over the class trees of the workgroup (node ids, g, h requested two trees ahead)
-        const int nkw = SPARSE ? nkd : nk;          // class trees walked tile by tile
-        if (!(MT_FLAT_PIPE && ROUTE))
-        if (nkw > 0)
-        for (long long wt = wt_lo + wave; wt < wt_hi; wt += WAVES) {
-            uint4 ra[4], r1[4]; uint32_t bagmask;
-            load_rec(wt, ra, r1, bagmask);
-            const uint32_t rowmask = row_mask(wt);
-            uint32_t n4_a = 0xFFFFFFFFu, n4_b = 0xFFFFFFFFu; float4 ga0, ga1, gb0, gb1;
-            ga0 = ga1 = gb0 = gb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint2 tq_a = tree_entry(0), tq_b = tree_entry(1);
-            load_tree(wt, 0, n4_a, ga0, ga1);
-            if (nkw > 1) load_tree(wt, 1, n4_b, gb0, gb1);
-            uint2 e_a[4]; uint32_t in_a = 0u;
-            lookup(n4_a, tq_a, rowmask, e_a, in_a);
-            for (int kk = 0; kk < nkw; ++kk) {
-                // ---- rotate the pipeline
-                const uint32_t n4 = n4_a; const float4 g0 = ga0, g1 = ga1;
-                uint2 e[4]; const uint32_t inm = in_a; const uint2 tq = tq_a;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = e_a[j];
-                n4_a = n4_b; ga0 = gb0; ga1 = gb1; tq_a = tq_b;
-                if (kk + 2 < nkw) load_tree(wt, kk + 2, n4_b, gb0, gb1); else n4_b = 0xFFFFFFFFu;     // stage A
-                tq_b = tree_entry(kk + 2);
-                lookup(n4_a, tq_a, rowmask, e_a, in_a);                 // stage B (reads rt only: a table nobody writes during the row loop)
-                stage_c(wt * MT_WT_ROWS + lane * 4, ra, r1, bagmask, n4, g0, g1, e, inm, tq);   // stage C
-            }
-        }
+    if (!SPEC) {
         // ---- sparse sweep: the class trees [nkd, nk) of the workgroup, whose expanded parents hold < 1/MT_SPARSE_DIV of the rows.  Per class tree the wave
         // streams ONLY the node ids of its rows (1 B per row: sixteen rows per lane and step), tests them against the tree's 64-bit mask of
         // live nodes and collects the 4-row groups that hold a live row in a REGISTER of the wave (lanes [0, sp_cnt) hold pending groups; new
@@ -1083,19 +963,18 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                     const bool on = lane < nb;
                     const uint32_t g = pend;
                     const long long row0 = on ? (long long)g * 4 : row_lo;
-                    uint4 ra[4], r1[4]; uint32_t bagmask = BAG ? 0u : 0xFu, rowmask = 0u;
+                    uint4 ra[4], r1[4]; uint32_t bagmask = BAG ? 0u : 0xFu;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         long long rr = row0 + j; if (rr >= N) rr = N - 1;
                         ra[j] = rec_acc[rr]; r1[j] = make_uint4(0, 0, 0, 0);
                         if (BAG) bagmask |= (inbag[rr] ? 1u : 0u) << j;
-                        if (on && row0 + j < N) rowmask |= 1u << j;
                     }
                     const uint32_t n4 = on ? *reinterpret_cast<const uint32_t*>(nd_k + row0) : 0xFFFFFFFFu;     // (idle lanes: LV_INACTIVE, the dummy entry)
                     const float4 g0 = *reinterpret_cast<const float4*>(gh_k + row0), g1 = *reinterpret_cast<const float4*>(gh_k + row0 + 2);
-                    uint2 e[4]; uint32_t inm = 0u;
-                    lookup(n4, tq, rowmask, e, inm);
-                    stage_c(row0, ra, r1, bagmask, n4, g0, g1, e, inm, tq);
+                    uint2 e[4];
+                    lookup(n4, tq, e);
+                    stage_c(row0, ra, r1, bagmask, n4, g0, g1, e, tq);
                     sp_cnt = 0;
                 };
                 auto load16 = [&](long long st) __attribute__((always_inline)) -> uint4 {
