@@ -1002,7 +1002,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             bool acc2 = nchunk == 2 && sw.mt_acc2;
             if (acc2) {   // ... when one node's histograms of both chunks fit the LDS of the 768-thread workgroup (else: one pass per chunk, as for > 32 features)
                 const long long nb2 = ((long long)lv_slots(fmeta.data() + cmeta[0].first_feat, cmeta[0].nfeat, 0) + lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0) + MT_ROT_DUMMY) * 16;
-                if (nb2 > lc.lds_bytes - mt_fixed_bytes(MT_THREADS_ACC2, true, sw.mt_spec != 0)) acc2 = false;
+                if (nb2 > mt_hist_bytes(lc.lds_bytes, MT_THREADS_ACC2, true, sw.mt_spec != 0, cmeta[1].nfeat > 15 || wm)) acc2 = false;
             }
             if (wm && nchunk == 2 && !acc2) throw std::invalid_argument("a two-chunk table with row multiplicities needs the one-pass level form (the multiplicity rides in the second record)");
             for (int ch = 0; ch < (acc2 ? 1 : nchunk); ++ch) {
@@ -1011,7 +1011,9 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 if (acc2) node_bytes += (long long)lv_slots(fmeta.data() + cmeta[1].first_feat, cmeta[1].nfeat, 0) * 16;
                 const int mt_thr = acc2 ? MT_THREADS_ACC2 : ((nchunk == 1 && sw.mt_threads == 768 && sw.mt_spec != 1) ? 768 : LV_THREADS);
                 const bool spec = acc2 ? sw.mt_spec != 0 : (nchunk == 1 && sw.mt_spec == 1);
-                long long cap = (lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec)) / std::max<long long>(node_bytes, 1);
+                const bool li_arr = cmeta[acc2 ? 1 : ch].nfeat > 15 || wm;          // the ring needs a slot array (k_level_mt: !li_in_rec)
+                const long long hist_room = mt_hist_bytes(lc.lds_bytes, mt_thr, acc2, spec, li_arr);
+                long long cap = hist_room / std::max<long long>(node_bytes, 1);
                 cap = std::min<long long>(cap, MT_MAX_NODES);
                 if (cap < 1) throw std::invalid_argument("histogram of one node exceeds LDS");
                 const int win = (int)std::min<long long>(worst, cap);                    // built slots per launch
@@ -1032,10 +1034,10 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 // that fill at least three quarters of them)
                 const bool rot_full = cmeta[ch].nfeat >= 12 && (!acc2 || cmeta[1].nfeat >= 12);
                 const bool rot = plain1 && (sw.mt_rot == 1 || (sw.mt_rot < 0 && rot_full && cap * 2 < (long long)sw.mt_rot_copies2 * T * win)) &&
-                                 (long long)T * win * (node_bytes + mt_rot_dummy(true) * 16) <= lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec);
+                                 (long long)T * win * (node_bytes + mt_rot_dummy(true) * 16) <= hist_room;
                 // a rotated launch needs ONE copy: as many class trees per workgroup as the LDS holds (RGBM_MT_ROT_T=0: keep the T sized for replication)
                 if (rot && sw.mt_rot_T && sw.mt_T < 1) {
-                    const long long cap_rot = std::min<long long>((lc.lds_bytes - mt_fixed_bytes(mt_thr, acc2, spec)) / (node_bytes + mt_rot_dummy(true) * 16), MT_MAX_NODES);
+                    const long long cap_rot = std::min<long long>(hist_room / (node_bytes + mt_rot_dummy(true) * 16), MT_MAX_NODES);
                     T = (int)std::max<long long>(T, std::min<long long>(std::min<long long>(cap_rot / win, MT_MAX_T), std::min<long long>(K, MT_RT_BUDGET / (2 * worst))));
                 }
                 const int G = (K + T - 1) / T;
@@ -1060,6 +1062,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             for (auto& L : mt_plan[level]) L.gx = (int)gx;
             part_items = std::max(part_items, (size_t)K * (size_t)gx * (size_t)worst);
         }
+        if (sw.timing) for (int level = 1; level < p.max_depth; ++level) for (const auto& L : mt_plan[level])
+            fprintf(stderr, "[rgbm] level %d launch: chunk %d slots %d..%d route %d T %d G %d gx %d acc2 %d rot %d\n", level, L.ch, L.slot0, L.slot0 + L.nslots - 1, L.route, L.T, L.G, L.gx, L.acc2, L.rot);
         {
             size_t prog_words = 0;
             for (int level = 1; level < p.max_depth; ++level) for (const auto& L : mt_plan[level]) prog_words = std::max(prog_words, (size_t)L.G * (size_t)L.gx);

@@ -60,7 +60,7 @@ constexpr int MT_WT_ROWS = 256;              // rows of one wave tile: 4 consecu
 constexpr int MT_RING_PLAIN = MT_RING_N;           // entries of a wave's built-row ring: <= 63 waiting + <= 64 appended per row step (64: the waiting ones leave first)
 constexpr int MT_RING_SPEC = MT_RING_N < 128 ? 128 : MT_RING_N;    // wave-specialised pass: the consumer takes full batches only, so a ring holds two of them
 __host__ __device__ constexpr int mt_ring(bool spec) { return spec ? MT_RING_SPEC : MT_RING_PLAIN; }
-constexpr int MT_CNT_REP = 8;
+constexpr int MT_CNT_REP = 4;              // copies of a built node's row counter (one LDS atomic per ring entry)
 
 constexpr int MT_THREADS_ACC2 = 768;
 #ifndef MT_CONSUMERS_N
@@ -172,9 +172,21 @@ constexpr int LV_ROOT_FIXED = 256;
 // filter + one dense step (~430 with the gathers) per 64 groups of 4 rows that hold a live row, against ~330 per 256 rows tile by tile:
 // break-even near 18 % live rows
 constexpr long long MT_SPARSE_DIV = MT_SPARSE_DIV_N;
-__host__ __device__ constexpr long long mt_fixed_bytes(int threads, bool acc2, bool spec = false) {
+__host__ __device__ constexpr long long mt_fixed_bytes(int threads, bool acc2, bool spec = false, bool li = true /* the ring carries the built slot of an entry in an array of its own (a chunk with 16 features, rows with multiplicities) instead of in byte 15 of the record */) {
     return ((!acc2 && !spec) ? (long long)MT_MAX_T * 8 /* live-node masks of the sparse sweep */ : 0) + (long long)MT_MAX_T * 32 + MT_MAX_NODES + 16 + 512 + 256 + (long long)(MT_MAX_T + 2) * 8 + (long long)MT_MAX_RT * 8 + (long long)MT_MAX_NODES * MT_CNT_REP * 4 + (long long)MT_MAX_NODES * 8 +
-           (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * mt_ring(spec) * ((acc2 ? 32 : 16) + 8 + 2) + 256;     // (consumer waves have no ring)
+           (long long)(threads / 64 - (spec ? MT_CONSUMERS : 0)) * mt_ring(spec) * ((acc2 ? 32 : 16) + 8 + (li ? 2 : 0)) + 256;     // (consumer waves have no ring)
+}
+// distance in bytes between a slot's gradient sum and its hessian sum in the LDS of a level pass: a COMPILE-TIME constant per instantiation (the second atomic
+// of a pair is the first one's address register + an immediate offset), half of what the smaller fixed part (no slot array) leaves of the CU's LDS
+__host__ __device__ constexpr long long mt_hd(int threads, bool acc2, bool spec) { return ((LV_LDS_TOTAL - mt_fixed_bytes(threads, acc2, spec, false)) / 2) & ~15ll; }
+// bytes a level pass has for its histograms (both halves): the gradient half starts behind the fixed part and must end before the hessian half, which must end
+// inside the LDS; lds_bytes < LV_LDS_TOTAL is the test hook that forces several built-slot windows per level
+__host__ __device__ constexpr long long mt_hist_bytes(long long lds_bytes, int threads, bool acc2, bool spec, bool li) {
+    const long long fixed = mt_fixed_bytes(threads, acc2, spec, li), hd = mt_hd(threads, acc2, spec);
+    const long long room_h = (long long)LV_LDS_TOTAL - fixed - hd;
+    const long long x = hd < room_h ? hd : room_h;
+    const long long a = lds_bytes - fixed;
+    return a < 2 * x ? a : 2 * x;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,17 +417,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     uint4* ring_rec1_all = ring_rec_all + (ACC2 ? NRINGS * MT_RING : 0);                        // [waves][MT_RING] (two-chunk pass)
     uint2* ring_gh_all = reinterpret_cast<uint2*>(ring_rec1_all + NRINGS * MT_RING);            // [waves][MT_RING]
     uint16_t* ring_li_all = reinterpret_cast<uint16_t*>(ring_gh_all + NRINGS * MT_RING);        // [waves][MT_RING]
-    size_t off = reinterpret_cast<unsigned char*>(ring_li_all + NRINGS * MT_RING) - smem;
+    size_t off = reinterpret_cast<unsigned char*>(ring_li_all + (li_in_rec ? 0 : NRINGS * MT_RING)) - smem;      // (no slot array where the slot rides in the record: 4 KB more for histograms)
     off = (off + 15) & ~(size_t)15;
     unsigned long long* xmask = reinterpret_cast<unsigned long long*>(smem + off);            // [MT_MAX_T] sparse sweep: bit i = node base + i of the class tree is live
     if (!ACC2 && !SPEC) off += (size_t)MT_MAX_T * 8;                                            // (reserved for every plain pass: mt_fixed_bytes)
     unsigned long long* hist_g = reinterpret_cast<unsigned long long*>(smem + off);     // [total][spn] gradient sums; the hessian sums [total][spn] (see k_level_root) start
-    // MT_HD bytes further on: a COMPILE-TIME distance, half of what the instantiation's fixed part leaves of the CU's LDS, so that the second atomic of a
-    // (g, h) pair is the first one's address register with an immediate offset (one VALU per feature and batch less than with a run-time distance)
-    constexpr int MT_HD = (int)(((LV_LDS_TOTAL - mt_fixed_bytes(THREADS, ACC2, SPEC)) / 2) & ~15ll);
-    long long avail = (long long)c.lds_bytes - (long long)off;
-    if (avail > 2ll * MT_HD) avail = 2ll * MT_HD;
-    if (tid == 0 && (long long)off + 2ll * MT_HD > (long long)LV_LDS_TOTAL) atomicOr(err_flag, 2);     // (never: mt_fixed_bytes covers the carve-up above)
+    // MT_HD bytes further on (mt_hd: a compile-time distance, so that the second atomic of a (g, h) pair is the first one's address register with an immediate offset)
+    constexpr int MT_HD = (int)mt_hd(THREADS, ACC2, SPEC);
+    const long long avail = mt_hist_bytes(c.lds_bytes, THREADS, ACC2, SPEC, !li_in_rec);
+    if (tid == 0 && ((long long)off > mt_fixed_bytes(THREADS, ACC2, SPEC, !li_in_rec) || (long long)off + MT_HD + avail / 2 > (long long)LV_LDS_TOTAL)) atomicOr(err_flag, 2);     // (never: mt_fixed_bytes covers the carve-up above)
 
     // ---- the class trees of this workgroup and their built slots inside this launch's window
     if (tid < 64) {   // wave 0: lane kk reads the plan of class tree k0 + kk; exclusive prefix sums place its built slots and table entries
