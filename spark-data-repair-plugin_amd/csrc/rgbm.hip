@@ -571,10 +571,10 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // per launch where fewer than RGBM_MT_ROT_COPIES2 / 2 copies of its histograms fit the LDS -- the default --, never, every launch that has the
 // instantiation; RGBM_MT_ROT_T=0 keeps the replicated layout's class trees per workgroup), RGBM_MT_LOCK=<rounds> (lock-step of the class-tree groups
 // of a row block, wave-specialised pass), RGBM_JOINT_WIDE=1 (16-bit joint codes in the root pass), RGBM_FX_MEASURE=separate (the coarse gradient sums of
-// numerics v2.2 from a pass of their own instead of out of the gradient kernels), RGBM_TEST_HOOKS=1 + RGBM_FX_ROWS=R (TEST hook: the fixed-point grid of a
+// numerics v2.2 from a pass of their own instead of out of the gradient kernels), round 6: RGBM_DEFER_SCORE=1 (AddScore inside the next iteration's gradient kernel; slower, off), RGBM_TEST_HOOKS=1 + RGBM_FX_ROWS=R (TEST hook: the fixed-point grid of a
 // table of R rows; the oracle reads the same pair; a warning goes to stderr when it is active).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than mt_rot_copies2 / 2 = EIGHT copies of the launch's worst-case histograms (default), 0 = never, 1 = every pass that has the instantiation */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 16 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (16 = eight copies: every launch that cannot have the eight copies the replicated layout is sized for; round 5 had 6 -- the flat pipeline of round 6 moved the balance, profiles/r6r_*) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool fx_separate = false /* RGBM_FX_MEASURE=separate: the coarse sums behind every class tree's fixed-point grid come from a pass of their own over the (g, h) array (k_fx_measure) instead of out of the gradient kernels -- same sums, same models; the tests run both */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than mt_rot_copies2 / 2 = EIGHT copies of the launch's worst-case histograms (default), 0 = never, 1 = every pass that has the instantiation */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 16 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (16 = eight copies: every launch that cannot have the eight copies the replicated layout is sized for; round 5 had 6 -- the flat pipeline of round 6 moved the balance, profiles/r6r_*) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool defer_score = false /* RGBM_DEFER_SCORE=1: the level grower adds a tree's output to the scores inside the NEXT iteration's gradient kernel (PendingScore; k_level_last finishes routing + counts on the node ids alone) instead of in a pass of its own (k_level_final) -- same scores, same models; the tests run both.  Measured SLOWER (round 6, profiles/r7b_*: k_grad_mc 2.08 -> 3.91 ms per launch for 0.81 ms saved in the last pass; bench step 80.8 / 81.1 -> 83.1 / 83.3 ms): the gradient kernel is FP64-bound at 3.6 TB/s, the pass of its own streams at 4.7 TB/s -- the third fusion of these two that lost; off */; bool fx_separate = false /* RGBM_FX_MEASURE=separate: the coarse sums behind every class tree's fixed-point grid come from a pass of their own over the (g, h) array (k_fx_measure) instead of out of the gradient kernels -- same sums, same models; the tests run both */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -589,6 +589,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_SPEC")) w.mt_spec = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RGBM_MT_SPARSE")) w.mt_sparse = atoi(e) != 0;
     if (const char* e = getenv("RGBM_FX_MEASURE")) w.fx_separate = strcmp(e, "separate") == 0;
+    if (const char* e = getenv("RGBM_DEFER_SCORE")) w.defer_score = atoi(e) != 0;
     if (const char* e = getenv("RGBM_MT_LOCK")) w.mt_lock = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT")) w.mt_rot = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT_COPIES2")) w.mt_rot_copies2 = atoi(e);
@@ -1235,6 +1236,8 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
     };
 
     const int score_gx = (int)std::max<long long>(1, std::min<long long>((N + 1023) / 1024, (2048 + K - 1) / K));
+    const int last_gx = (int)std::max<long long>(1, std::min<long long>((N + 4095) / 4096, (2048 + K - 1) / K));      // k_level_last: 16 rows per thread and step
+    const bool defer_score = sw.defer_score;
     auto timed = [&](bool root, auto&& fn) {   // HIP events around one histogram launch, on the stream it is launched on
         hipEvent_t a = nullptr, b = nullptr;
         if (stats) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventRecord(a, s)); }
@@ -1354,6 +1357,11 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
             // last level: plan -> replay (leaf values never depend on the deepest counts) -> route + count + score in one pass
             hipLaunchKernelGGL(k_level_plan, dim3(K), dim3(256), 0, s, d_plan.p, d_snodes.p, d_lcand.p, d_fmeta.p, p.max_depth, tc, lc);
             hipLaunchKernelGGL(k_level_replay, dim3(K), dim3(64), 0, s, d_plan.p, d_snodes.p, cntg, to, d_init.p, d_ndelta.p, d_leafnode.p, d_any.p, d_err.p, d_it.p, tc);
+            // AddScore: the pass that routes, counts and adds in one (k_level_final).  RGBM_DEFER_SCORE=1 (measured slower, off): folded into the NEXT iteration's
+            // gradient kernel, with k_level_last for the last routing step + the deepest counts; the last iteration has no next one and keeps k_level_final
+            if (defer_score && cur_it + 1 < NE)
+                hipLaunchKernelGGL(k_level_last, dim3(last_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr, d_plan.p, to, d_count.p, d_it.p, lc);
+            else
             hipLaunchKernelGGL(k_level_final, dim3(score_gx, K), dim3(256), 0, s, d_rec.p, d_node.p, use_bagging ? d_inbag.p : (const uint8_t*)nullptr,
                                d_plan.p, to, d_ndelta.p, d_score.p, d_count.p, d_it.p, lc);
             if (dp) { hipLaunchKernelGGL(k_copy_i32, dim3(K), dim3(256), 0, s, d_count.p, d_count_g.p, (long long)K * 256); all_reduce(d_count_g.p, (size_t)K * 256, AR_I32, s); }
@@ -1375,13 +1383,16 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
         const uint8_t* inbag = use_bagging ? d_inbag.p : nullptr;
         uint8_t* node0 = level_mode ? d_node.p : nullptr;
         unsigned long long* qp = fx_fused ? d_qpart.p : nullptr;
-        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, tc);
+        // level grower: the AddScore of the previous iteration's trees rides in this kernel (PendingScore, rgbm_kernels.h)
+        PendingScore pd{nullptr, nullptr, nullptr, 0};
+        if (level_mode && defer_score && cur_it > 0) pd = PendingScore{d_node.p, d_ndelta.p, to.L + (size_t)(cur_it - 1) * K, lc.NS};
+        if (obj == 0) hipLaunchKernelGGL(k_grad<0>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, pd, tc);
         else if (mc_rows)
-            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, tc);
+            hipLaunchKernelGGL(k_grad_mc_rows<256>, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)K * 256 * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, pd, tc);
         else if (mc_tile)
-            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, tc);
-        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, (unsigned long long*)nullptr, d_mult, tc);
-        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, tc);
+            hipLaunchKernelGGL(k_grad_mc, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)(K * 64 + 320) * 8, s, d_score.p, d_ycol, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, pd, tc);
+        else if (obj == 1) hipLaunchKernelGGL(k_grad<1>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, (unsigned long long*)nullptr, d_mult, pd, tc);
+        else hipLaunchKernelGGL(k_grad<2>, dim3(grad_gx), dim3(256), 0, s, d_score.p, d_ycol, yv, cw, sw_, inbag, d_gh.p, node0, lc.NS, qp, d_mult, pd, tc);
         if (fx_fused) {
             const long long total = fx_parts * K * 2;
             const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(256, (total + 8191) / 8192));

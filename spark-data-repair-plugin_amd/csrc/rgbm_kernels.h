@@ -121,18 +121,39 @@ __global__ __launch_bounds__(256) void k_init_score(double* __restrict__ score, 
     for (int k = 0; k < K; ++k) score[(long long)k * N + i] = init[k];
 }
 
+// Level grower: AddScore of the PREVIOUS iteration's trees, folded into this iteration's gradient kernel (round 6).  The kernel reads every score anyway; with the final
+// node id of the row (1 B) and the tree's node -> delta table it adds the previous tree's output on the way, writes the score back and continues with the new
+// value -- the same double addition k_level_final made, on the same operands, so the scores (and everything after them) keep their bits.  k_level_final used to
+// read and write all K x N scores in a pass of its own (17 B per (row, class tree)); what is left of it is the last routing step + the deepest counts
+// (k_level_last: the node ids only).  node == nullptr: nothing pending (first iteration, leaf-wise grower, batched small fits).
+struct PendingScore {
+    const uint8_t* node;      // [K][NS] the node every row ended in (LV_INACTIVE = 255: the row takes no part, its score never changes)
+    const double* ndelta;     // [K][256] node -> Shrinkage * leaf output (k_level_replay)
+    const int32_t* L;         // [K] leaves of the previous iteration's trees: <= 1 = no split, no score change
+    long long NS;
+};
+
 // the rows first, first + stride, ... of one fit (k_grad: a grid-stride loop; k_small_grad: the same loop per fit of a batch)
 template <int OBJ>
-__device__ __forceinline__ void grad_rows(long long first, long long stride, const double* __restrict__ score, const int32_t* __restrict__ ycol,
+__device__ __forceinline__ void grad_rows(long long first, long long stride, const double* score /* (not restrict: the pending AddScore writes it) */, const int32_t* __restrict__ ycol,
                                           const double* __restrict__ y_value, const double* __restrict__ class_w,
                                           const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
                                           float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
                                           long long NS, const TrainConst& c,
                                           unsigned long long* qacc = nullptr /* OBJ != 1: this thread's sums of the coarse magnitudes of its (g, h) (numerics v2.2), or null */,
-                                          const uint8_t* __restrict__ mult = nullptr /* row multiplicities: a row's magnitudes count mult[row] times */) {
+                                          const uint8_t* __restrict__ mult = nullptr /* row multiplicities: a row's magnitudes count mult[row] times */,
+                                          const PendingScore pd = PendingScore{nullptr, nullptr, nullptr, 0}) {
     const long long N = c.N;
     for (long long i = first; i < N; i += stride) {
         const int y = ycol[i];
+        if (pd.node) {   // the previous iteration's AddScore (before the node ids are reset below)
+            double* sc = const_cast<double*>(score);
+            const int KK = (OBJ == 1) ? c.K : 1;
+            for (int k = 0; k < KK; ++k) {
+                const int n = pd.node[(long long)k * pd.NS + i];
+                if (n != 255 && pd.L[k] > 1) sc[(long long)k * N + i] += pd.ndelta[k * 256 + n];
+            }
+        }
         if (node0) {   // every training row restarts in node 0 (the root); all other rows never take part
             const int KK = (OBJ == 1) ? c.K : 1;
             const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
@@ -173,16 +194,16 @@ __device__ __forceinline__ void grad_rows(long long first, long long stride, con
 }
 
 template <int OBJ>
-__global__ __launch_bounds__(256) void k_grad(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+__global__ __launch_bounds__(256) void k_grad(double* score, const int32_t* __restrict__ ycol,
                                               const double* __restrict__ y_value, const double* __restrict__ class_w,
                                               const double* __restrict__ sample_w, const uint8_t* __restrict__ row_in_bag /* null = no bagging */,
                                               float2* __restrict__ gh, uint8_t* __restrict__ node0 /* level grower: node ids to reset, or null */,
                                               long long NS, unsigned long long* __restrict__ qpart /* OBJ != 1: [gridDim.x][2] coarse sums of this workgroup's (g, h), or null */,
-                                              const uint8_t* __restrict__ mult, TrainConst c) {
+                                              const uint8_t* __restrict__ mult, const PendingScore pd, TrainConst c) {
     unsigned long long acc[2] = {0ull, 0ull};
     const bool measure = OBJ != 1 && qpart != nullptr;
     grad_rows<OBJ>((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, score, ycol, y_value, class_w, sample_w, row_in_bag, gh, node0, NS, c,
-                   measure ? acc : nullptr, mult);
+                   measure ? acc : nullptr, mult, pd);
     if (measure) {
         __shared__ unsigned long long ws[4][2];
         const unsigned long long a0 = wave_sum_u64(acc[0]), a1 = wave_sum_u64(acc[1]);
@@ -260,12 +281,13 @@ __global__ __launch_bounds__(256) void k_fx_scale(unsigned long long* __restrict
 // (order-independent), exp(s_k - max) overwrites the tile, ONE wave adds the K terms of every row in class order (the
 // summation order of the numerics spec), and every wave finishes its own classes.  Same arithmetic, in the same order,
 // as k_grad<1>; 4x the waves per LDS byte of a thread-per-row layout, which is what an FP64-bound kernel needs.
-__global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+__global__ __launch_bounds__(256) void k_grad_mc(double* score, const int32_t* __restrict__ ycol,
                                                  const double* __restrict__ class_w, const double* __restrict__ sample_w,
                                                  const uint8_t* __restrict__ row_in_bag, float2* __restrict__ gh,
                                                  uint8_t* __restrict__ node0, long long NS,
                                                  unsigned long long* __restrict__ qpart /* [gridDim.x][K][2] coarse sums of this workgroup's (g, h) (numerics v2.2), or null */,
-                                                 const uint8_t* __restrict__ mult /* row multiplicities (<= 255: q * m stays below 2^32), or null */, TrainConst c) {
+                                                 const uint8_t* __restrict__ mult /* row multiplicities (<= 255: q * m stays below 2^32), or null */,
+                                                 const PendingScore pd, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem);          // [K][64]
     double* pmax = tile + (size_t)c.K * 64;                  // [4][64]
@@ -277,8 +299,19 @@ __global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ scor
     const long long ic = valid ? i : N - 1;
     double m = -INFINITY;
     const int y = ycol[ic];
+    if (pd.node) {   // with the previous iteration's AddScore on the way (this thread also resets the node ids of its (row, class tree) pairs below)
+        double* sc = score;
 #pragma unroll 4
-    for (int k = wv; k < K; k += 4) { const double v = score[(long long)k * N + ic]; tile[k * 64 + r] = v; if (v > m) m = v; }
+        for (int k = wv; k < K; k += 4) {
+            double v = score[(long long)k * N + ic];
+            const int n = pd.node[(long long)k * pd.NS + ic];
+            if (n != 255 && pd.L[k] > 1) { v += pd.ndelta[k * 256 + n]; if (valid) sc[(long long)k * N + i] = v; }
+            tile[k * 64 + r] = v; if (v > m) m = v;
+        }
+    } else {
+#pragma unroll 4
+        for (int k = wv; k < K; k += 4) { const double v = score[(long long)k * N + ic]; tile[k * 64 + r] = v; if (v > m) m = v; }
+    }
     pmax[wv * 64 + r] = m;
     if (node0 && valid) {   // every training row restarts in node 0 (the root); all other rows never take part
         const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;
@@ -328,12 +361,12 @@ __global__ __launch_bounds__(256) void k_grad_mc(const double* __restrict__ scor
 // Few classes (K < 16): one thread per row, the row's K scores parked in its own LDS column (no barrier); the
 // four-waves-per-row-block layout above would leave most of its waves idle.
 template <int R>
-__global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ score, const int32_t* __restrict__ ycol,
+__global__ __launch_bounds__(R) void k_grad_mc_rows(double* score, const int32_t* __restrict__ ycol,
                                                     const double* __restrict__ class_w, const double* __restrict__ sample_w,
                                                     const uint8_t* __restrict__ row_in_bag, float2* __restrict__ gh,
                                                     uint8_t* __restrict__ node0, long long NS,
                                                     unsigned long long* __restrict__ qpart /* [gridDim.x * R / 64][K][2] coarse sums of every wave's (g, h) (numerics v2.2), or null */,
-                                                    const uint8_t* __restrict__ mult, TrainConst c) {
+                                                    const uint8_t* __restrict__ mult, const PendingScore pd, TrainConst c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile0 = reinterpret_cast<double*>(smem);
     double* tile = tile0 + threadIdx.x;   // element k at tile[k * R]
@@ -345,8 +378,19 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(const double* __restrict__ s
     const long long ic = valid ? i : N - 1;
     const double* sp = score + ic;
     double wmax = -INFINITY;
+    if (pd.node) {   // with the previous iteration's AddScore on the way
+        double* sc = score + ic;
 #pragma unroll 4
-    for (int k = 0; k < K; ++k) { const double v = sp[(long long)k * N]; tile[k * R] = v; if (v > wmax) wmax = v; }
+        for (int k = 0; k < K; ++k) {
+            double v = sp[(long long)k * N];
+            const int n = pd.node[(long long)k * pd.NS + ic];
+            if (n != 255 && pd.L[k] > 1) { v += pd.ndelta[k * 256 + n]; if (valid) sc[(long long)k * N] = v; }
+            tile[k * R] = v; if (v > wmax) wmax = v;
+        }
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) { const double v = sp[(long long)k * N]; tile[k * R] = v; if (v > wmax) wmax = v; }
+    }
     const int y = ycol[ic];
     if (node0 && valid) {
         const uint8_t v = (y < 0) ? (uint8_t)255 : (uint8_t)0;

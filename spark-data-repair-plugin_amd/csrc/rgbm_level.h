@@ -1530,6 +1530,62 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_level_last: what is left of k_level_final when the score update rides in the next iteration's gradient kernel (PendingScore, rgbm_kernels.h): the
+// last DataPartition::Split -- the rows of the nodes expanded at depth max_depth - 1 move to their children, in place -- and the exact counts of those
+// children.  Reads the node ids (1 B per (row, class tree)) of the class trees that expanded anything at that depth, and the split byte of the rows concerned.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_last(const uint4* __restrict__ rec, uint8_t* __restrict__ node_all, const uint8_t* __restrict__ inbag,
+                                                    const LvPlan* __restrict__ plan, const TreeOut out, int32_t* __restrict__ count, const int32_t* __restrict__ itp, LevelConst c) {
+    const int it = *itp;
+    __shared__ uint32_t route0[256], route1[256];
+    __shared__ int32_t cnt[2 * LV_MAX_EXP * LV_CNT_REP];
+    const int k = blockIdx.y;
+    if (out.L[(long long)it * c.K + k] <= 1) return;   // no split
+    const LvPlan* pp = &plan[k];
+    if (pp->done) return;                              // plan(max_depth) expanded nothing: every row already sits in its leaf
+    const int n_exp = pp->n_exp, child_first = pp->child_first;
+    const int tid = threadIdx.x, lane = tid & 63;
+    route0[tid] = pp->route0[tid]; route1[tid] = pp->route1[tid];
+    for (int i = tid; i < 2 * n_exp * LV_CNT_REP; i += 256) cnt[i] = 0;
+    __syncthreads();
+    const long long N = c.N;
+    uint8_t* node = node_all + (long long)k * c.NS;
+    const uint8_t* rec8 = reinterpret_cast<const uint8_t*>(rec);
+    // 16 rows per thread and step (the node-id arrays are padded with LV_INACTIVE to whole wave tiles)
+    for (long long i = ((long long)blockIdx.x * 256 + tid) * 16; i < N; i += (long long)gridDim.x * 4096) {
+        uint4 v = *reinterpret_cast<const uint4*>(node + i);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        bool changed = false;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = (int)((w[d] >> (8 * j)) & 0xFFu);
+                const uint32_t w0 = route0[n];             // (LV_INACTIVE: never expanded)
+                if (w0 & (1u << 24)) {
+                    const long long row = i + d * 4 + j;
+                    const int f = (int)(w0 & 0xFFu), theta1 = (int)((w0 >> 8) & 0xFFu), nanbin = (int)((w0 >> 16) & 0xFFu);
+                    const int bin = (int)rec8[((long long)(f >> 4) * N + row) * 16 + (f & 15)];
+                    const bool left = (bin == nanbin) ? ((w0 >> 25) & 1u) != 0u : (bin < theta1);
+                    const uint32_t w1 = route1[n];
+                    const int nn = left ? (int)(w1 & 0xFFu) : (int)((w1 >> 8) & 0xFFu);
+                    if (!inbag || inbag[row]) atomicAdd(&cnt[(nn - child_first) * LV_CNT_REP + (lane & (LV_CNT_REP - 1))], c.has_mult ? (int)rec8[((long long)(c.nchunk - 1) * N + row) * 16 + 15] : 1);
+                    w[d] = (w[d] & ~(0xFFu << (8 * j))) | ((uint32_t)nn << (8 * j));
+                    changed = true;
+                }
+            }
+        }
+        if (changed) *reinterpret_cast<uint4*>(node + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    for (int ci = tid; ci < 2 * n_exp; ci += 256) {
+        int tot = 0;
+        for (int r2 = 0; r2 < LV_CNT_REP; ++r2) tot += cnt[ci * LV_CNT_REP + r2];
+        if (tot) atomicAdd(&count[(long long)k * 256 + child_first + ci], tot);
+    }
+}
+
 // leaf counts of the finished tree (Tree::leaf_count_), once every child count is final
 __global__ __launch_bounds__(LV_MAX_LEAVES) void k_level_leafcount(const LvPlan* __restrict__ plan, const int32_t* __restrict__ count,
                                                                    const int32_t* __restrict__ leaf_node, TreeOut out, const int32_t* __restrict__ itp, TrainConst c) {

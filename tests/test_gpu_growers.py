@@ -341,6 +341,41 @@ def test_grid_sums_out_of_the_gradient_kernels_equal_a_pass_of_their_own(rows, c
             assert blobs[0] == mo, {k: v for k, v in kw.items() if k not in ("class_weight", "y_value")}
 
 
+@pytest.mark.parametrize("rows,cols,tgt", [(600, 4, 2), (30000, 11, 10), (30000, 11, 5), (50000, 6, 0), (20000, 20, 7)])
+def test_score_update_inside_the_next_gradient_kernel_equals_a_pass_of_its_own(rows, cols, tgt, monkeypatch):
+    """AddScore of the level grower: by default a pass of its own after every iteration (k_level_final: the last routing step, the deepest counts and the
+    score update in one).  RGBM_DEFER_SCORE=1 (round 6; measured slower, kept as a switch) lets the NEXT iteration's gradient kernel add the output of an
+    iteration's trees (PendingScore in k_grad<0/1/2>, k_grad_mc, k_grad_mc_rows: the kernel reads every score anyway; k_level_last finishes the routing and
+    the deepest counts on the node ids alone).  The same double additions on the same operands: the model bytes must not depend on it -- binary / few-class / many-class / L2
+    targets, NULL target cells (rows that never take part), bagging (out-of-bag rows are routed and scored too), trees without a split, a
+    one-iteration job, two chunks -- and both equal the oracle's model."""
+    from oracle import oracle as O
+    from repair import _native as N
+    from tests.synth import make_table, balanced_weights
+    dirty, clean, cards = make_table(rows, cols, seed=37, null_ratio=0.03)
+    feats = [c for c in range(cols) if c != tgt]
+    K = int(cards[tgt])
+    tab = N.Table(dirty, cards)
+    yv = np.arange(K, dtype=np.float64) * 0.75 - 1.0
+    base = dict(objective=0 if K == 2 else 1, num_class=max(K, 2))
+    cases = [dict(base, class_weight=balanced_weights(dirty[tgt], K), n_estimators=9, learning_rate=0.2),
+             dict(base, class_weight=balanced_weights(dirty[tgt], K), n_estimators=7, learning_rate=0.2, bagging_fraction=0.6, bagging_freq=2),
+             dict(base, class_weight=None, n_estimators=5, min_data_in_leaf=rows),          # no tree can split
+             dict(base, class_weight=None, n_estimators=1),
+             dict(objective=2, y_value=yv, class_weight=None, n_estimators=7, learning_rate=0.3, num_leaves=50, min_data_in_leaf=5)]
+    r = dirty[tgt] >= 0
+    for ci, kw in enumerate(cases):
+        blobs = []
+        for v in ("1", "0"):
+            monkeypatch.setenv("RGBM_DEFER_SCORE", v)
+            blobs.append(tab.train(tgt, feats, **kw).save())
+        monkeypatch.delenv("RGBM_DEFER_SCORE")
+        assert blobs[0] == blobs[1], {k: v for k, v in kw.items() if k not in ("class_weight", "y_value")}
+        if ci in (0, 1, 4):
+            mo = O.train(np.ascontiguousarray(dirty[feats][:, r]), cards[feats], dirty[tgt][r], K, **kw).save()
+            assert blobs[0] == mo, {k: v for k, v in kw.items() if k not in ("class_weight", "y_value")}
+
+
 @pytest.mark.parametrize("rows,cols,tgt", [(40000, 11, 10), (30000, 11, 8), (25000, 24, 7), (60000, 16, 10), (40000, 32, 7)])
 def test_feature_rotation_of_the_level_pass_changes_nothing(rows, cols, tgt, monkeypatch):
     """The histogram updates of a level pass in rotated form (lane l works on feature (j + l) mod 16: rgbm_level.h, MT_ROT) -- chosen per launch
