@@ -506,7 +506,7 @@ def main():
                  "achieved": nbytes / max(ms, 1e-9) * 1e-6, "frac": nbytes / max(ms, 1e-9) * 1e-6 / HBM_PEAK_GBS}
             if name == "level":   # what a level pass streams by construction: 1 B node id + 8 B (g, h) of every (row, class tree) of its target
                 c["stream_bytes_per_launch"] = level_stream_bytes / nl
-                c["bound"] = "instruction issue: routing VALU + LDS atomics of a SIMD take turns (DESIGN 5); its HBM stream alone would take stream_bytes / ~5 TB/s"
+                c["bound"] = "the CU's LDS pipeline: 30 ds_add_u64 per built row + ring traffic (DESIGN 5: with two steps of loads in flight per wave neither the stream nor instruction issue binds); its HBM stream alone would take stream_bytes / ~5 TB/s"
                 if needed_level_rows:
                     c["needed_alg_bytes_per_launch"] = needed_level_rows * (cols - 1 + 8) / nl
                     c["frac_needed"] = needed_level_rows * (cols - 1 + 8) / max(ms, 1e-9) * 1e-6 / HBM_PEAK_GBS
