@@ -1027,7 +1027,7 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 const long long t_nodes = std::max<long long>(win, cap / rep_target);
                 int T = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(t_nodes / win, MT_MAX_T), std::min<long long>(K, MT_RT_BUDGET / (2 * worst))));
                 if (sw.mt_T >= 1) T = std::max(1, std::min(T, sw.mt_T));
-                // Feature rotation of the histogram updates (rgbm_level.h, MT_ROT) for the launches whose LDS holds fewer than three copies of their
+                // Feature rotation of the histogram updates (rgbm_level.h, MT_ROT) for the launches whose LDS holds fewer than eight copies (RGBM_MT_ROT_COPIES2 / 2) of their
                 // worst-case histograms -- the deepest dense levels, where rows of one cluster pile up on one address per feature: measured -11 % at
                 // level 5 of the K = 64 target and +35-60 % where there IS room for replicas (profiles/r5c_*), hence per launch.  Plain one-chunk pass only.
                 const bool plain1 = (!acc2 && nchunk == 1 && !spec && mt_thr == LV_THREADS) || (acc2 && spec);      // the two instantiations that exist with rotation

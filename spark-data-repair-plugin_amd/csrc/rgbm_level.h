@@ -142,7 +142,7 @@ __host__ __device__ inline int lv_slots(const FeatMeta* fm, int nfeat, int q) {
 // better than conflict-free: rows of a cluster hold the same bin, replica = lane index puts the lanes of an instruction on CONSECUTIVE 8-byte slots (no
 // bank conflict at all), while the rotated lanes land on pseudo-random banks -- and it wins where the LDS holds one or two copies: level 5 of K = 64
 // 3.93 -> 3.43 ms, of K = 32 2.41 -> 1.41, of K = 16 1.44 -> 0.82, and most levels of the two-chunk pass (a node's two histograms are 10 KB).  So rotation is a
-// TEMPLATE PARAMETER (ROTP) and the host picks it per launch: fewer than three copies of the launch's worst-case histograms fit -> rotate, and give the
+// TEMPLATE PARAMETER (ROTP) and the host picks it per launch: fewer than EIGHT copies (round 5: three; the flat pipeline of round 6 moved the balance towards many class trees per workgroup) of the launch's worst-case histograms fit -> rotate, and give the
 // workgroup as many class trees as one copy allows (rgbm.hip, RGBM_MT_ROT / RGBM_MT_ROT_COPIES2 / RGBM_MT_ROT_T).  Bench step 83.9 -> 80.5 ms (same box),
 // one rank's 12.5M x 32 shard 72.1 -> 64.1 ms.  -DMT_ROT=1 still rotates everything (the experiment).
 #ifndef MT_ROT
@@ -338,8 +338,9 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
 // of a row block in ONE workgroup.
 //
 // A lane owns 4 consecutive rows; their bin records are loaded ONCE and stay in registers while the lane walks the T class trees of
-// its workgroup.  Per class tree it reads one dword of node ids and the rows' float32 (g, h) (two dwordx4, requested two class trees
-// ahead), looks the (<= 2^(L-1)) nodes of the level up in an LDS route table, moves the rows to their children IN PLACE (changed
+// its workgroup.  Per class tree -- one STEP of the wave's flat software pipeline, which runs over all its (wave tile, class tree) pairs with
+// the loads of two further steps in flight (round 6: see "flat pipeline" below) -- it reads one dword of node ids and the rows' float32 (g, h)
+// (two dwordx4), takes every row's entry out of an LDS route table indexed by the node id itself, moves the rows to their children IN PLACE (changed
 // dwords only) and appends the rows that fall into a BUILT child -- record, (g, h), histogram slot -- to its wave's LDS ring.  Whenever
 // 64 entries wait, they are taken out as one FULL wave of histogram updates: (g, h) go onto the fixed-point grid and into the built
 // child's LDS histogram with two 64-bit atomics per feature.  A wave instruction of LDS atomics costs the same for 6 active lanes as
@@ -364,7 +365,7 @@ template <int NCHR /* records a row needs for ROUTING: 1, 2 (both in registers),
           bool ROUTE /* the first launch of a level: moves the rows to their children; later launches find the built rows by the final ids */,
           int THREADS /* 1024, or MT_THREADS_ACC2 */, bool ACC2 /* NCHR == 2 only: the histograms of BOTH chunks are accumulated by this launch */,
           bool SPEC /* wave-specialised: the last MT_CONSUMERS waves only run the batches (LDS atomics) out of the other waves' rings */,
-          bool ROTP = false /* feature rotation of the histogram updates (see MT_ROT): the host picks it for the launches whose LDS holds fewer than three copies of their worst-case histograms (RGBM_MT_ROT_COPIES2 = 6) */>
+          bool ROTP = false /* feature rotation of the histogram updates (see MT_ROT): the host picks it for the launches whose LDS holds fewer than eight copies of their worst-case histograms (RGBM_MT_ROT_COPIES2 = 16) */>
 __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict__ rec, const float2* __restrict__ gh, uint8_t* __restrict__ node /* [K][NS], in place */,
                                                          const uint8_t* __restrict__ inbag, const LvPlan* __restrict__ plan, HistBin* __restrict__ part,
                                                          int32_t* __restrict__ count, const FeatMeta* __restrict__ fmeta, const ChunkMeta* __restrict__ cmeta,

@@ -379,7 +379,7 @@ def test_score_update_inside_the_next_gradient_kernel_equals_a_pass_of_its_own(r
 @pytest.mark.parametrize("rows,cols,tgt", [(40000, 11, 10), (30000, 11, 8), (25000, 24, 7), (60000, 16, 10), (40000, 32, 7)])
 def test_feature_rotation_of_the_level_pass_changes_nothing(rows, cols, tgt, monkeypatch):
     """The histogram updates of a level pass in rotated form (lane l works on feature (j + l) mod 16: rgbm_level.h, MT_ROT) -- chosen per launch
-    where the LDS holds fewer than three copies of the level's histograms (RGBM_MT_ROT=-1, the default), never (0) or for every pass that has the
+    where the LDS holds fewer than eight copies of the level's histograms (RGBM_MT_ROT=-1, the default; three until round 6), never (0) or for every pass that has the
     instantiation (1) -- are the same exact integer sums in another order of atomics: the model bytes must not depend on it.  Many-class targets on
     one 16-byte record (deep levels rotate by default) and a two-chunk table (the wave-specialised pass: both records rotated), also with bagging
     and with a small LDS pool (several built-slot windows per level)."""
@@ -400,7 +400,7 @@ def test_feature_rotation_of_the_level_pass_changes_nothing(rows, cols, tgt, mon
             monkeypatch.delenv(k_)
         assert blobs[0] == blobs[1] == blobs[2], (kw, env)
         #  the DEFAULT per-launch policy only rotates chunks that fill >= 12 of their 16 feature slots: the 16-column table (15 features, K = 64:
-        # levels 4-5 hold fewer than three copies) and the 32-column one (16 + 15 features, wave-specialised two-chunk pass) are the shapes where "-1" really
+        # levels 2-6 hold fewer than eight copies) and the 32-column one (16 + 15 features, wave-specialised two-chunk pass) are the shapes where "-1" really
         # rotates some launches and not others -- held to the oracle as well
         if cols in (16, 32) and not kw:
             from oracle import oracle as O
