@@ -33,12 +33,13 @@ bench)
 final)
   ( time timeout 1500 python -m pytest tests -q -m gpu --durations=6 ) > $O/tests_gpu_full.log 2>&1; grep -E "passed|failed|error" $O/tests_gpu_full.log | tail -3 | tee $O/tests_gpu.log
   timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -i smoke | tail -1 | tee $O/smoke.log
-  timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1; J $O/bench_default.log $O/bench_steps20_warmup5.json; show $O/bench_steps20_warmup5.json
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_seq -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-full-job --concurrency 1 --roofline-steps 1 > $O/trace_seq.log 2>&1 )
-  f=$(find $O/trace_seq -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_steps10_seq_kernel_stats.csv; J $O/trace_seq.log $O/bench_steps10_seq.json
+  # (the PMC passes first: the bench line attaches profiles/traffic.json, which must describe THIS build)
   ALL=0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15
   for c in FETCH_SIZE WRITE_SIZE; do ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $GRAFT_REPO_ROOT/tools/probe.py --iters 1 --targets $ALL --stats 0 > $O/pmc_$c.log 2>&1 ); done
   python tools/make_traffic_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $tag > $O/traffic_json.log 2>&1; tail -4 $O/traffic_json.log
+  timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1; J $O/bench_default.log $O/bench_steps20_warmup5.json; show $O/bench_steps20_warmup5.json
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_seq -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-full-job --concurrency 1 --roofline-steps 1 > $O/trace_seq.log 2>&1 )
+  f=$(find $O/trace_seq -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_steps10_seq_kernel_stats.csv; J $O/trace_seq.log $O/bench_steps10_seq.json
   T8=0,1,2,3,4,5,6,7
   for c in FETCH_SIZE WRITE_SIZE; do ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc32_$c -- python $GRAFT_REPO_ROOT/tools/probe.py --rows 100000000 --cols 32 --seed 43 --parallel 1 --iters 1 --targets $T8 --stats 0 > $O/pmc32_$c.log 2>&1 ); done
   python tools/make_traffic_json.py $O/pmc32_FETCH_SIZE $O/pmc32_WRITE_SIZE ${tag}_100m32 --rows 100000000 --cols 32 --targets $T8 > $O/traffic32_json.log 2>&1; tail -4 $O/traffic32_json.log
