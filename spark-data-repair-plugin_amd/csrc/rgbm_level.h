@@ -919,12 +919,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                 long long q = 0;
                 auto step = [&](TS& cur, TS& nxt, TS& in) __attribute__((always_inline)) {
                     if (SPEC && lock && kk_c == 0) lock_step((uint32_t)((wt_c - my_first) / NPROD));
-                    if (cross) {      // (before this step's loads are requested: what has to have arrived is at least a step old)
+                    load_tree(wt_l, kk_l, in.n4, in.g0, in.g1);                              // step q + 2 (past the end: the last step once more, never used)
+                    if (cross) {      // (AFTER this step's loads have been requested: the wait in front of these copies then lets those three stay in flight -- in front
+                                      // of them it was a vmcnt(0) at every tile boundary, i.e. at every step or second step of the deep levels, where T is 1 or 2)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { ra[j] = rn[j]; r1[j] = r1n[j]; }
                         bagmask = bagmask_n;
                     }
-                    load_tree(wt_l, kk_l, in.n4, in.g0, in.g1);                              // step q + 2 (past the end: the last step once more, never used)
                     if (kk_c == 0 && wt_c + NPROD < wt_hi) load_rec(wt_c + NPROD, rn, r1n, bagmask_n);     // (uniform) first step of a wave tile: the records of the wave's next tile
                     const uint2 tq_c = tree_entry(kk_c);
                     const bool live = (tq_c.x >> 31) != 0u;                                  // (scalar) else: the class tree is finished or has nothing to split at this level
