@@ -574,7 +574,7 @@ void find_bin(const unsigned int* cnt, int32_t n_codes, int64_t n_train, const r
 // numerics v2.2 from a pass of their own instead of out of the gradient kernels), round 6: RGBM_DEFER_SCORE=1 (AddScore inside the next iteration's gradient kernel; slower, off), RGBM_TEST_HOOKS=1 + RGBM_FX_ROWS=R (TEST hook: the fixed-point grid of a
 // table of R rows; the oracle reads the same pair; a warning goes to stderr when it is active).
 constexpr int LV_THREADS_DEFAULT = 1024;
-struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than mt_rot_copies2 / 2 = EIGHT copies of the launch's worst-case histograms (default), 0 = never, 1 = every pass that has the instantiation */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; int mt_rot_tdiv = 1 /* RGBM_MT_ROT_TDIV=d: a rotated launch takes 1/d of the class trees one copy would allow and replicates with the rest (measured: see profiles/EXPERIMENTS.md) */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 16 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (16 = eight copies: every launch that cannot have the eight copies the replicated layout is sized for; round 5 had 6 -- the flat pipeline of round 6 moved the balance, profiles/r6r_*) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool defer_score = false /* RGBM_DEFER_SCORE=1: the level grower adds a tree's output to the scores inside the NEXT iteration's gradient kernel (PendingScore; k_level_last finishes routing + counts on the node ids alone) instead of in a pass of its own (k_level_final) -- same scores, same models; the tests run both.  Measured SLOWER (round 6, profiles/r7b_*: k_grad_mc 2.08 -> 3.91 ms per launch for 0.81 ms saved in the last pass; bench step 80.8 / 81.1 -> 83.1 / 83.3 ms): the gradient kernel is FP64-bound at 3.6 TB/s, the pass of its own streams at 4.7 TB/s -- the third fusion of these two that lost; off */; bool fx_separate = false /* RGBM_FX_MEASURE=separate: the coarse sums behind every class tree's fixed-point grid come from a pass of their own over the (g, h) array (k_fx_measure) instead of out of the gradient kernels -- same sums, same models; the tests run both */; };
+struct RunSwitches { int grower = 0; int lv_lds = 0; long long lv_blocks = 0; long long mt_blocks = 0; int mt_T = 0; int mt_rep = MT_ROT ? 4 : 8 /* replicas the level passes are sized for: under feature rotation four resolve every conflict */; bool joint_root = true; bool timing = false; bool mt_acc2 = true; int mt_threads = LV_THREADS_DEFAULT; int mt_spec = -1 /* -1: wave-specialised pass for two-chunk tables only (measured) */; bool mt_sparse = true /* class trees with < 1/MT_SPARSE_DIV (= 1/16) live rows are swept through their node ids */; int mt_rot = -1 /* RGBM_MT_ROT: feature rotation of the level pass atomics: -1 = where the LDS holds fewer than mt_rot_copies2 / 2 = EIGHT copies of the launch's worst-case histograms (default), 0 = never, 1 = every pass that has the instantiation */; bool joint_wide = false /* RGBM_JOINT_WIDE=1: 16-bit joint codes in the root pass (groups of <= 1024 joint bins, 10 atomics per row instead of 14 on the synthetic table): measured neutral (the two copies that fit conflict more), off */; int mt_rot_tmin = 2 /* RGBM_MT_ROT_TMIN: a launch whose replicated layout holds fewer class trees per workgroup than this (2: a single one) rotates when one copy holds at least twice as many (0 = off).  Measured (profiles/EXPERIMENTS.md, r7m / r7n): 0 / 2 / 4: bench step 80.4-80.8 / 80.0-80.1 / 80.8-81.2 ms, roofline frac 0.196 / 0.200 / 0.200 */; int mt_rot_tdiv = 1 /* RGBM_MT_ROT_TDIV=d: a rotated launch takes 1/d of the class trees one copy would allow and replicates with the rest (measured: see profiles/EXPERIMENTS.md) */; bool mt_rot_T = true /* RGBM_MT_ROT_T=0: rotated launches keep the class trees per workgroup of the replicated layout */; int mt_rot_copies2 = 16 /* RGBM_MT_ROT_COPIES2: twice the number of plain copies of a launch's histograms below which it rotates (16 = eight copies: every launch that cannot have the eight copies the replicated layout is sized for; round 5 had 6 -- the flat pipeline of round 6 moved the balance, profiles/r6r_*) */; int mt_lock = -1 /* RGBM_MT_LOCK=<tile rounds>: lock-step window of the class-tree groups of a row block in the wave-specialised pass; -1 / 0 = off (default) */; bool defer_score = false /* RGBM_DEFER_SCORE=1: the level grower adds a tree's output to the scores inside the NEXT iteration's gradient kernel (PendingScore; k_level_last finishes routing + counts on the node ids alone) instead of in a pass of its own (k_level_final) -- same scores, same models; the tests run both.  Measured SLOWER (round 6, profiles/r7b_*: k_grad_mc 2.08 -> 3.91 ms per launch for 0.81 ms saved in the last pass; bench step 80.8 / 81.1 -> 83.1 / 83.3 ms): the gradient kernel is FP64-bound at 3.6 TB/s, the pass of its own streams at 4.7 TB/s -- the third fusion of these two that lost; off */; bool fx_separate = false /* RGBM_FX_MEASURE=separate: the coarse sums behind every class tree's fixed-point grid come from a pass of their own over the (g, h) array (k_fx_measure) instead of out of the gradient kernels -- same sums, same models; the tests run both */; };
 RunSwitches read_switches() {
     RunSwitches w;
     if (const char* e = getenv("RGBM_GROWER")) w.grower = strcmp(e, "leafwise") == 0 ? 2 : (strcmp(e, "level") == 0 ? 1 : 0);
@@ -594,6 +594,7 @@ RunSwitches read_switches() {
     if (const char* e = getenv("RGBM_MT_ROT")) w.mt_rot = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT_COPIES2")) w.mt_rot_copies2 = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT_TDIV")) w.mt_rot_tdiv = std::max(1, atoi(e));
+    if (const char* e = getenv("RGBM_MT_ROT_TMIN")) w.mt_rot_tmin = atoi(e);
     if (const char* e = getenv("RGBM_MT_ROT_T")) w.mt_rot_T = atoi(e) != 0;
     if (const char* e = getenv("RGBM_JOINT_WIDE")) w.joint_wide = atoi(e) != 0;
     w.timing = getenv("RGBM_TIMING") != nullptr;
@@ -1035,7 +1036,12 @@ rgbm_model* train_core(const rgbm_table& tab, int32_t target_col, const int32_t*
                 // (a rotated step works on sixteen feature slots per chunk whatever the chunk holds: with few features most lanes of a step idle -- rotate only chunks
                 // that fill at least three quarters of them)
                 const bool rot_full = cmeta[ch].nfeat >= 12 && (!acc2 || cmeta[1].nfeat >= 12);
-                const bool rot = plain1 && (sw.mt_rot == 1 || (sw.mt_rot < 0 && rot_full && cap * 2 < (long long)sw.mt_rot_copies2 * T * win)) &&
+                // ... and (round 6) where the replicated layout would leave the workgroup fewer than RGBM_MT_ROT_TMIN (2: a single one) class trees although one copy holds at least twice
+                // as many: every doubling of the class trees per workgroup is ~5 % of a deep level (the records are read once per T steps), which eight copies do not buy back
+                const long long cap_rot1 = std::min<long long>(hist_room / (node_bytes + mt_rot_dummy(true) * 16), MT_MAX_NODES);
+                const long long T_rot1 = std::min<long long>(std::min<long long>(cap_rot1 / win, MT_MAX_T), std::min<long long>(K, MT_RT_BUDGET / (2 * worst)));
+                const bool few_trees = T < sw.mt_rot_tmin && T_rot1 >= 2 * (long long)T;
+                const bool rot = plain1 && (sw.mt_rot == 1 || (sw.mt_rot < 0 && rot_full && (cap * 2 < (long long)sw.mt_rot_copies2 * T * win || few_trees))) &&
                                  (long long)T * win * (node_bytes + mt_rot_dummy(true) * 16) <= hist_room;
                 // a rotated launch needs ONE copy: as many class trees per workgroup as the LDS holds (RGBM_MT_ROT_T=0: keep the T sized for replication)
                 if (rot && sw.mt_rot_T && sw.mt_T < 1) {
