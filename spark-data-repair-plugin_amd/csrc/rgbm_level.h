@@ -467,11 +467,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         // not, the pass would silently drop rows: the training call fails instead (err_flag bit 1)
         const bool ok = total <= MT_MAX_NODES && rt_total <= MT_MAX_RT;
         if (!ok) { t.live = 0; t.nb = 0; t.nlev = 0; if (lane == 0) atomicOr(err_flag, 2); }
-        // the workgroup's class trees in LDS: the dense ones first, then the sparse ones (the row loop walks [0, nkd), the sparse sweep [nkd, nk))
-        const unsigned long long dmask = __ballot(lane < nk && !sparse_t), smask = __ballot(lane < nk && sparse_t);
-        const int nkd_ = __popcll(dmask);
+        // the workgroup's class trees in LDS: the live dense ones first, then the sparse ones, then the ones that are finished or have nothing to split at this
+        // level (the row loop walks [0, nkd), the sparse sweep [nkd, nke); a finished class tree is not streamed at all: neither its node ids nor its (g, h))
+        const bool dead_t = lane < nk && (!t.live || (!route && t.nb == 0));       // (a later launch of a level: also a class tree with no built child in this launch's window)
+        const unsigned long long dmask = __ballot(lane < nk && !sparse_t && !dead_t), smask = __ballot(lane < nk && sparse_t && !dead_t), zmask = __ballot(dead_t);
+        const int nkd_ = __popcll(dmask), nks_ = __popcll(smask);
         const unsigned long long below = (1ull << lane) - 1ull;
-        const int pos = lane >= nk ? lane : (sparse_t ? nkd_ + __popcll(smask & below) : __popcll(dmask & below));
+        const int pos = lane >= nk ? lane : (dead_t ? nkd_ + nks_ + __popcll(zmask & below) : (sparse_t ? nkd_ + __popcll(smask & below) : __popcll(dmask & below)));
         if (lane < nk) ti[pos] = t;
         tpk[pos] = make_uint2((uint32_t)t.base | (uint32_t)t.nlev << 8 | (uint32_t)(ntab > 0 ? ntab - 1 : 0) << 17 | (t.live && lane < nk ? 1u << 31 : 0u), (uint32_t)t.rt_off | (uint32_t)t.k << 16);
         if (lane < 2) tpk[64 + lane] = make_uint2(0u, 0u);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
             while (s > 0 && (long long)tot * (mt_slots(fm, nfeat, s, ROT) + (ACC2 ? mt_slots(fm1, nfeat1, s, ROT) : 0) + mt_rot_dummy(ROT)) * 16 > avail) --s;
             const int spn0 = mt_slots(fm, nfeat, s, ROT) + (ACC2 ? mt_slots(fm1, nfeat1, s, ROT) : 0) + mt_rot_dummy(ROT);
             if ((long long)tot * spn0 * 16 > avail) atomicOr(err_flag, 2);          // (the host's window sizing guarantees the plain layout fits)
-            scal[0] = tot; scal[1] = s; scal[2] = spn0; scal[3] = ((ok && livem != 0ull) ? 1 : 0) | (ok ? nkd_ : nk) << 8;
+            scal[0] = tot; scal[1] = s; scal[2] = spn0; scal[3] = ((ok && livem != 0ull) ? 1 : 0) | nkd_ << 8 | (nkd_ + nks_) << 16;
         }
     }
     __syncthreads();
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     // wave-uniform from here on: in SGPRs, so that everything derived from them (shifts, strides) is scalar as well
     const int total = __builtin_amdgcn_readfirstlane(scal[0]), s = __builtin_amdgcn_readfirstlane(scal[1]), spn = __builtin_amdgcn_readfirstlane(scal[2]);
     if (!route && total == 0) return;
-    const int nkd = SPARSE ? __builtin_amdgcn_readfirstlane(scal[3] >> 8) : nk;       // dense class trees: [0, nkd)
+    const int nkd = __builtin_amdgcn_readfirstlane((scal[3] >> 8) & 0xFF), nke = __builtin_amdgcn_readfirstlane((scal[3] >> 16) & 0xFF);       // live dense class trees: [0, nkd), sparse ones: [nkd, nke)
     for (int kk = 0; kk < nk; ++kk) {
         const MtTree t = ti[kk];
         const LvPlan* pp = &plan[t.k];
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
                     const uint32_t f = w0 & 0xFFu;
                     e = make_uint2((NCHR == 0 ? f : (f & 7u) | ((f >> 4) & 1u) << 30 | ((f >> 3) & 1u) << 31) | thr << 8 | offb << 16 | 1u << 24,
                                    (w1 & 0xFFu) | (lb ? (uint32_t)(t.slot0 + ls) : 0xFFu) << 8 | ((w1 >> 8) & 0xFFu) << 16 | (rbb ? (uint32_t)(t.slot0 + rs) : 0xFFu) << 24);
-                    if (SPARSE && kk >= nkd && n - t.base < 64) atomicOr(&xmask[kk], 1ull << (n - t.base));
+                    if (SPARSE && kk >= nkd && kk < nke && n - t.base < 64) atomicOr(&xmask[kk], 1ull << (n - t.base));
                 } else {
                     const uint32_t self = i < ntab_k - 1 ? (uint32_t)n : (uint32_t)LV_INACTIVE;
                     e = make_uint2(0u, self | 0xFF00u | self << 16 | 0xFF000000u);
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
     auto tree_entry = [&](int kk) __attribute__((always_inline)) -> uint2 {       // (of the trees the row loop walks: the dense ones in a plain pass)
         const int kc = kk < 64 ? kk : 63;
         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.x, kc), y = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.y, kc);
-        return kk < (SPARSE ? nkd : nk) ? make_uint2(x, y) : make_uint2(0u, 0u);
+        return kk < nkd ? make_uint2(x, y) : make_uint2(0u, 0u);
     };
 
     // one FULL (or final, partial) wave of histogram updates from the ring
@@ -892,7 +894,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         // in step q + 1 (node ids: the route lookup) / q + 2 (g, h): two whole steps in flight, also across wave tiles; the records of the next tile
         // are requested when the last class tree of a tile has been routed.
     if (wave < NPROD) {
-        const int nkw = (!SPEC && SPARSE) ? nkd : nk;          // class trees walked tile by tile (the sparse ones are swept below)
+        const int nkw = nkd;          // class trees walked tile by tile (the sparse ones are swept below, the finished ones not at all)
         {
             // (the wave index through readfirstlane: tile numbers, step counters and everything derived from them are then SCALAR -- as a VGPR value
             // the compiler keeps the whole step bookkeeping in 64-bit VALU operations)
@@ -951,17 +953,17 @@ __global__ __launch_bounds__(THREADS, 1) void k_level_mt(const uint4* __restrict
         }
     }
     if (!SPEC) {
-        // ---- sparse sweep: the class trees [nkd, nk) of the workgroup, whose expanded parents hold < 1/MT_SPARSE_DIV of the rows.  Per class tree the wave
+        // ---- sparse sweep: the class trees [nkd, nke) of the workgroup, whose expanded parents hold < 1/MT_SPARSE_DIV of the rows.  Per class tree the wave
         // streams ONLY the node ids of its rows (1 B per row: sixteen rows per lane and step), tests them against the tree's 64-bit mask of
         // live nodes and collects the 4-row groups that hold a live row in a REGISTER of the wave (lanes [0, sp_cnt) hold pending groups; new
         // ones are pushed to the next free lanes with one ds_permute: no LDS memory -- 8 KB of rings cost the K = 64 passes 5 % through the
         // histograms' replication, profiles/r05d_*); 64 such groups are one dense step: every lane
         // fetches its group's records, node ids and (g, h) and goes through the same lookup + route + append code as the row loop.  A pass
         // over a class tree with 1 % live rows costs its node-id stream instead of records + (g, h) + ~330 instructions per 256 rows.
-        if (SPARSE && nkd < nk) {
+        if (SPARSE && nkd < nke) {
             const long long row_lo = wt_lo * MT_WT_ROWS, row_hi = (wt_hi * MT_WT_ROWS < N) ? wt_hi * MT_WT_ROWS : N;
             const long long nst = (wt_hi * MT_WT_ROWS - row_lo + 1023) / 1024;        // super tiles of 1024 rows (the block's rows are whole wave tiles)
-            for (int kk = nkd; kk < nk; ++kk) {
+            for (int kk = nkd; kk < nke; ++kk) {
                 const uint32_t tq0 = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.x, kk < 64 ? kk : 63), tq1 = (uint32_t)__builtin_amdgcn_readlane((int)tpk_v.y, kk < 64 ? kk : 63);
                 const uint2 tq = make_uint2(tq0, tq1);
                 const uint32_t base = tq0 & 0xFFu, nlev = (tq0 >> 8) & 0x1FFu;
