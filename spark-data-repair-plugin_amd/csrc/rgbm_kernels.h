@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_grad_mc(double* score, const int32_t* _
         }
     } else {
 #pragma unroll 4
-        for (int k = wv; k < K; k += 4) { const double v = score[(long long)k * N + ic]; tile[k * 64 + r] = v; if (v > m) m = v; }
+        for (int k = wv; k < K; k += 4) { const double v = __builtin_nontemporal_load(score + (long long)k * N + ic); tile[k * 64 + r] = v; if (v > m) m = v; }      // (read once per iteration)
     }
     pmax[wv * 64 + r] = m;
     if (node0 && valid) {   // every training row restarts in node 0 (the root); all other rows never take part
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_grad_mc(double* score, const int32_t* _
         if (on) {
             const double pk = tile[k * 64 + r] / wsum;
             const float g32 = (float)(((y == k) ? (pk - 1.0) : pk) * wi), h32 = (float)(c.factor * pk * (1.0 - pk) * wi);
-            gh[(long long)k * c.NG + i] = make_float2(g32, h32);
+            { typedef float v2f __attribute__((ext_vector_type(2))); v2f gv; gv.x = g32; gv.y = h32; __builtin_nontemporal_store(gv, reinterpret_cast<v2f*>(gh + (long long)k * c.NG + i)); }
             if (qpart) packed = __hiloint2double((int)(mrow * fx_coarse(h32, c.fx.c_h)), (int)(mrow * fx_coarse(g32, c.fx.c_g)));
         }
         // numerics v2.2: the tile entry of (k, r) is dead once pk is known -- it takes the coarse magnitudes of this (row, class tree)
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(double* score, const int32_t
         }
     } else {
 #pragma unroll 4
-        for (int k = 0; k < K; ++k) { const double v = sp[(long long)k * N]; tile[k * R] = v; if (v > wmax) wmax = v; }
+        for (int k = 0; k < K; ++k) { const double v = __builtin_nontemporal_load(sp + (long long)k * N); tile[k * R] = v; if (v > wmax) wmax = v; }
     }
     const int y = ycol[ic];
     if (node0 && valid) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(R) void k_grad_mc_rows(double* score, const int32_t
         for (int kk = 0; kk < K; ++kk) {
             const double pk = tile[kk * R] / wsum;
             const float g32 = (float)(((y == kk) ? (pk - 1.0) : pk) * wi), h32 = (float)(c.factor * pk * (1.0 - pk) * wi);
-            gh[(long long)kk * c.NG + i] = make_float2(g32, h32);
+            { typedef float v2f __attribute__((ext_vector_type(2))); v2f gv; gv.x = g32; gv.y = h32; __builtin_nontemporal_store(gv, reinterpret_cast<v2f*>(gh + (long long)kk * c.NG + i)); }
             // numerics v2.2: the dead tile entry takes the coarse magnitudes (bits 0..31: |g|, bits 32..63: h)
             if (qpart) tile[kk * R] = __hiloint2double((int)(mrow * fx_coarse(h32, c.fx.c_h)), (int)(mrow * fx_coarse(g32, c.fx.c_g)));
         }

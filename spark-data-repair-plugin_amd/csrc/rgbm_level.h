@@ -284,9 +284,11 @@ __global__ __launch_bounds__(LV_THREADS, 1) void k_level_root(const uint4* __res
         for (int q = 0; q < RPT; ++q) {
             const unsigned o = (unsigned)(q * LV_THREADS + tid);
             const unsigned oc = o < lim ? o : lim;
-            const int nv = (int)(node_in + pb)[oc];
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const int nv = (int)__builtin_nontemporal_load(node_in + pb + oc);          // (node ids and (g, h): read once per iteration; the records are re-read by the other class trees)
             fr[q] = (recc + pb)[oc];
-            fg[q] = (ghk + pb)[oc];
+            const v2f gv = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(ghk + pb + oc));
+            fg[q] = make_float2(gv.x, gv.y);
             fn[q] = (tv && o <= lim) ? nv : LV_INACTIVE;
         }
     };
@@ -1487,8 +1489,11 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
     const bool aligned16 = (((unsigned long long)sk) & 15ull) == 0ull;   // uniform
     for (long long i = ((long long)blockIdx.x * 256 + tid) * 4; i < N; i += (long long)gridDim.x * 1024) {
         if (i + 3 < N && aligned16) {
-            const uint32_t n4 = *reinterpret_cast<const uint32_t*>(node + i);
-            double2 s01 = *reinterpret_cast<const double2*>(sk + i), s23 = *reinterpret_cast<const double2*>(sk + i + 2);
+            // (non-temporal: every score is read and written once per iteration -- 19 GB per step of the 10M x 16 job that would otherwise push the bin records the
+            // level passes of the other targets in flight re-read out of the L2)
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const uint32_t n4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(node + i));
+            v2d s01 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(sk + i)), s23 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(sk + i + 2));
             if (n4 == 0xFFFFFFFFu) continue;
             double sv[4] = {s01.x, s01.y, s23.x, s23.y};
 #pragma unroll
@@ -1508,7 +1513,7 @@ __global__ __launch_bounds__(256) void k_level_final(const uint4* __restrict__ r
                 sv[j] += nd[n];
             }
             s01.x = sv[0]; s01.y = sv[1]; s23.x = sv[2]; s23.y = sv[3];
-            *reinterpret_cast<double2*>(sk + i) = s01; *reinterpret_cast<double2*>(sk + i + 2) = s23;
+            __builtin_nontemporal_store(s01, reinterpret_cast<v2d*>(sk + i)); __builtin_nontemporal_store(s23, reinterpret_cast<v2d*>(sk + i + 2));
             continue;
         }
         for (long long row = i; row < N && row < i + 4; ++row) {
